@@ -1,0 +1,172 @@
+/*
+ * dmz_oracle.h -- CPU ORACLE for the card.io-dmz per-frame scan hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT THE PRODUCT.  It is a plain-C restatement of
+ * the reference algorithm (each function cites the /root/reference file:line it
+ * follows).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it, and only as the checker / reported baseline.  The shipped
+ * path (card.io-dmz_amd/csrc) never links or calls anything in oracle/.
+ *
+ * Parity pinning (see DESIGN.md "Oracle"):
+ *   pinned   : the six model forward passes against the reference's embedded
+ *              known-answer vectors (tests/golden/model_kats.npz, 1e-5), and --
+ *              when oracle/_ref was built in the build container -- geometry,
+ *              homography (Eigen HouseholderQR), vseg box-sum, hseg search and
+ *              Luhn against the reference's own compiled code (bit-exact).
+ *   UNPINNED : every stage whose arithmetic lives in un-vendored OpenCV 2.4
+ *              (cvSobel, cvWarpPerspective, cvMorphologyEx, cvResize,
+ *              cvNormalize, cvConvertScale, cvReduce) or needs an OpenCV
+ *              library symbol to run (Canny, Hough, equalize-hist: cvGetMat /
+ *              cvGetSize).  Those are restated from the in-tree source and the
+ *              published OpenCV 2.4 semantics; no
+ *              reference fixture exists for them => "parity unpinned".
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off; no FMA, IEEE semantics)
+ */
+#ifndef DMZ_ORACLE_H
+#define DMZ_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_CARD_W 428
+#define ORC_CARD_H 270
+#define ORC_NUM_W 19
+#define ORC_NUM_H 27
+
+/* ---- weights blob (card.io-dmz_amd/weights/dmz_models.bin, after the 16-byte
+ * header): float offsets, same order as tools/extract_models.py writes ------- */
+enum {
+  ORC_W_VSEG_W1 = 0,                         /* 50x204 */
+  ORC_W_VSEG_B1 = ORC_W_VSEG_W1 + 50 * 204,  /* 50 */
+  ORC_W_VSEG_W2 = ORC_W_VSEG_B1 + 50,        /* 3x50 */
+  ORC_W_VSEG_B2 = ORC_W_VSEG_W2 + 150,       /* 3 */
+  ORC_W_DIGIT0 = ORC_W_VSEG_B2 + 3,          /* 3 models x 10682 */
+  ORC_DIGIT_CONV_W = 0,                      /* 8x3x3 */
+  ORC_DIGIT_CONV_B = 72,                     /* 8 */
+  ORC_DIGIT_HID_W = 80,                      /* 32x320 */
+  ORC_DIGIT_HID_B = 80 + 10240,              /* 32 */
+  ORC_DIGIT_LOG_W = 80 + 10240 + 32,         /* 10x32 */
+  ORC_DIGIT_LOG_B = 80 + 10240 + 32 + 320,   /* 10 */
+  ORC_DIGIT_STRIDE = 80 + 10240 + 32 + 320 + 10, /* 10682 */
+  ORC_W_SLASH = ORC_W_DIGIT0 + 3 * ORC_DIGIT_STRIDE, /* 80x176,80,2x80,2 */
+  ORC_W_EXPIRY = ORC_W_SLASH + 80 * 176 + 80 + 160 + 2,
+  ORC_W_TOTAL = ORC_W_EXPIRY + 1250 + 50 + 50000 + 40 + 21120 + 176 + 1760 + 10
+};
+
+/* Install the weight blob (pointer must stay valid). */
+void orc_set_weights(const float *blob);
+
+/* ---- per-frame result record: field-for-field the layout of
+ * dmz_hip_frame_result (include/dmz_hip.h); 1024 bytes ----------------------- */
+typedef struct {
+  int32_t found[4];    /* top, left, bottom, right  (dmz.h:33-38 order) */
+  float rho[4];
+  float theta[4];
+  float corners[8];    /* top_left, bottom_left, top_right, bottom_right (x,y) */
+  int32_t found_all;   /* return value of dmz_detect_edges */
+  int32_t flags;       /* ORC_FLAG_* */
+  float vseg_score;
+  int32_t vseg_y_offset;
+  int32_t pattern_type; /* 0 unknown, 1 visa-like, 2 amex-like */
+  int32_t n_offsets;
+  uint16_t offsets[16];
+  float hseg_score;
+  float number_width;
+  int32_t pattern_offset;
+  float number_score;  /* n_offsets - sum(scores), frame.cpp:63 */
+  uint8_t digits[16];  /* argmax of each scores row, first max wins */
+  float scores[16][10];
+  int32_t expiry_month;
+  int32_t expiry_year;
+  uint8_t reserved[1024 - 816];
+} orc_frame_result;
+
+#define ORC_FLAG_USABLE 1       /* FrameScanResult.usable (frame.cpp:43,64) */
+#define ORC_FLAG_UPSIDE_DOWN 2  /* frame.cpp:38-41 */
+#define ORC_FLAG_VSEG_OK 4      /* vseg.score > 15 and not upside down */
+#define ORC_FLAG_WARPED 8       /* card was rectified (all four edges found) */
+
+/* ---- cv/ ------------------------------------------------------------------- */
+/* dmz.cpp:279-341; boxes[4][4] = top,bottom,left,right x (x,y,w,h) */
+void orc_detection_boxes(int width, int height, int orientation, int boxes[4][4]);
+/* sobel.cpp:476-478 = cvSobel(src,dst,dx,dy,7) on an isolated ROI */
+void orc_sobel7(const uint8_t *src, int stride, int w, int h, int want_dx, int16_t *dst);
+/* canny.cpp:568-580 + 58-336; out 0/255, also returns low/high */
+void orc_adaptive_canny7(const int16_t *dx, const int16_t *dy, int w, int h,
+                         uint8_t *out, int *low_out, int *high_out);
+/* hough.cpp:52-195 with dmz.cpp:246-249 parameters; returns 1 if a line was found */
+int orc_hough(const uint8_t *edges, const int16_t *dx, const int16_t *dy, int w, int h,
+              int vertical, float *rho, float *theta, int *n_out, int *r_out, int *max_out);
+/* dmz.cpp:224-271 on ROI (x,y,w,h) of an 8U plane; returns found, line in ROI coords */
+int orc_best_line(const uint8_t *plane, int stride, int x, int y, int w, int h,
+                  int vertical, float *rho, float *theta);
+/* geometry.cpp:34-43 */
+void orc_line_by_shifting_origin(float rho, float theta, int xoff, int yoff,
+                                 float *rho_out, float *theta_out);
+/* geometry.cpp:14-32; returns 1 if intersect */
+int orc_parametric_intersect(float rho1, float theta1, float rho2, float theta2,
+                             float *x, float *y);
+/* dmz.cpp:371-439.  cb/cr may be NULL (then only the Y plane is searched). */
+int orc_detect_edges(const uint8_t *y, int y_stride, int w, int h,
+                     const uint8_t *cb, const uint8_t *cr, int c_stride,
+                     int orientation, orc_frame_result *res);
+/* warp.cpp:34-125 (row-major 3x3) */
+void orc_calc_persp_transform(const float src_pts[8], const float dst_pts[8], float m[9]);
+/* cvWarpPerspective(INTER_LINEAR|FILL_OUTLIERS, 0), SURVEY Appendix A10 */
+void orc_warp_perspective(const uint8_t *src, int stride, int sw, int sh,
+                          const float m[9], uint8_t *dst, int dstride, int dw, int dh);
+/* dmz.cpp:443-497 for a 1-channel plane, upsample=false */
+void orc_transform_card(const uint8_t *plane, int stride, int w, int h,
+                        const float corners[8], int orientation, int truncate_corners,
+                        uint8_t *card /* 428x270, stride 428 */);
+
+/* ---- scan/ ----------------------------------------------------------------- */
+void orc_morph_grad3_1d(const uint8_t *src, int n, uint8_t *dst);           /* morph.cpp:108-112 */
+void orc_morph_grad3_2d_cross(const uint8_t *src, int stride, int w, int h,
+                              uint8_t *dst, int dstride);                   /* morph.cpp:190-220 */
+void orc_lineardown2_1d(const uint8_t *src, int n_out, uint8_t *dst);       /* convert.cpp:195-197 */
+void orc_norm_convert_1d(const uint8_t *src, int n, float *dst);            /* convert.cpp:380-383 */
+void orc_equalize_hist(uint8_t *img, int stride, int w, int h);             /* stats.cpp:116-159 */
+void orc_applym_vseg(const float x[204], float out[3]);                     /* modelm_befe75da.cpp:1770-1786 */
+void orc_applyc_digit(int model, const float x[27 * 19], float out[10]);    /* modelc_*.cpp:1893-1937 */
+void orc_applym_slash(const float x[176], float out[2]);                    /* modelm_730c4cbd.cpp:2431-2449 */
+void orc_applyc_expiry(const float x[16 * 11], float out[10],
+                       float *l1 /*50*70 or NULL*/, float *l2 /*120*/, float *l3 /*176*/); /* modelc_bf4dd6c8.cpp:13457-13505 */
+void orc_vseg_row_features(const uint8_t *row408, float feat[204]);         /* n_vseg.cpp:39-43 */
+void orc_best_segmentation_for_vseg_scores(const float *visa, const float *amex, float *score,
+                                           int *y_offset, int *pattern);    /* n_vseg.cpp:49-92 */
+void orc_best_n_vseg(const uint8_t *card, int stride, float *score, int *y_offset, int *pattern,
+                     float *visa_scores /*270 or NULL*/, float *amex_scores); /* n_vseg.cpp:94-168 */
+void orc_hseg_grad_sums(const uint8_t *strip, int stride, float sums[428]); /* n_hseg.cpp:90-96 */
+void orc_best_n_hseg_constrained(const float *grad_sums, int pattern_type,
+                                 float wmin, float wmax, float wstep,
+                                 int omin, int omax, int ostep,
+                                 uint16_t offsets[16], float *score, float *number_width,
+                                 int *pattern_offset);                      /* n_hseg.cpp:39-84 */
+void orc_best_n_hseg(const uint8_t *strip, int stride, int pattern_type, orc_frame_result *res); /* n_hseg.cpp:88-151 */
+void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets, int n,
+                       float scores[160]);                                  /* n_categorize.cpp:75-107 */
+void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res); /* frame.cpp:24-81 (number path) */
+
+/* ---- full per-frame pipeline: detect -> transform(Y) -> scan ---------------- */
+void orc_scan_frame(const uint8_t *y, int stride, int w, int h, int orientation,
+                    int truncate_corners, uint8_t *card_out /* 428*270 or NULL */,
+                    orc_frame_result *res);
+
+/* dmz_olm.cpp:40-49 */
+int orc_passes_luhn(const uint8_t *digits, int n);
+
+/* ---- synthetic frames (bench / test inputs; integer + IEEE-exact math so the
+ * HIP generator in card.io-dmz_amd/csrc/synth.hip produces identical bytes) -- */
+void orc_synth_frame(uint64_t seed, uint64_t frame_index, uint8_t *y /* 640x480 */, uint8_t digits_out[16]);
+void orc_synth_card(uint64_t seed, uint64_t frame_index, uint8_t *card /* 428x270 */, uint8_t digits_out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+// ref_driver.cpp -- recipe TU for the PARTIAL REFERENCE BUILD oracle/_ref/libdmzref.so.
+//
+// Test infrastructure only (see dmz_oracle.h).  It compiles the reference's own
+// unity translation unit from where it lies (-I/root/reference; nothing is
+// copied) and exports thin extern "C" wrappers around those reference functions
+// that need only the vendored Eigen / OpenCV *headers*.  The OpenCV *libraries*
+// are not in the image, so every reference function that calls a cv* library
+// symbol (cvGetMat, cvGetSize, cvSobel, cvWarpPerspective, ...) is left
+// unreachable and dropped by --gc-sections; no stand-in for any of them is
+// written.  Flavour: -DCYTHON_DMZ=1 -DSCAN_EXPIRY=1 -DEIGEN_DONT_VECTORIZE
+// -O2 -ffp-contract=off (the pinned oracle flavour).
+//
+// What this pins (tests/test_oracle_vs_ref.py): the six generated models and
+// their pass*_() known-answer tests, geometry.cpp (lineByShiftingOrigin,
+// parametricIntersect), llcv_calc_persp_transform (Eigen HouseholderQR),
+// best_segmentation_for_vseg_scores, best_n_hseg_constrained, Luhn.
+#include "dmz_all.cpp"
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+REF_API int ref_pass_kats(void) {
+  int ok = 0;
+  ok |= passm_befe75da() ? 1 : 0;
+  ok |= passc_5c241121() ? 2 : 0;
+  ok |= passc_01266c1b() ? 4 : 0;
+  ok |= passc_b00bf70c() ? 8 : 0;
+  ok |= passm_730c4cbd() ? 16 : 0;
+  ok |= passc_bf4dd6c8() ? 32 : 0;
+  return ok;
+}
+
+REF_API void ref_applym_vseg(const float *x, float *out) {
+  ModelMInput_befe75da in;
+  for (int i = 0; i < 204; i++) in(i, 0) = x[i];
+  ModelMOutput_befe75da o = applym_befe75da(in);
+  for (int i = 0; i < 3; i++) out[i] = o(i, 0);
+}
+
+REF_API void ref_applyc_digit(int model, const float *x, float *out) {
+  ModelCInput_5c241121 in;
+  for (int r = 0; r < 27; r++)
+    for (int c = 0; c < 19; c++) in(r, c) = x[r * 19 + c];
+  ModelCOutput_5c241121 o;
+  if (model == 0) o = applyc_5c241121(in);
+  else if (model == 1) o = applyc_01266c1b(in);
+  else o = applyc_b00bf70c(in);
+  for (int i = 0; i < 10; i++) out[i] = o(i, 0);
+}
+
+REF_API void ref_applym_slash(const float *x, float *out) {
+  ModelMInput_730c4cbd in;
+  for (int i = 0; i < 176; i++) in(i, 0) = x[i];
+  ModelMOutput_730c4cbd o = applym_730c4cbd(in);
+  for (int i = 0; i < 2; i++) out[i] = o(i, 0);
+}
+
+REF_API void ref_applyc_expiry(const float *x, float *out) {
+  ModelCInput_bf4dd6c8 in;
+  for (int r = 0; r < 16; r++)
+    for (int c = 0; c < 11; c++) in(r, c) = x[r * 11 + c];
+  ModelCOutput_bf4dd6c8 o = applyc_bf4dd6c8(in);
+  for (int i = 0; i < 10; i++) out[i] = o(i, 0);
+}
+
+REF_API void ref_line_by_shifting_origin(float rho, float theta, int xo, int yo, float *rho_out,
+                                         float *theta_out) {
+  ParametricLine l;
+  l.rho = rho;
+  l.theta = theta;
+  ParametricLine n = lineByShiftingOrigin(l, xo, yo);
+  *rho_out = n.rho;
+  *theta_out = n.theta;
+}
+
+REF_API int ref_parametric_intersect(float rho1, float theta1, float rho2, float theta2, float *x,
+                                     float *y) {
+  ParametricLine a, b;
+  a.rho = rho1; a.theta = theta1;
+  b.rho = rho2; b.theta = theta2;
+  return parametricIntersect(a, b, x, y) ? 1 : 0;
+}
+
+REF_API void ref_calc_persp_transform(const float *src_pts, const float *dst_pts, float *m9) {
+  dmz_point s[4], d[4];
+  for (int i = 0; i < 4; i++) {
+    s[i] = dmz_create_point(src_pts[2 * i], src_pts[2 * i + 1]);
+    d[i] = dmz_create_point(dst_pts[2 * i], dst_pts[2 * i + 1]);
+  }
+  llcv_calc_persp_transform(m9, 9, true, s, d);
+}
+
+REF_API void ref_card_dest_points(float *dst_pts) {
+  dmz_point d[4];
+  dmz_rect_get_points(dmz_create_rect(0, 0, kCreditCardTargetWidth - 1, kCreditCardTargetHeight - 1), d);
+  for (int i = 0; i < 4; i++) { dst_pts[2 * i] = d[i].x; dst_pts[2 * i + 1] = d[i].y; }
+}
+
+REF_API void ref_best_segmentation_for_vseg_scores(float *visa, float *amex, float *score,
+                                                   int *y_offset, int *pattern) {
+  NVerticalSegmentation best;
+  best_segmentation_for_vseg_scores(visa, amex, &best);
+  *score = best.score;
+  *y_offset = best.y_offset;
+  *pattern = best.pattern_type;
+}
+
+REF_API void ref_best_n_hseg_constrained(float *grad_sums, int pattern_type, float wmin, float wmax,
+                                         float wstep, int omin, int omax, int ostep,
+                                         uint16_t *offsets, float *score, float *number_width,
+                                         int *pattern_offset) {
+  NVerticalSegmentation vseg;
+  vseg.pattern_type = (NumberPatternType)pattern_type;
+  vseg.number_pattern_length = NumberPatternLengthForPatternType[pattern_type];
+  memcpy(&vseg.number_pattern, NumberPatternForPatternType[pattern_type], sizeof(vseg.number_pattern));
+  vseg.number_length = NumberLengthForNumberPatternType[pattern_type];
+  NHorizontalSegmentation best;
+  best.n_offsets = vseg.number_length;
+  best.score = *score;
+  best.number_width = *number_width;
+  best.pattern_offset = (uint16_t)*pattern_offset;
+  memcpy(best.offsets, offsets, sizeof(best.offsets));
+  SliceF32 ws; ws.min = wmin; ws.max = wmax; ws.step = wstep;
+  SliceU16 os; os.min = (uint16_t)omin; os.max = (uint16_t)omax; os.step = (uint16_t)ostep;
+  best = best_n_hseg_constrained(grad_sums, vseg, best, ws, os);
+  memcpy(offsets, best.offsets, sizeof(best.offsets));
+  *score = best.score;
+  *number_width = best.number_width;
+  *pattern_offset = best.pattern_offset;
+}
+
+REF_API int ref_passes_luhn(uint8_t *digits, int n) {
+  return dmz_passes_luhn_checksum(digits, (uint8_t)n) ? 1 : 0;
+}
