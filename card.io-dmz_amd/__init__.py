@@ -1,0 +1,247 @@
+"""Python host binding of libdmz_hip.so (the C-ABI of include/dmz_hip.h).
+
+The directory name `card.io-dmz_amd` is not a Python identifier; load it with
+`__graft_entry__.load_package()` (importlib by path, module name `dmz_amd`).
+
+This module is plumbing only: numpy/torch buffers in, ctypes calls to the HIP
+library out.  There is NO CPU fallback here -- if the shared library or a GPU is
+missing every entry point raises.  (The CPU oracle lives in oracle/ and is never
+imported from this package.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdmz_hip.so")
+
+FRAME_W, FRAME_H = 640, 480
+CARD_W, CARD_H = 428, 270
+CARD_BYTES = CARD_W * CARD_H
+FRAME_BYTES = FRAME_W * FRAME_H
+
+ORIENTATION_PORTRAIT = 1
+ORIENTATION_PORTRAIT_UPSIDE_DOWN = 2
+ORIENTATION_LANDSCAPE_RIGHT = 3
+ORIENTATION_LANDSCAPE_LEFT = 4
+
+FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
+OPT_TRUNCATE_CORNERS = 1
+STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits")
+
+# mirror of struct dmz_hip_frame_result (include/dmz_hip.h), 1024 bytes
+RESULT_DTYPE = np.dtype([
+    ("found", "<i4", (4,)), ("rho", "<f4", (4,)), ("theta", "<f4", (4,)),
+    ("corners", "<f4", (8,)), ("found_all", "<i4"), ("flags", "<i4"),
+    ("vseg_score", "<f4"), ("vseg_y_offset", "<i4"), ("pattern_type", "<i4"),
+    ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("hseg_score", "<f4"),
+    ("number_width", "<f4"), ("pattern_offset", "<i4"), ("number_score", "<f4"),
+    ("digits", "u1", (16,)), ("scores", "<f4", (16, 10)),
+    ("expiry_month", "<i4"), ("expiry_year", "<i4"), ("reserved", "u1", (208,)),
+])
+assert RESULT_DTYPE.itemsize == 1024
+
+# every symbol include/dmz_hip.h declares
+EXPORTS = (
+    "dmz_hip_device_count", "dmz_hip_context_create", "dmz_hip_context_destroy",
+    "dmz_hip_synchronize", "dmz_hip_set_stream", "dmz_hip_last_error",
+    "dmz_hip_detect_batch", "dmz_hip_transform_batch", "dmz_hip_scan_cards_batch",
+    "dmz_hip_pipeline_batch", "dmz_hip_calc_persp_transform", "dmz_hip_warp_perspective_batch",
+    "dmz_hip_apply_vseg_model", "dmz_hip_apply_digit_model", "dmz_hip_synth_frames",
+    "dmz_hip_synth_cards", "dmz_hip_set_profiling", "dmz_hip_get_stage_times",
+    "dmz_hip_malloc", "dmz_hip_free", "dmz_hip_memcpy_h2d", "dmz_hip_memcpy_d2h",
+)
+
+
+class DmzHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", HERE, "-j8"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libdmz_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmzHipError("%s is missing: run `make -C %s` (the HIP extension is required; "
+                          "there is no CPU fallback)" % (LIB_PATH, HERE))
+    lib = C.CDLL(LIB_PATH)
+    vp, i, sz, u64 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64
+    lib.dmz_hip_device_count.restype = i
+    lib.dmz_hip_context_create.argtypes = [i, C.POINTER(vp)]
+    lib.dmz_hip_context_destroy.argtypes = [vp]
+    lib.dmz_hip_context_destroy.restype = None
+    lib.dmz_hip_synchronize.argtypes = [vp]
+    lib.dmz_hip_set_stream.argtypes = [vp, vp]
+    lib.dmz_hip_last_error.argtypes = [vp]
+    lib.dmz_hip_last_error.restype = C.c_char_p
+    lib.dmz_hip_detect_batch.argtypes = [vp, vp, sz, i, i, i, vp, vp, sz, i, i, i, vp]
+    lib.dmz_hip_transform_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, vp, sz]
+    lib.dmz_hip_scan_cards_batch.argtypes = [vp, vp, sz, i, i, vp]
+    lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
+    lib.dmz_hip_calc_persp_transform.argtypes = [vp, vp, vp, vp]
+    lib.dmz_hip_warp_perspective_batch.argtypes = [vp, vp, sz, i, i, i, i, vp, vp, sz]
+    lib.dmz_hip_apply_vseg_model.argtypes = [vp, vp, i, vp]
+    lib.dmz_hip_apply_digit_model.argtypes = [vp, i, vp, i, vp]
+    lib.dmz_hip_synth_frames.argtypes = [vp, u64, u64, i, vp]
+    lib.dmz_hip_synth_cards.argtypes = [vp, u64, u64, i, vp]
+    lib.dmz_hip_set_profiling.argtypes = [vp, i]
+    lib.dmz_hip_get_stage_times.argtypes = [vp, vp, vp, i]
+    lib.dmz_hip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.dmz_hip_free.argtypes = [vp, vp]
+    lib.dmz_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    lib.dmz_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """Address of a numpy array, a torch tensor, a raw int address or None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):  # torch tensor (device or host)
+        assert a.is_contiguous()
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+class DeviceBuffer:
+    """Raw HBM allocation through the C-ABI (for hosts without torch)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._check(ctx.lib.dmz_hip_malloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.dmz_hip_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count=None):
+        dtype = np.dtype(dtype)
+        count = self.nbytes // dtype.itemsize if count is None else count
+        out = np.empty(count, dtype)
+        self.ctx._check(self.ctx.lib.dmz_hip_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.dmz_hip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """dmz_hip_context: the MI355X twin of the reference's dmz_context / mz handle."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.dmz_hip_device_count() <= 0:
+            raise DmzHipError("no HIP device visible: the MI355X path cannot run (no CPU fallback)")
+        h = C.c_void_p()
+        rc = self.lib.dmz_hip_context_create(device, C.byref(h))
+        if rc != 0:
+            raise DmzHipError("dmz_hip_context_create(%d) failed with %d" % (device, rc))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.dmz_hip_context_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DmzHipError("dmz_hip error %d: %s" % (rc, self.lib.dmz_hip_last_error(self.h).decode()))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self):
+        self._check(self.lib.dmz_hip_synchronize(self.h))
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.dmz_hip_set_stream(self.h, stream_handle))
+
+    def set_profiling(self, on):
+        self._check(self.lib.dmz_hip_set_profiling(self.h, int(on)))
+
+    def stage_times(self, reset=True):
+        ms = np.zeros(len(STAGES), np.float32)
+        cnt = np.zeros(len(STAGES), np.int32)
+        self._check(self.lib.dmz_hip_get_stage_times(self.h, ms.ctypes.data, cnt.ctypes.data, int(reset)))
+        return {s: (float(ms[k]), int(cnt[k])) for k, s in enumerate(STAGES)}
+
+    # ---- batched stages (pointers: numpy host arrays, torch tensors, DeviceBuffer.ptr ints) ----
+    def detect(self, y, n, results, width=FRAME_W, height=FRAME_H, orientation=ORIENTATION_LANDSCAPE_RIGHT,
+               cb=None, cr=None, frame_stride=None, row_stride=None):
+        row_stride = row_stride or width
+        frame_stride = frame_stride or row_stride * height
+        self._check(self.lib.dmz_hip_detect_batch(
+            self.h, _ptr(y), frame_stride, row_stride, width, height, _ptr(cb), _ptr(cr),
+            (width // 2) * (height // 2), width // 2, n, orientation, _ptr(results)))
+
+    def transform(self, plane, n, results, cards, width=FRAME_W, height=FRAME_H,
+                  orientation=ORIENTATION_LANDSCAPE_RIGHT, options=0, frame_stride=None, row_stride=None):
+        row_stride = row_stride or width
+        frame_stride = frame_stride or row_stride * height
+        self._check(self.lib.dmz_hip_transform_batch(
+            self.h, _ptr(plane), frame_stride, row_stride, width, height, n, orientation, options,
+            _ptr(results), _ptr(cards), CARD_BYTES))
+
+    def scan_cards(self, cards, n, results, only_warped=False):
+        self._check(self.lib.dmz_hip_scan_cards_batch(self.h, _ptr(cards), CARD_BYTES, n, int(only_warped),
+                                                      _ptr(results)))
+
+    def pipeline(self, y, n, results, cards=None, width=FRAME_W, height=FRAME_H,
+                 orientation=ORIENTATION_LANDSCAPE_RIGHT, options=0):
+        self._check(self.lib.dmz_hip_pipeline_batch(
+            self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
+            _ptr(cards), CARD_BYTES, _ptr(results)))
+
+    def calc_persp_transform(self, src_pts, dst_pts):
+        s = np.ascontiguousarray(src_pts, np.float32).reshape(8)
+        d = np.ascontiguousarray(dst_pts, np.float32).reshape(8)
+        m = np.empty(9, np.float32)
+        self._check(self.lib.dmz_hip_calc_persp_transform(self.h, s.ctypes.data, d.ctypes.data, m.ctypes.data))
+        return m
+
+    def warp_perspective(self, plane, n, matrices, cards, width=FRAME_W, height=FRAME_H):
+        self._check(self.lib.dmz_hip_warp_perspective_batch(
+            self.h, _ptr(plane), width * height, width, width, height, n, _ptr(matrices), _ptr(cards), CARD_BYTES))
+
+    def apply_vseg_model(self, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, 204)
+        out = np.empty((x.shape[0], 3), np.float32)
+        self._check(self.lib.dmz_hip_apply_vseg_model(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def apply_digit_model(self, model, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, 27 * 19)
+        out = np.empty((x.shape[0], 10), np.float32)
+        self._check(self.lib.dmz_hip_apply_digit_model(self.h, model, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def synth_frames(self, seed, first, n, y_dev):
+        self._check(self.lib.dmz_hip_synth_frames(self.h, seed, first, n, _ptr(y_dev)))
+
+    def synth_cards(self, seed, first, n, cards_dev):
+        self._check(self.lib.dmz_hip_synth_cards(self.h, seed, first, n, _ptr(cards_dev)))

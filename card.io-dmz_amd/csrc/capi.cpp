@@ -1,0 +1,747 @@
+// capi.cpp -- the extern "C" boundary declared in include/dmz_hip.h: context
+// life cycle, host-side table preparation, pointer staging and stage launches.
+//
+// Host-evaluated tables (glibc libm, exactly where the x86 reference evaluates
+// them): detection boxes dmz.cpp:279-341; Hough sin/cos/slope tables and angles
+// hough.cpp:98-124,190-191 with dmz.cpp:246-249's parameters; origin shift
+// geometry.cpp:34-43; cosf/sinf of the candidate angles geometry.cpp:22.
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "dmz_hip_internal.h"
+
+extern "C" const unsigned char dmz_weights_blob[];
+extern "C" const unsigned char dmz_weights_blob_end[];
+
+#define DMZ_PI 3.1415926535897932384626433832795  // CV_PI
+
+struct dmz_hip_context {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  float *d_weights = nullptr;  // blob
+  float *d_w1t = nullptr;      // vseg hidden W transposed [204][64]
+  float *d_hidwt = nullptr;    // digit hidden W transposed 3 x [320][32]
+
+  // detection tables for the current (width, height, orientation)
+  int cfg_w = 0, cfg_h = 0, cfg_orientation = 0;
+  DmzDetectParams h_params[3];
+  DmzDetectParams *d_params = nullptr;
+
+  // grow-only device scratch
+  struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+  };
+  Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc;
+
+  // profiling
+  bool profiling = false;
+  struct Span {
+    int stage;
+    hipEvent_t a, b;
+  };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> free_events;
+  float stage_ms[DMZ_HIP_STAGE_COUNT] = {0};
+  int stage_launches[DMZ_HIP_STAGE_COUNT] = {0};
+};
+
+namespace {
+
+int fail(dmz_hip_context *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+  if (ctx) {
+    ctx->err = what;
+    if (e != hipSuccess) {
+      ctx->err += ": ";
+      ctx->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                 \
+  do {                                                                     \
+    hipError_t e__ = (call);                                               \
+    if (e__ != hipSuccess) return fail(ctx, DMZ_HIP_ERUNTIME, #call, e__); \
+  } while (0)
+
+int ensure(dmz_hip_context *ctx, dmz_hip_context::Buf &b, size_t bytes) {
+  if (b.cap >= bytes) return DMZ_HIP_OK;
+  if (b.p) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return DMZ_HIP_OK;
+}
+
+bool is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // clear the sticky "invalid value" of a plain host pointer
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// ---- dmz.cpp:279-341 -------------------------------------------------------
+void detection_boxes(int width_in, int height, int orientation, int b[4][4]) {
+  int inset_v = 0, slop_v = 0, inset_h = 0, slop_h = 0;
+  const int width = (height * 4) / 3;
+  const int left_margin = (width_in - width) / 2;
+  const float slop_pct = 0.03f;  // kVerticalPercentSlop == kHorizontalPercentSlop
+  if (orientation == DMZ_ORIENTATION_PORTRAIT || orientation == DMZ_ORIENTATION_PORTRAIT_UPSIDE_DOWN) {
+    const float pv = (float)((480 - 428) / 2) / (float)480;
+    const float ph = (float)((640 - 270) / 2) / (float)640;
+    inset_v = (int)roundf(pv * height);
+    slop_v = (int)roundf(slop_pct * height);
+    inset_h = (int)roundf(ph * width);
+    slop_h = (int)roundf(slop_pct * width);
+  } else if (orientation == DMZ_ORIENTATION_LANDSCAPE_RIGHT || orientation == DMZ_ORIENTATION_LANDSCAPE_LEFT) {
+    const float pv = (float)((480 - 270) / 2) / (float)480;
+    const float ph = (float)((640 - 428) / 2) / (float)640;
+    inset_v = (int)roundf(pv * height);
+    slop_v = (int)roundf(slop_pct * height);
+    inset_h = (int)roundf(ph * width);
+    slop_h = (int)roundf(slop_pct * width);
+  }
+  const int ix = left_margin, iy = 0, iw = width - 1, ih = height - 1;
+  const int ox = ix + (inset_h - slop_h), oy = iy + (inset_v - slop_v);
+  const int nx = ix + (inset_h + slop_h), ny = iy + (inset_v + slop_v);
+  const int nw = iw - 2 * (inset_h + slop_h), nh = ih - 2 * (inset_v + slop_v);
+  // result order top, left, bottom, right
+  const int t[4][4] = {{nx, oy, nw, 2 * slop_v},
+                       {ox, ny, 2 * slop_h, nh},
+                       {nx, ny + nh, nw, 2 * slop_v},
+                       {nx + nw, ny, 2 * slop_h, nh}};
+  memcpy(b, t, sizeof(t));
+}
+
+int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], int plane_w, int plane_h,
+                    int vertical, float rho_multiplier) {
+  memset(&bp, 0, sizeof(bp));
+  // cvSetImageROI clips the rectangle to the image
+  int x0 = box[0] < 0 ? 0 : box[0], y0 = box[1] < 0 ? 0 : box[1];
+  int x1 = box[0] + box[2] > plane_w ? plane_w : box[0] + box[2];
+  int y1 = box[1] + box[3] > plane_h ? plane_h : box[1] + box[3];
+  bp.x = x0; bp.y = y0; bp.w = x1 - x0; bp.h = y1 - y0;
+  if (bp.w < 8 || bp.h < 8) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "detection box smaller than 8 px");
+  const int off = 4 + (bp.x & 3);
+  const int sp = (off + bp.w + 3 + 3) & ~3;
+  if (bp.w * bp.h > kDetectMaxPixels || sp * bp.h > kDetectSrcBytes)
+    return fail(ctx, DMZ_HIP_EUNSUPPORTED,
+                "detection box does not fit the LDS-resident detect kernel (max 11264 px)");
+  bp.vertical = vertical;
+  bp.rho_multiplier = rho_multiplier;
+  bp.inv_w = (uint32_t)((0x100000000ull + (uint64_t)bp.w - 1) / (uint64_t)bp.w);
+  // dmz.cpp:246-258 + hough.cpp:98-124
+  const float rho = 1.0f;
+  const float theta = (float)DMZ_PI / 180.0f;
+  bp.threshold = (bp.w > bp.h ? bp.w : bp.h) / 6;
+  const float base_angle = vertical ? (float)DMZ_PI : (float)(DMZ_PI / 2.0f);
+  const float max_dev = (float)(5.0f * (DMZ_PI / 180.0f));
+  const float theta_min = base_angle - max_dev, theta_max = base_angle + max_dev;
+  const float irho = 1 / rho;
+  const int numangle = (int)lrint((double)((theta_max - theta_min) / theta));
+  if (numangle != kNumAngle) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "unexpected Hough angle count");
+  bp.numrho = (int)lrint((double)(((bp.w + bp.h) * 2 + 1) / rho));
+  if (bp.numrho * kNumAngle > kDetectMaxPixels)
+    return fail(ctx, DMZ_HIP_EUNSUPPORTED, "Hough accumulator does not fit LDS");
+  float ang = theta_min;
+  for (int n = 0; n < kNumAngle; ang += theta, n++) {
+    bp.tab_sin[n] = (int)floorf(1024 * sinf(ang) * irho);
+    bp.tab_cos[n] = (int)floorf(1024 * cosf(ang) * irho);
+  }
+  const float gat = 10;  // kHoughGradientAngleThreshold
+  if (vertical) {
+    bp.slope_a = tanf((float)(DMZ_PI * (180 - gat) / 180.0f));
+    bp.slope_b = tanf((float)(DMZ_PI * (180 + gat) / 180.0f));
+  } else {
+    bp.slope_a = tanf((float)(DMZ_PI * (90 - gat) / 180.0f));
+    bp.slope_b = tanf((float)(DMZ_PI * (90 + gat) / 180.0f));
+  }
+  // geometry.cpp:34-43 for origin (x, y) of this box and each candidate angle.
+  // NB: the shift uses the ORIGINAL rectangle origin handed to lineByShiftingOrigin
+  // (detection_rects[i].x/.y, dmz.cpp:364), which equals the clipped one for in-image boxes.
+  const int xo = box[0], yo = box[1];
+  const double offset_angle = xo == 0 ? DMZ_PI / 2.0f : (double)atanf((float)yo / (float)xo);
+  const double offset_magnitude = sqrt((double)(xo * xo + yo * yo));
+  for (int n = 0; n < kNumAngle; n++) {
+    const float th = n * theta + theta_min;  // hough.cpp:191
+    bp.theta_n[n] = th;
+    const double delta_angle = th - offset_angle + DMZ_PI / 2.0f;
+    bp.delta_rho[n] = offset_magnitude * cos(DMZ_PI / 2 - delta_angle);
+    bp.cos_t[n] = cosf(th);
+    bp.sin_t[n] = sinf(th);
+  }
+  return DMZ_HIP_OK;
+}
+
+int configure_detection(dmz_hip_context *ctx, int width, int height, int orientation) {
+  if (ctx->cfg_w == width && ctx->cfg_h == height && ctx->cfg_orientation == orientation)
+    return DMZ_HIP_OK;
+  for (int pl = 0; pl < 3; pl++) {
+    const int pw = pl == 0 ? width : width / 2, ph = pl == 0 ? height : height / 2;
+    int boxes[4][4];
+    detection_boxes(pw, ph, orientation, boxes);
+    for (int e = 0; e < 4; e++) {
+      const int vertical = (e == 1 || e == 3);
+      int rc = fill_box_params(ctx, ctx->h_params[pl].box[e], boxes[e], pw, ph, vertical,
+                               pl == 0 ? 1.0f : 2.0f);
+      if (rc != DMZ_HIP_OK) return rc;
+    }
+  }
+  if (!ctx->d_params) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_params, sizeof(ctx->h_params)));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, ctx->h_params, sizeof(ctx->h_params),
+                              hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->cfg_w = width;
+  ctx->cfg_h = height;
+  ctx->cfg_orientation = orientation;
+  return DMZ_HIP_OK;
+}
+
+// ---- profiling spans --------------------------------------------------------
+struct StageTimer {
+  dmz_hip_context *ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  int stage;
+  StageTimer(dmz_hip_context *c, int s) : ctx(c), stage(s) {
+    if (!ctx->profiling) return;
+    a = take();
+    b = take();
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~StageTimer() {
+    if (!ctx->profiling) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->spans.push_back({stage, a, b});
+  }
+  hipEvent_t take() {
+    hipEvent_t e = nullptr;
+    if (!ctx->free_events.empty()) {
+      e = ctx->free_events.back();
+      ctx->free_events.pop_back();
+    } else {
+      (void)hipEventCreate(&e);
+    }
+    return e;
+  }
+};
+
+void resolve_spans(dmz_hip_context *ctx) {
+  for (auto &s : ctx->spans) {
+    float ms = 0.0f;
+    (void)hipEventSynchronize(s.b);
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      ctx->stage_ms[s.stage] += ms;
+      ctx->stage_launches[s.stage] += 1;
+    }
+    ctx->free_events.push_back(s.a);
+    ctx->free_events.push_back(s.b);
+  }
+  ctx->spans.clear();
+}
+
+// Stage an input that may live on the host.
+int stage_in(dmz_hip_context *ctx, dmz_hip_context::Buf &buf, const void *src, size_t bytes,
+             const void **dev) {
+  if (is_device_ptr(src)) {
+    *dev = src;
+    return DMZ_HIP_OK;
+  }
+  int rc = ensure(ctx, buf, bytes);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = buf.p;
+  return DMZ_HIP_OK;
+}
+
+// ---- stage runners on device pointers ---------------------------------------
+int run_detect(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+               const uint8_t *cb, const uint8_t *cr, size_t cstride, int crow, int n,
+               dmz_hip_frame_result *results) {
+  const int nplanes = (cb && cr) ? 3 : 1;
+  int rc = ensure(ctx, ctx->hits, sizeof(DmzBoxHit) * 4 * (size_t)n * 3);
+  if (rc) return rc;
+  DmzBoxHit *hits = (DmzBoxHit *)ctx->hits.p;
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_DETECT);
+    dmz_launch_detect(ctx->stream, y, frame_stride, row_stride, n, ctx->h_params[0], hits, nullptr);
+    if (nplanes == 3) {
+      // chroma fallback (dmz.cpp:351-367): a box is searched on Cb only if Y found nothing,
+      // on Cr only if neither Y nor Cb did.  hits[] doubles as the skip mask: DmzBoxHit.found
+      // is its first int, so plane p skips box b when hits[p-1][b].found (accumulated).
+      HIP_TRY(ctx, hipMemsetAsync(hits + (size_t)n * 4, 0, sizeof(DmzBoxHit) * 4 * (size_t)n * 2, ctx->stream));
+      rc = ensure(ctx, ctx->skip, sizeof(int) * 4 * (size_t)n * 2);
+      if (rc) return rc;
+      int *skip = (int *)ctx->skip.p;
+      // skip1 = found on Y
+      HIP_TRY(ctx, hipMemcpy2DAsync(skip, sizeof(int), hits, sizeof(DmzBoxHit), sizeof(int),
+                                    (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      dmz_launch_detect(ctx->stream, cb, cstride, crow, n, ctx->h_params[1], hits + (size_t)n * 4, skip);
+      // skip2 = found on Y or Cb: k_geometry takes the first plane that found the edge, so it
+      // is enough for correctness that Cr is searched wherever Cb found nothing.
+      int *skip2 = skip + (size_t)n * 4;
+      HIP_TRY(ctx, hipMemcpy2DAsync(skip2, sizeof(int), hits + (size_t)n * 4, sizeof(DmzBoxHit),
+                                    sizeof(int), (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      dmz_launch_detect(ctx->stream, cr, cstride, crow, n, ctx->h_params[2], hits + (size_t)n * 8, skip2);
+    }
+  }
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_GEOMETRY);
+    dmz_launch_geometry(ctx->stream, n, ctx->d_params, hits, nplanes, results);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return DMZ_HIP_OK;
+}
+
+int run_transform(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_stride, int row_stride,
+                  int width, int height, int n, int orientation, int options,
+                  dmz_hip_frame_result *results, uint8_t *cards, size_t card_stride) {
+  int rc = ensure(ctx, ctx->mats, sizeof(DmzWarpMat) * (size_t)n);
+  if (rc) return rc;
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_GEOMETRY);
+    dmz_launch_homography(ctx->stream, n, orientation, options, results, (DmzWarpMat *)ctx->mats.p);
+  }
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_WARP);
+    dmz_launch_warp(ctx->stream, plane, frame_stride, row_stride, width, height, n,
+                    (const DmzWarpMat *)ctx->mats.p, cards, card_stride);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return DMZ_HIP_OK;
+}
+
+int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n, int only_warped,
+             dmz_hip_frame_result *results) {
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_VSEG);
+    dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_w1t, cards, card_stride, n, only_warped, results);
+  }
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_HSEG);
+    dmz_launch_hseg(ctx->stream, cards, card_stride, n, results);
+  }
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_DIGITS);
+    dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, cards, card_stride, n, results);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return DMZ_HIP_OK;
+}
+
+int check_frames(dmz_hip_context *ctx, const void *y, size_t frame_stride, int row_stride, int width,
+                 int height, int n) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!y || n <= 0 || width <= 0 || height <= 0 || row_stride < width ||
+      frame_stride < (size_t)row_stride * (size_t)(height - 1) + (size_t)width)
+    return fail(ctx, DMZ_HIP_EINVAL, "bad frame geometry");
+  return DMZ_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmz_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
+  if (!out) return DMZ_HIP_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev)
+    return DMZ_HIP_ENODEVICE;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return DMZ_HIP_ENODEVICE;
+  dmz_hip_context *ctx = new dmz_hip_context();
+  ctx->device = device_ordinal;
+  if (hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+    delete ctx;
+    return DMZ_HIP_ENODEVICE;
+  }
+  ctx->stream = ctx->own_stream;
+  // weights: blob + the two transposed copies the kernels read coalesced
+  const size_t blob_bytes = (size_t)(dmz_weights_blob_end - dmz_weights_blob);
+  if (blob_bytes < 16 + sizeof(float) * dmzw::TOTAL || memcmp(dmz_weights_blob, "DMZW0001", 8) != 0) {
+    delete ctx;
+    return DMZ_HIP_ENODEVICE;
+  }
+  const float *w = (const float *)(dmz_weights_blob + 16);
+  std::vector<float> w1t(204 * 64, 0.0f), hidwt(3 * 320 * 32);
+  for (int j = 0; j < 50; j++)
+    for (int k = 0; k < 204; k++) w1t[k * 64 + j] = w[dmzw::VSEG_W1 + j * 204 + k];
+  for (int m = 0; m < 3; m++)
+    for (int j = 0; j < 32; j++)
+      for (int i = 0; i < 320; i++)
+        hidwt[(size_t)m * 320 * 32 + i * 32 + j] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
+  bool ok = hipMalloc((void **)&ctx->d_weights, sizeof(float) * dmzw::TOTAL) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_w1t, sizeof(float) * w1t.size()) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_hidwt, sizeof(float) * hidwt.size()) == hipSuccess &&
+            hipMemcpy(ctx->d_weights, w, sizeof(float) * dmzw::TOTAL, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(ctx->d_w1t, w1t.data(), sizeof(float) * w1t.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(ctx->d_hidwt, hidwt.data(), sizeof(float) * hidwt.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            dmz_configure_detect() == 0 && dmz_configure_scan() == 0;
+  if (!ok) {
+    dmz_hip_context_destroy(ctx);
+    return DMZ_HIP_ENODEVICE;
+  }
+  *out = ctx;
+  return DMZ_HIP_OK;
+}
+
+void dmz_hip_context_destroy(dmz_hip_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  resolve_spans(ctx);
+  for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+  dmz_hip_context::Buf *bufs[] = {&ctx->hits, &ctx->mats, &ctx->skip, &ctx->synth, &ctx->stage_in,
+                                  &ctx->stage_cb, &ctx->stage_cr, &ctx->stage_cards, &ctx->stage_res,
+                                  &ctx->cards, &ctx->misc};
+  for (auto *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->d_params) (void)hipFree(ctx->d_params);
+  if (ctx->d_weights) (void)hipFree(ctx->d_weights);
+  if (ctx->d_w1t) (void)hipFree(ctx->d_w1t);
+  if (ctx->d_hidwt) (void)hipFree(ctx->d_hidwt);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int dmz_hip_synchronize(dmz_hip_context *ctx) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_set_stream(dmz_hip_context *ctx, void *hip_stream) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return DMZ_HIP_OK;
+}
+
+const char *dmz_hip_last_error(const dmz_hip_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int dmz_hip_detect_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+                         int width, int height, const uint8_t *cb, const uint8_t *cr,
+                         size_t chroma_frame_stride, int chroma_row_stride, int n, int orientation,
+                         dmz_hip_frame_result *results) {
+  int rc = check_frames(ctx, y, frame_stride, row_stride, width, height, n);
+  if (rc) return rc;
+  if (!results || (cb == nullptr) != (cr == nullptr)) return fail(ctx, DMZ_HIP_EINVAL, "bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if ((rc = configure_detection(ctx, width, height, orientation))) return rc;
+  const void *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, frame_stride * (size_t)n, &dy))) return rc;
+  if (cb) {
+    if ((rc = stage_in(ctx, ctx->stage_cb, cb, chroma_frame_stride * (size_t)n, &dcb))) return rc;
+    if ((rc = stage_in(ctx, ctx->stage_cr, cr, chroma_frame_stride * (size_t)n, &dcr))) return rc;
+  }
+  const bool res_dev = is_device_ptr(results);
+  dmz_hip_frame_result *dres = results;
+  if (!res_dev) {
+    if ((rc = ensure(ctx, ctx->stage_res, sizeof(dmz_hip_frame_result) * (size_t)n))) return rc;
+    dres = (dmz_hip_frame_result *)ctx->stage_res.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dres, results, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
+  if ((rc = run_detect(ctx, (const uint8_t *)dy, frame_stride, row_stride, (const uint8_t *)dcb,
+                       (const uint8_t *)dcr, chroma_frame_stride, chroma_row_stride, n, dres)))
+    return rc;
+  if (!res_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_transform_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_stride,
+                            int row_stride, int width, int height, int n, int orientation, int options,
+                            dmz_hip_frame_result *results, uint8_t *cards, size_t card_stride) {
+  int rc = check_frames(ctx, plane, frame_stride, row_stride, width, height, n);
+  if (rc) return rc;
+  if (!results || !cards || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad card buffer (stride must be >= 115560 and a multiple of 4)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const void *dp = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, plane, frame_stride * (size_t)n, &dp))) return rc;
+  const bool res_dev = is_device_ptr(results), cards_dev = is_device_ptr(cards);
+  dmz_hip_frame_result *dres = results;
+  uint8_t *dcards = cards;
+  if (!res_dev) {
+    if ((rc = ensure(ctx, ctx->stage_res, sizeof(dmz_hip_frame_result) * (size_t)n))) return rc;
+    dres = (dmz_hip_frame_result *)ctx->stage_res.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dres, results, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!cards_dev) {
+    if ((rc = ensure(ctx, ctx->stage_cards, card_stride * (size_t)n))) return rc;
+    dcards = (uint8_t *)ctx->stage_cards.p;
+  }
+  if (((uintptr_t)dcards) & 3) return fail(ctx, DMZ_HIP_EINVAL, "card buffer must be 4-byte aligned");
+  if ((rc = run_transform(ctx, (const uint8_t *)dp, frame_stride, row_stride, width, height, n,
+                          orientation, options, dres, dcards, card_stride)))
+    return rc;
+  if (!res_dev)
+    HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  if (!cards_dev)
+    HIP_TRY(ctx, hipMemcpyAsync(cards, dcards, card_stride * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (!res_dev || !cards_dev) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                             int only_warped, dmz_hip_frame_result *results) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!cards || !results || n <= 0 || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad card buffer (stride must be >= 115560 and a multiple of 4)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dc = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_cards, cards, card_stride * (size_t)n, &dc))) return rc;
+  if (((uintptr_t)dc) & 3) return fail(ctx, DMZ_HIP_EINVAL, "card buffer must be 4-byte aligned");
+  const bool res_dev = is_device_ptr(results);
+  dmz_hip_frame_result *dres = results;
+  if (!res_dev) {
+    if ((rc = ensure(ctx, ctx->stage_res, sizeof(dmz_hip_frame_result) * (size_t)n))) return rc;
+    dres = (dmz_hip_frame_result *)ctx->stage_res.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dres, results, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
+  if ((rc = run_scan(ctx, (const uint8_t *)dc, card_stride, n, only_warped, dres))) return rc;
+  if (!res_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+                           int width, int height, int n, int orientation, int options, uint8_t *cards,
+                           size_t card_stride, dmz_hip_frame_result *results) {
+  int rc = check_frames(ctx, y, frame_stride, row_stride, width, height, n);
+  if (rc) return rc;
+  if (!results) return fail(ctx, DMZ_HIP_EINVAL, "null results");
+  if (!cards) card_stride = (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT;
+  if (card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad card stride");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if ((rc = configure_detection(ctx, width, height, orientation))) return rc;
+  const void *dy = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, frame_stride * (size_t)n, &dy))) return rc;
+  const bool res_dev = is_device_ptr(results);
+  const bool cards_dev = cards && is_device_ptr(cards);
+  dmz_hip_frame_result *dres = results;
+  uint8_t *dcards = cards;
+  if (!res_dev) {
+    if ((rc = ensure(ctx, ctx->stage_res, sizeof(dmz_hip_frame_result) * (size_t)n))) return rc;
+    dres = (dmz_hip_frame_result *)ctx->stage_res.p;
+  }
+  if (!cards_dev) {
+    if ((rc = ensure(ctx, ctx->cards, card_stride * (size_t)n))) return rc;
+    dcards = (uint8_t *)ctx->cards.p;
+  }
+  if (((uintptr_t)dcards) & 3) return fail(ctx, DMZ_HIP_EINVAL, "card buffer must be 4-byte aligned");
+  if ((rc = run_detect(ctx, (const uint8_t *)dy, frame_stride, row_stride, nullptr, nullptr, 0, 0, n, dres)))
+    return rc;
+  if ((rc = run_transform(ctx, (const uint8_t *)dy, frame_stride, row_stride, width, height, n,
+                          orientation, options, dres, dcards, card_stride)))
+    return rc;
+  if ((rc = run_scan(ctx, dcards, card_stride, n, 1, dres))) return rc;
+  if (!res_dev)
+    HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  if (cards && !cards_dev)
+    HIP_TRY(ctx, hipMemcpyAsync(cards, dcards, card_stride * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (!res_dev || (cards && !cards_dev)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts, const float *dst_pts, float *m) {
+  if (!ctx || !src_pts || !dst_pts || !m) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure(ctx, ctx->misc, sizeof(float) * 32);
+  if (rc) return rc;
+  float *d = (float *)ctx->misc.p;
+  HIP_TRY(ctx, hipMemcpyAsync(d, src_pts, sizeof(float) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d + 8, dst_pts, sizeof(float) * 8, hipMemcpyHostToDevice, ctx->stream));
+  dmz_launch_persp(ctx->stream, 1, d, d + 8, d + 16);
+  HIP_TRY(ctx, hipMemcpyAsync(m, d + 16, sizeof(float) * 9, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_warp_perspective_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_stride,
+                                   int row_stride, int width, int height, int n, const float *matrices,
+                                   uint8_t *cards, size_t card_stride) {
+  int rc = check_frames(ctx, plane, frame_stride, row_stride, width, height, n);
+  if (rc) return rc;
+  if (!matrices || !cards || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const void *dp = nullptr, *dm = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, plane, frame_stride * (size_t)n, &dp))) return rc;
+  if ((rc = stage_in(ctx, ctx->misc, matrices, sizeof(float) * 9 * (size_t)n, &dm))) return rc;
+  if ((rc = ensure(ctx, ctx->mats, sizeof(DmzWarpMat) * (size_t)n))) return rc;
+  const bool cards_dev = is_device_ptr(cards);
+  uint8_t *dcards = cards;
+  if (!cards_dev) {
+    if ((rc = ensure(ctx, ctx->stage_cards, card_stride * (size_t)n))) return rc;
+    dcards = (uint8_t *)ctx->stage_cards.p;
+  }
+  dmz_launch_mats_from_float(ctx->stream, n, (const float *)dm, (DmzWarpMat *)ctx->mats.p);
+  {
+    StageTimer t(ctx, DMZ_HIP_STAGE_WARP);
+    dmz_launch_warp(ctx->stream, (const uint8_t *)dp, frame_stride, row_stride, width, height, n,
+                    (const DmzWarpMat *)ctx->mats.p, dcards, card_stride);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (!cards_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(cards, dcards, card_stride * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+static int run_model(dmz_hip_context *ctx, int which, int model, const float *x, int n, float *out,
+                     int in_len, int out_len) {
+  if (!ctx || !x || !out || n <= 0) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dx = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, x, sizeof(float) * (size_t)in_len * n, &dx))) return rc;
+  const bool out_dev = is_device_ptr(out);
+  float *dout = out;
+  if (!out_dev) {
+    if ((rc = ensure(ctx, ctx->misc, sizeof(float) * (size_t)out_len * n))) return rc;
+    dout = (float *)ctx->misc.p;
+  }
+  if (which == 0)
+    dmz_launch_vseg_model(ctx->stream, ctx->d_weights, ctx->d_w1t, (const float *)dx, n, dout);
+  else
+    dmz_launch_digit_model(ctx->stream, ctx->d_weights, ctx->d_hidwt, model, (const float *)dx, n, dout);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!out_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, sizeof(float) * (size_t)out_len * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_apply_vseg_model(dmz_hip_context *ctx, const float *x, int n, float *out) {
+  return run_model(ctx, 0, 0, x, n, out, 204, 3);
+}
+
+int dmz_hip_apply_digit_model(dmz_hip_context *ctx, int model, const float *x, int n, float *out) {
+  if (model < 0 || model > 2) return fail(ctx, DMZ_HIP_EINVAL, "model must be 0..2");
+  return run_model(ctx, 1, model, x, n, out, 27 * 19, 10);
+}
+
+static int run_synth(dmz_hip_context *ctx, int cards, uint64_t seed, uint64_t first, int n, uint8_t *out) {
+  if (!ctx || !out || n <= 0) return DMZ_HIP_EINVAL;
+  if (!is_device_ptr(out)) return fail(ctx, DMZ_HIP_EINVAL, "synthetic generator needs a device pointer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // generate in chunks so that the parameter scratch stays small
+  const int chunk = 8192;
+  int rc = ensure(ctx, ctx->synth, dmz_synth_params_bytes(chunk));
+  if (rc) return rc;
+  const size_t item = cards ? (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT : (size_t)640 * 480;
+  for (int base = 0; base < n; base += chunk) {
+    const int m = n - base < chunk ? n - base : chunk;
+    if (dmz_synth_upload_params(ctx->stream, seed, first + (uint64_t)base, m, ctx->synth.p) != 0)
+      return fail(ctx, DMZ_HIP_ERUNTIME, "synth parameter upload failed");
+    if (cards)
+      dmz_launch_synth_cards(ctx->stream, ctx->synth.p, m, out + item * (size_t)base);
+    else
+      dmz_launch_synth_frames(ctx->stream, ctx->synth.p, m, out + item * (size_t)base);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the scratch is reused by the next chunk
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_synth_frames(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n, uint8_t *y) {
+  return run_synth(ctx, 0, seed, first_index, n, y);
+}
+
+int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n, uint8_t *cards) {
+  return run_synth(ctx, 1, seed, first_index, n, cards);
+}
+
+int dmz_hip_set_profiling(dmz_hip_context *ctx, int enabled) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  ctx->profiling = enabled != 0;
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_get_stage_times(dmz_hip_context *ctx, float ms[DMZ_HIP_STAGE_COUNT],
+                            int launches[DMZ_HIP_STAGE_COUNT], int reset) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  resolve_spans(ctx);
+  for (int i = 0; i < DMZ_HIP_STAGE_COUNT; i++) {
+    if (ms) ms[i] = ctx->stage_ms[i];
+    if (launches) launches[i] = ctx->stage_launches[i];
+    if (reset) {
+      ctx->stage_ms[i] = 0.0f;
+      ctx->stage_launches[i] = 0;
+    }
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_malloc(dmz_hip_context *ctx, size_t bytes, void **dptr) {
+  if (!ctx || !dptr) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMalloc(dptr, bytes));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_free(dmz_hip_context *ctx, void *dptr) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(dptr));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_memcpy_h2d(dmz_hip_context *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_memcpy_d2h(dmz_hip_context *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+}  // extern "C"

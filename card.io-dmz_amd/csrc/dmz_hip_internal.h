@@ -1,0 +1,114 @@
+// dmz_hip_internal.h -- shared between the HIP kernels and the C-ABI host code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dmz_hip.h"
+
+// ---------------------------------------------------------------------------
+// Model weights: float offsets into the blob written by tools/extract_models.py
+// (card.io-dmz_amd/weights/dmz_models.bin, after its 16-byte header).
+// ---------------------------------------------------------------------------
+namespace dmzw {
+constexpr int VSEG_W1 = 0;                    // 50 x 204   modelm_befe75da.cpp:16
+constexpr int VSEG_B1 = VSEG_W1 + 50 * 204;   // 50
+constexpr int VSEG_W2 = VSEG_B1 + 50;         // 3 x 50
+constexpr int VSEG_B2 = VSEG_W2 + 150;        // 3
+constexpr int DIGIT0 = VSEG_B2 + 3;           // 3 x DIGIT_STRIDE  modelc_*.cpp:22-1818
+constexpr int D_CONV_W = 0;                   // 8 x 3 x 3
+constexpr int D_CONV_B = 72;                  // 8
+constexpr int D_HID_W = 80;                   // 32 x 320
+constexpr int D_HID_B = 80 + 10240;           // 32
+constexpr int D_LOG_W = D_HID_B + 32;         // 10 x 32
+constexpr int D_LOG_B = D_LOG_W + 320;        // 10
+constexpr int DIGIT_STRIDE = D_LOG_B + 10;    // 10682
+constexpr int SLASH = DIGIT0 + 3 * DIGIT_STRIDE;
+constexpr int EXPIRY = SLASH + 80 * 176 + 80 + 160 + 2;
+constexpr int TOTAL = EXPIRY + 1250 + 50 + 50000 + 40 + 21120 + 176 + 1760 + 10;
+}  // namespace dmzw
+
+// ---------------------------------------------------------------------------
+// Detection tables.  Everything that the reference evaluates with libm on the
+// host for a (plane size, orientation, box) is evaluated on the host here too
+// (glibc, same as the x86 reference) and handed to the kernels, so that the
+// device never calls a transcendental on the bit-exact detect->warp chain:
+//   hough.cpp:112-124 tabSin/tabCos/slope bounds, hough.cpp:190-191 angles,
+//   geometry.cpp:37-41 origin shift, geometry.cpp:22 cosf/sinf of the angle.
+// ---------------------------------------------------------------------------
+constexpr int kNumAngle = 10;  // cvRound(2 * 5deg / 1deg), hough.cpp:98
+
+struct DmzBoxParams {
+  int x, y, w, h;        // ROI in the plane (dmz.cpp:279-341)
+  int vertical;          // LineOrientationVertical (left/right boxes)
+  int numrho;            // hough.cpp:99
+  int threshold;         // max(w,h)/6, dmz.cpp:246
+  int tab_sin[kNumAngle];
+  int tab_cos[kNumAngle];
+  float slope_a, slope_b;        // hough.cpp:117-124
+  float theta_n[kNumAngle];      // n*theta + theta_min (float)
+  double delta_rho[kNumAngle];   // geometry.cpp:37-40 for this box origin and angle n
+  float cos_t[kNumAngle];        // cosf(theta_n), geometry.cpp:22
+  float sin_t[kNumAngle];        // sinf(theta_n)
+  float rho_multiplier;          // dmz.cpp:383
+  uint32_t inv_w;                // ceil(2^32 / w): flat index -> (row, col)
+  int pad_;
+};
+
+struct DmzDetectParams {
+  DmzBoxParams box[4];  // result order: top, left, bottom, right
+};
+
+// Per-frame detection scratch written by k_detect_box and consumed by k_geometry.
+struct DmzBoxHit {
+  int found;  // line found in this box (hough maxVal > threshold)
+  int n;      // angle index
+  int r;      // rho index
+  int max_val;
+};
+
+// Inverse homography (dst -> src) of one frame, double, as cv::invert leaves it.
+struct DmzWarpMat {
+  double m[9];
+  int valid;
+  int pad_;
+};
+
+// LDS capacity of the detect kernel (one (frame, box) per workgroup).
+constexpr int kDetectMaxPixels = 11264;
+constexpr int kDetectSrcBytes = 13824;
+constexpr int kDetectThreads = 1024;
+constexpr int kDetectLdsBytes = kDetectSrcBytes + 2 * kDetectMaxPixels * 4;
+
+// ---- launchers (defined in the .hip files) --------------------------------
+void dmz_launch_detect(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
+                       int n, const DmzDetectParams &p, DmzBoxHit *hits /* n x 4 */,
+                       const int *skip_mask /* n x 4 or null: nonzero = already found */);
+void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params_by_plane /* 3, device */,
+                         const DmzBoxHit *hits /* 3 planes x n x 4 */, int nplanes,
+                         dmz_hip_frame_result *results);
+void dmz_launch_homography(hipStream_t s, int n, int orientation, int options,
+                           dmz_hip_frame_result *results, DmzWarpMat *mats);
+void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9);
+void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMat *mats);
+void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
+                     int width, int height, int n, const DmzWarpMat *mats, uint8_t *cards,
+                     size_t card_stride);
+void dmz_launch_vseg(hipStream_t s, const float *weights, const float *w1t /* [204][64] */,
+                     const uint8_t *cards, size_t card_stride, int n, int only_warped,
+                     dmz_hip_frame_result *results);
+void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
+                     dmz_hip_frame_result *results);
+void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidwt /* 3 x [320][32] */,
+                       const uint8_t *cards, size_t card_stride, int n,
+                       dmz_hip_frame_result *results);
+void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *w1t, const float *x,
+                           int n, float *out);
+void dmz_launch_digit_model(hipStream_t s, const float *weights, const float *hidwt, int model,
+                            const float *x, int n, float *out);
+size_t dmz_synth_params_bytes(int n);
+int dmz_synth_upload_params(hipStream_t s, uint64_t seed, uint64_t first, int n, void *scratch);
+void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *y);
+void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards);
+int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
+int dmz_configure_scan(void);

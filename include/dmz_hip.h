@@ -1,0 +1,184 @@
+/*
+ * dmz_hip.h -- C-ABI of the MI355X (gfx950) implementation of the card.io-dmz
+ * per-frame scan hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * This is the drop-in boundary: each entry point is the batched form of one of
+ * the reference's per-frame entry points, and the reference-side binding a
+ * maintainer would add is shown in INTEGRATION.md.  The single-frame C++
+ * mirrors of the reference API (dmz_detect_edges, dmz_transform_card,
+ * scanner_add_frame_with_expiry, ... in card.io-dmz_amd/host/dmz.h) are
+ * batch-of-1 wrappers over these functions, with `dmz_context.mz`
+ * (reference dmz.h:17-20, mz.h:19-25) holding the dmz_hip_context exactly where
+ * the Android flavour keeps its GLES warp context (mz_android.cpp:233-240).
+ *
+ * Pointer convention: every image/result pointer may be a DEVICE pointer
+ * (HBM-resident batches: the fast path, nothing is copied) or a HOST pointer
+ * (staged through an internal device buffer; PCIe-bound).  The kind is detected
+ * with hipPointerGetAttributes.
+ *
+ * Error convention: the reference has no error codes (bool/found flags, asserts,
+ * silent CPU fallback on accelerator failure: mz_android.cpp:8-24).  Here every
+ * function returns DMZ_HIP_OK (0) or a negative DMZ_HIP_E* code and
+ * dmz_hip_last_error() gives the text.  There is NO CPU fallback: a missing GPU
+ * or kernel image is an error.
+ */
+#ifndef DMZ_HIP_H
+#define DMZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMZ_HIP_OK 0
+#define DMZ_HIP_EINVAL (-1)     /* bad argument (assert in the reference: dmz.cpp:373-377, frame.cpp:25-29) */
+#define DMZ_HIP_ENODEVICE (-2)  /* no usable gfx950 device / HIP runtime error at create */
+#define DMZ_HIP_ERUNTIME (-3)   /* HIP error during a batch call */
+#define DMZ_HIP_EUNSUPPORTED (-4) /* geometry outside what the LDS-resident kernels hold */
+
+/* FrameOrientation, reference dmz_olm.h:17-23 */
+#define DMZ_ORIENTATION_PORTRAIT 1
+#define DMZ_ORIENTATION_PORTRAIT_UPSIDE_DOWN 2
+#define DMZ_ORIENTATION_LANDSCAPE_RIGHT 3
+#define DMZ_ORIENTATION_LANDSCAPE_LEFT 4
+
+#define DMZ_CARD_WIDTH 428  /* kCreditCardTargetWidth,  dmz_constants.h:8 */
+#define DMZ_CARD_HEIGHT 270 /* kCreditCardTargetHeight, dmz_constants.h:9 */
+
+/* Fixed-size POD result record, one per frame (1024 bytes).  It flattens what
+ * the reference returns per frame: dmz_edges + dmz_corner_points (dmz.h:22-37,
+ * dmz_olm.h:37-42) and the number-path fields of FrameScanResult (frame.h:14-28:
+ * NVerticalSegmentation n_vseg.h:14-21, NHorizontalSegmentation n_hseg.h:13-19,
+ * NumberScores n_categorize.h:14). */
+typedef struct dmz_hip_frame_result {
+  int32_t found[4];     /* dmz_edges order: top, left, bottom, right */
+  float rho[4];         /* ParametricLine.rho   (frame coordinates) */
+  float theta[4];       /* ParametricLine.theta */
+  float corners[8];     /* top_left, bottom_left, top_right, bottom_right (x,y) */
+  int32_t found_all;    /* return value of dmz_detect_edges (dmz.cpp:418-438) */
+  int32_t flags;        /* DMZ_HIP_FLAG_* */
+  float vseg_score;     /* NVerticalSegmentation.score */
+  int32_t vseg_y_offset;
+  int32_t pattern_type; /* 0 unknown, 1 visa-like (16), 2 amex-like (15); n_vseg.cpp:20-24 */
+  int32_t n_offsets;    /* NHorizontalSegmentation.n_offsets */
+  uint16_t offsets[16];
+  float hseg_score;
+  float number_width;
+  int32_t pattern_offset;
+  float number_score;   /* n_offsets - scores.sum()  (frame.cpp:63) */
+  uint8_t digits[16];   /* argmax of each scores row (first maximum) */
+  float scores[16][10]; /* NumberScores, row-major */
+  int32_t expiry_month; /* 0 = not scanned */
+  int32_t expiry_year;
+  uint8_t reserved[1024 - 816];
+} dmz_hip_frame_result;
+
+#define DMZ_HIP_FLAG_USABLE 1      /* FrameScanResult.usable */
+#define DMZ_HIP_FLAG_UPSIDE_DOWN 2 /* FrameScanResult.upside_down */
+#define DMZ_HIP_FLAG_VSEG_OK 4     /* passed the vseg gates (frame.cpp:38-47) */
+#define DMZ_HIP_FLAG_WARPED 8      /* card image was rectified */
+
+/* dmz_hip_transform_batch / pipeline option bits */
+#define DMZ_HIP_OPT_TRUNCATE_CORNERS 1 /* cast corner points to int like cython_dmz/dmz.pyx:267-270 */
+
+typedef struct dmz_hip_context dmz_hip_context;
+
+/* Number of HIP devices (does not initialise a device). */
+int dmz_hip_device_count(void);
+
+/* Replaces mz_create()/dmz_context_create() (mz.h:19, dmz.cpp:23-27): binds a
+ * device, uploads the model weights and the Hough/geometry tables. */
+int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out);
+/* Replaces mz_destroy()/dmz_context_destroy() (mz.h:22, dmz.cpp:29-32). */
+void dmz_hip_context_destroy(dmz_hip_context *ctx);
+/* Replaces mz_prepare_for_backgrounding() (mz.h:25): drains the stream. */
+int dmz_hip_synchronize(dmz_hip_context *ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+int dmz_hip_set_stream(dmz_hip_context *ctx, void *hip_stream);
+const char *dmz_hip_last_error(const dmz_hip_context *ctx);
+
+/* Batched dmz_detect_edges (dmz.h:82-83, dmz.cpp:371-439) on n luma planes.
+ * y: n planes of height x width bytes, plane i at y + i*frame_stride, rows
+ * row_stride bytes apart.  cb/cr (half-size planes, chroma fallback of
+ * dmz.cpp:346-369) may be NULL.  Writes found/rho/theta/corners/found_all. */
+int dmz_hip_detect_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride,
+                         int row_stride, int width, int height,
+                         const uint8_t *cb, const uint8_t *cr, size_t chroma_frame_stride,
+                         int chroma_row_stride, int n, int orientation,
+                         dmz_hip_frame_result *results);
+
+/* Batched dmz_transform_card (dmz.h:92-96, dmz.cpp:443-497; llcv_unwarp
+ * warp.cpp:130-169) of a 1-channel plane: for every frame with
+ * results[i].found_all, rectifies to cards + i*card_stride (428x270, row stride
+ * 428) and sets DMZ_HIP_FLAG_WARPED; other cards are zero-filled. */
+int dmz_hip_transform_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_stride,
+                            int row_stride, int width, int height, int n, int orientation,
+                            int options, dmz_hip_frame_result *results, uint8_t *cards,
+                            size_t card_stride);
+
+/* Batched scan_card_image number path (frame.h:34, frame.cpp:24-81 as driven by
+ * scanner_add_frame_with_expiry scan.cpp:41-50) on n 428x270 cards.
+ * only_warped != 0: skip cards whose result lacks DMZ_HIP_FLAG_WARPED. */
+int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride,
+                             int n, int only_warped, dmz_hip_frame_result *results);
+
+/* detect -> transform(Y) -> scan for n frames (the cython_dmz/dmz.pyx:379-483
+ * call sequence).  cards may be NULL (an internal buffer is used). */
+int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride,
+                           int row_stride, int width, int height, int n, int orientation,
+                           int options, uint8_t *cards, size_t card_stride,
+                           dmz_hip_frame_result *results);
+
+/* Single homography, llcv_calc_persp_transform (cv/warp.h:25, warp.cpp:34-125),
+ * computed on the device with the same kernel code the batch path uses.
+ * src_pts/dst_pts: 4 (x,y) pairs; m: 9 floats row-major (host pointers). */
+int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts,
+                                 const float *dst_pts, float *m);
+/* Batched cvWarpPerspective as used by llcv_unwarp (warp.cpp:153-166) with
+ * caller-supplied 3x3 float matrices (n x 9, row-major). */
+int dmz_hip_warp_perspective_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_stride,
+                                   int row_stride, int width, int height, int n,
+                                   const float *matrices, uint8_t *cards, size_t card_stride);
+
+/* Model forward passes on n inputs (device or host pointers): the generated
+ * applym_befe75da / applyc_{5c241121,01266c1b,b00bf70c} entry points
+ * (models/generated/modelm_befe75da.hpp, modelc_5c241121.hpp, ...), used by the
+ * known-answer tests. */
+int dmz_hip_apply_vseg_model(dmz_hip_context *ctx, const float *x /* n x 204 */, int n,
+                             float *out /* n x 3 */);
+int dmz_hip_apply_digit_model(dmz_hip_context *ctx, int model /* 0..2 */,
+                              const float *x /* n x 27 x 19 */, int n, float *out /* n x 10 */);
+
+/* Synthetic inputs resident in HBM (bench/test generator; byte-identical to
+ * oracle/orc_synth.c).  Frames are 640x480, cards 428x270, tightly packed. */
+int dmz_hip_synth_frames(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n,
+                         uint8_t *y);
+int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n,
+                        uint8_t *cards);
+
+/* Per-stage device timing with hipEvents on the context's stream. */
+#define DMZ_HIP_STAGE_DETECT 0
+#define DMZ_HIP_STAGE_GEOMETRY 1
+#define DMZ_HIP_STAGE_WARP 2
+#define DMZ_HIP_STAGE_VSEG 3
+#define DMZ_HIP_STAGE_HSEG 4
+#define DMZ_HIP_STAGE_DIGITS 5
+#define DMZ_HIP_STAGE_COUNT 6
+int dmz_hip_set_profiling(dmz_hip_context *ctx, int enabled);
+/* ms[i] = accumulated milliseconds, launches[i] = launch count since the last reset. */
+int dmz_hip_get_stage_times(dmz_hip_context *ctx, float ms[DMZ_HIP_STAGE_COUNT],
+                            int launches[DMZ_HIP_STAGE_COUNT], int reset);
+
+/* Raw device memory helpers so that non-torch hosts (tests, C++ callers) can
+ * keep batches resident. */
+int dmz_hip_malloc(dmz_hip_context *ctx, size_t bytes, void **dptr);
+int dmz_hip_free(dmz_hip_context *ctx, void *dptr);
+int dmz_hip_memcpy_h2d(dmz_hip_context *ctx, void *dst, const void *src, size_t bytes);
+int dmz_hip_memcpy_d2h(dmz_hip_context *ctx, void *dst, const void *src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMZ_HIP_H */
