@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the card.io-dmz scan hot path on MI355X.
+
+A "step" = one pass of the full per-frame pipeline (detect edges -> rectify card
+-> number-row search -> digit segmentation -> digit categorisation) over one
+HBM-resident batch of synthetic 640x480 luma frames (BASELINE.json configs[3],
+number path).  `value` = frames/s of the whole job (all ranks), inputs resident
+in HBM when the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU; frames are sharded (weak scaling: B frames per GPU) and each
+step ends with an RCCL all-gather of the fixed-size result records.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+SEED = 0xCA4D10
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3     # vector == f32-MFMA peak
+# ALGORITHMIC bytes / flops per frame and per kernel (DESIGN.md "Kernels and rooflines").
+# The pipeline total is SURVEY 8(d)'s 423,784 B/frame: 307,200 read + 115,560 card written
+# + 1,024 result record.
+ALGO = {
+    #            bytes/frame                flop/frame
+    "detect":   (307200 + 64,               2 * 2.2e6 + 1.2e6),
+    "geometry": (64 + 152 + 80,             2.0e3),
+    "warp":     (115560,                    1.2e6 + 0.9e6),
+    "vseg":     (103 * 408 + 24,            2 * 103 * (204 * 50 + 150)),
+    "hseg":     (27 * 428 + 48,             2.0e5),
+    "digits":   (16 * 27 * 19 + 744,        16 * 3 * 2 * (8 * 360 * 9 + 320 * 32 + 320)),
+}
+PIPELINE_BYTES = 307200 + 115560 + 1024
+
+
+def cpu_baseline(orc_mod, frames, budget_s=12.0):
+    """The CPU oracle (a port of the reference algorithm, oracle/*.c) timed on ONE host
+    core over a bounded sample of the same frames."""
+    o = orc_mod.Oracle()
+    t0 = time.perf_counter()
+    done = 0
+    for f in frames:
+        o.scan_frame(f, want_card=True)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the benchmark's synthetic 640x480 frames, full pipeline, 1 thread, %.1f s"
+                      % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")  # RCCL on ROCm
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    pkg = entry.load_package()
+    from dmz_amd import sharding
+    ctx = pkg.Context(dev.index)  # raises without the HIP library / a GPU: no fallback
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    B = args.batch
+    frames = torch.empty((B, pkg.FRAME_H, pkg.FRAME_W), dtype=torch.uint8, device=dev)
+    cards = torch.empty((B, pkg.CARD_H, pkg.CARD_W), dtype=torch.uint8, device=dev)
+    results = torch.zeros((B, 1024), dtype=torch.uint8, device=dev)
+    gathered = torch.empty((world * B, 1024), dtype=torch.uint8, device=dev) if world > 1 else None
+    # every rank scans its own contiguous slice of the synthetic corpus (weak scaling:
+    # the corpus is world*B frames, rank g owns [g*B, (g+1)*B))
+    lo, hi = sharding.shard_range(world * B, rank, world)
+    assert hi - lo == B
+    ctx.synth_frames(SEED, lo, B, frames)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        ctx.pipeline(frames, B, results, cards)
+        if world > 1:
+            sharding.gather_results(results, world, out=gathered)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dev_ms = ev0.elapsed_time(ev1)
+
+    # per-kernel durations with hipEvents on the launch stream (untimed extra steps)
+    ctx.set_profiling(True)
+    ctx.stage_times(reset=True)
+    prof_steps = 2
+    for _ in range(prof_steps):
+        ctx.pipeline(frames, B, results, cards)
+    stage = ctx.stage_times(reset=True)
+    ctx.set_profiling(False)
+
+    if rank == 0:
+        res = results.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+        gates = {
+            "found_all": float((res["found_all"] != 0).mean()),
+            "vseg_ok": float(((res["flags"] & pkg.FLAG_VSEG_OK) != 0).mean()),
+            "usable": float(((res["flags"] & pkg.FLAG_USABLE) != 0).mean()),
+        }
+        per_stage = {}
+        for name, (ms, cnt) in stage.items():
+            if cnt == 0:
+                continue
+            avg_ms = ms / prof_steps  # all launches of the stage in one step
+            by, fl = ALGO[name]
+            per_stage[name] = {
+                "ms_per_step": round(avg_ms, 4),
+                "GBps": round(by * B / (avg_ms * 1e-3) / 1e9, 2),
+                "TFLOPs": round(fl * B / (avg_ms * 1e-3) / 1e12, 3),
+            }
+        dom = max(per_stage, key=lambda k: per_stage[k]["ms_per_step"])
+        hbm_frac = per_stage[dom]["GBps"] / HBM_PEAK_GBPS
+        fl_frac = per_stage[dom]["TFLOPs"] / FP32_PEAK_TFLOPS
+        if hbm_frac >= fl_frac:
+            roof = {"bound": "hbm", "achieved": per_stage[dom]["GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": None}
+        else:
+            roof = {"bound": "mfma", "achieved": per_stage[dom]["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fl_frac, 5), "traffic": None}
+        roof["kernel"] = dom
+        roof["launch_ms"] = per_stage[dom]["ms_per_step"]
+        value = world * B * args.steps / elapsed
+        roof["pipeline_GBps"] = round(value / world * PIPELINE_BYTES / 1e9, 2)
+        roof["pipeline_frac_of_hbm"] = round(value / world * PIPELINE_BYTES / 1e9 / HBM_PEAK_GBPS, 5)
+
+        out = {
+            "metric": "frames/sec full scan pipeline (640x480)",
+            "value": round(value, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 images / int32 votes / f32 scores (f64 warp coordinates)",
+            "data": "synthetic",
+            "config": {
+                "workload": "full pipeline detect->warp->vseg->hseg->digits (number path, no expiry), "
+                            "%d synthetic 640x480 Y frames per GPU resident in HBM" % B,
+                "frames_per_gpu": B,
+                "parallelism": "frame-sharded x%d, all-gather of 1 KiB result records" % world,
+                "gate_pass_rates": gates,
+                "device_ms_per_step": round(dev_ms / args.steps, 3),
+            },
+            "roofline": roof,
+            "stages": per_stage,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = frames[:2048].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

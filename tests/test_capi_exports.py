@@ -1,0 +1,42 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/dmz_hip.h
+declares.  No compute call is made here."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "dmz_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(dmz_hip_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 20
+    lib = pkg.load_library()
+    for name in declared:
+        assert hasattr(lib, name), "libdmz_hip.so does not export %s" % name
+    assert sorted(pkg.EXPORTS) == declared
+
+
+def test_result_record_layout(pkg, orc):
+    assert pkg.RESULT_DTYPE.itemsize == 1024
+    assert pkg.RESULT_DTYPE == orc.RESULT_DTYPE
+    header = open(os.path.join(ROOT, "include", "dmz_hip.h")).read()
+    assert "uint8_t reserved[1024 - 816];" in header
+    assert pkg.RESULT_DTYPE.fields["reserved"][1] == 816
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    import pytest
+    lib = pkg.load_library()
+    if lib.dmz_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.DmzHipError):
+        pkg.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "card.io-dmz_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".c")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "import orc" not in text and "dmz_oracle.h" not in text, f

@@ -1,0 +1,179 @@
+"""GPU parity per stage, through the C-ABI: model KATs, homography, warp with the oracle's
+matrix, scan of pre-warped cards, edge cases (blank / upside-down / undetectable frames,
+host-pointer staging, truncated corners)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KATS = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_kats.npz"))
+SEED = 4242
+
+
+def test_model_kats_on_device(ctx):
+    out = ctx.apply_vseg_model(KATS["vseg_in"])[0]
+    assert np.abs(out - KATS["vseg_out"]).max() <= 1e-5
+    for idx, name in enumerate(("5c241121", "01266c1b", "b00bf70c")):
+        out = ctx.apply_digit_model(idx, KATS["digit_%s_in" % name])[0]
+        assert np.abs(out - KATS["digit_%s_out" % name]).max() <= 1e-5, name
+
+
+def test_models_match_oracle_on_random_batches(ctx, oracle):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 1, (64, 204)).astype(np.float32)
+    got = ctx.apply_vseg_model(x)
+    want = np.stack([oracle.applym_vseg(r) for r in x])
+    assert np.abs(got - want).max() <= 1e-5
+    d = rng.uniform(0, 1, (32, 513)).astype(np.float32)
+    for m in range(3):
+        got = ctx.apply_digit_model(m, d)
+        want = np.stack([oracle.applyc_digit(m, r) for r in d])
+        assert np.abs(got - want).max() <= 1e-5
+
+
+def test_homography_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(1)
+    dst = np.array([0, 0, 427, 0, 0, 269, 427, 269], np.float32)
+    base = np.array([106, 105, 533, 105, 106, 374, 533, 374], np.float32)
+    for _ in range(200):
+        src = base + rng.uniform(-12, 12, 8).astype(np.float32)
+        a, b = ctx.calc_persp_transform(src, dst), oracle.calc_persp_transform(src, dst)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_warp_with_given_matrices_byte_exact(ctx, pkg, oracle):
+    """SURVEY Appendix B layering (ii): feed the oracle's float[9] to the HIP warp."""
+    rng = np.random.default_rng(2)
+    n = 6
+    frames = np.stack([oracle.synth_frame(SEED, i)[0] for i in range(n)])
+    dst = np.array([0, 0, 427, 0, 0, 269, 427, 269], np.float32)
+    base = np.array([106, 105, 533, 105, 106, 374, 533, 374], np.float32)
+    mats = []
+    for i in range(n):
+        jitter = rng.uniform(-30, 30, 8) if i >= 4 else rng.uniform(-6, 6, 8)  # i>=4: partly outside
+        if i == 5:
+            jitter += np.array([-150, -130] * 4)  # card hangs over the frame's top-left corner
+        mats.append(oracle.calc_persp_transform(base + jitter.astype(np.float32), dst))
+    mats = np.stack(mats)
+    cards = np.zeros((n, 270, 428), np.uint8)
+    ctx.warp_perspective(frames, n, mats, cards)  # host pointers: staged through HBM
+    for i in range(n):
+        want = oracle.warp_perspective(frames[i], mats[i])
+        assert np.array_equal(cards[i], want), (i, int((cards[i] != want).sum()))
+
+
+def test_scan_prewarped_cards(ctx, pkg, oracle):
+    """BASELINE configs[2]: vseg/hseg/categorise on pre-warped 428x270 crops."""
+    n = 40
+    dcards = ctx.alloc(n * pkg.CARD_BYTES)
+    res = ctx.alloc(n * 1024)
+    res.upload(np.zeros(n * 1024, np.uint8))
+    ctx.synth_cards(SEED, 0, n, dcards.ptr)
+    ctx.scan_cards(dcards.ptr, n, res.ptr)
+    ctx.synchronize()
+    got = res.download(pkg.RESULT_DTYPE, n)
+    cards = dcards.download(np.uint8).reshape(n, 270, 428)
+    for i in range(n):
+        ref_card, _ = oracle.synth_card(SEED, i)
+        assert np.array_equal(cards[i], ref_card)
+        w = oracle.scan_card_image(cards[i], warped=False)
+        g = got[i]
+        assert g["vseg_y_offset"] == w["vseg_y_offset"] and g["pattern_type"] == w["pattern_type"], i
+        assert (g["flags"] & 7) == (w["flags"] & 7), i
+        assert np.array_equal(g["offsets"], w["offsets"]) and g["n_offsets"] == w["n_offsets"]
+        assert g["hseg_score"].view(np.uint32) == w["hseg_score"].view(np.uint32)
+        assert np.abs(g["scores"] - w["scores"]).max() <= 1e-4
+        assert np.array_equal(g["digits"], w["digits"])
+    dcards.free()
+    res.free()
+
+
+def test_edge_case_frames(ctx, pkg, oracle):
+    """blank, pure noise, a frame whose card is upside down, a card-less frame with one strong
+    edge, and a normal frame; host pointers in and out (staging path)."""
+    rng = np.random.default_rng(3)
+    normal, _ = oracle.synth_frame(SEED, 11)
+    blank = np.full((480, 640), 128, np.uint8)
+    noise = rng.integers(0, 256, (480, 640)).astype(np.uint8)
+    flipped = normal[::-1, ::-1].copy()
+    one_edge = np.full((480, 640), 50, np.uint8)
+    one_edge[:105] = 200
+    black = np.zeros((480, 640), np.uint8)
+    white = np.full((480, 640), 255, np.uint8)
+    frames = np.stack([blank, noise, flipped, one_edge, normal, black, white])
+    n = len(frames)
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    cards = np.zeros((n, 270, 428), np.uint8)
+    ctx.pipeline(frames, n, res, cards)
+    for i in range(n):
+        w, wcard = oracle.scan_frame(frames[i])
+        g = res[i]
+        assert np.array_equal(g["found"], w["found"]), i
+        assert g["found_all"] == w["found_all"], i
+        assert np.array_equal(cards[i], wcard), i
+        assert g["flags"] == w["flags"], (i, g["flags"], w["flags"])
+        if w["found_all"]:
+            assert np.array_equal(g["corners"].view(np.uint32), w["corners"].view(np.uint32))
+            assert g["vseg_y_offset"] == w["vseg_y_offset"]
+            assert np.abs(g["scores"] - w["scores"]).max() <= 1e-4
+    assert res[0]["found_all"] == 0 and res[5]["found_all"] == 0 and res[6]["found_all"] == 0
+    assert res[2]["flags"] & pkg.FLAG_UPSIDE_DOWN
+    assert res[3]["found"].tolist() == [1, 0, 0, 0]
+    assert res[4]["flags"] & pkg.FLAG_VSEG_OK
+
+
+def test_truncated_corners_option(ctx, pkg, oracle):
+    """cython_dmz/dmz.pyx:267-270 casts the corner points to int before dmz_transform_card."""
+    n = 4
+    frames = np.stack([oracle.synth_frame(SEED, 20 + i)[0] for i in range(n)])
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    cards = np.zeros((n, 270, 428), np.uint8)
+    ctx.pipeline(frames, n, res, cards, options=pkg.OPT_TRUNCATE_CORNERS)
+    for i in range(n):
+        w, wcard = oracle.scan_frame(frames[i], truncate=True)
+        assert np.array_equal(cards[i], wcard), i
+        assert res[i]["vseg_y_offset"] == w["vseg_y_offset"]
+
+
+def test_detect_then_transform_then_scan_equals_pipeline(ctx, pkg, oracle):
+    """The three batched entry points chained by the caller == dmz_hip_pipeline_batch."""
+    n = 5
+    frames = np.stack([oracle.synth_frame(SEED, 30 + i)[0] for i in range(n)])
+    r1 = np.zeros(n, pkg.RESULT_DTYPE)
+    c1 = np.zeros((n, 270, 428), np.uint8)
+    ctx.pipeline(frames, n, r1, c1)
+    r2 = np.zeros(n, pkg.RESULT_DTYPE)
+    c2 = np.zeros((n, 270, 428), np.uint8)
+    ctx.detect(frames, n, r2)
+    ctx.transform(frames, n, r2, c2)
+    ctx.scan_cards(c2, n, r2, only_warped=True)
+    assert np.array_equal(c1, c2)
+    assert r1.tobytes() == r2.tobytes()
+
+
+def test_chroma_fallback_planes(ctx, pkg, oracle):
+    """dmz.cpp:346-369: an edge missing on Y is searched on Cb then Cr (rho doubled)."""
+    y, _ = oracle.synth_frame(SEED, 40)
+    y_no_top = y.copy()
+    y_no_top[80:130] = y_no_top[140:141]  # wipe the top edge from the luma plane
+    cb = np.ascontiguousarray(y[::2, ::2])  # half-size plane that still has all four edges
+    cr = np.full((240, 320), 128, np.uint8)
+    res = np.zeros(1, pkg.RESULT_DTYPE)
+    ctx.detect(y_no_top[None], 1, res, cb=cb[None], cr=cr[None])
+    w = oracle.detect_edges(y_no_top, cb=cb, cr=cr)
+    assert np.array_equal(res[0]["found"], w["found"])
+    m = w["found"] != 0
+    assert np.array_equal(res[0]["rho"][m].view(np.uint32), w["rho"][m].view(np.uint32))
+    assert np.array_equal(res[0]["theta"][m].view(np.uint32), w["theta"][m].view(np.uint32))
+    assert np.array_equal(res[0]["corners"].view(np.uint32), w["corners"].view(np.uint32))
+    only_y = oracle.detect_edges(y_no_top)
+    assert only_y["found"][0] == 0 and w["found"][0] == 1  # the fallback is what found the top edge
+
+
+def test_bad_arguments_are_errors_not_crashes(ctx, pkg):
+    res = np.zeros(1, pkg.RESULT_DTYPE)
+    with pytest.raises(pkg.DmzHipError):
+        ctx.pipeline(np.zeros((1, 480, 640), np.uint8), 0, res)
+    with pytest.raises(pkg.DmzHipError):  # 1280x720: boxes exceed the LDS-resident detect kernel
+        ctx.detect(np.zeros((1, 720, 1280), np.uint8), 1, res, width=1280, height=720)

@@ -1,0 +1,106 @@
+"""Pins the C restatement (oracle/*.c) against the REFERENCE'S OWN compiled code
+(oracle/_ref/libdmzref.so, built by `make -C oracle ref` from /root/reference sources
+where they lie).  Skipped where the reference tree / prebuilt _ref is absent."""
+import numpy as np
+import pytest
+
+
+def test_reference_known_answer_tests_pass(reference):
+    # passm_befe75da, passc_{5c241121,01266c1b,b00bf70c}, passm_730c4cbd, passc_bf4dd6c8
+    assert reference.pass_kats() == 63
+
+
+def test_models_match_reference_on_random_inputs(oracle, reference):
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        x = rng.uniform(0, 1, 204).astype(np.float32)
+        assert np.abs(oracle.applym_vseg(x) - reference.applym_vseg(x)).max() <= 2e-6
+        d = rng.uniform(0, 1, 27 * 19).astype(np.float32)
+        for m in range(3):
+            assert np.abs(oracle.applyc_digit(m, d) - reference.applyc_digit(m, d)).max() <= 2e-6
+        s = rng.uniform(0, 1, 176).astype(np.float32)
+        assert np.abs(oracle.applym_slash(s) - reference.applym_slash(s)).max() <= 2e-6
+    for _ in range(3):
+        e = rng.uniform(0, 1, 176).astype(np.float32)
+        assert np.abs(oracle.applyc_expiry(e)[0] - reference.applyc_expiry(e)).max() <= 5e-6
+
+
+def test_line_by_shifting_origin_bit_exact(oracle, reference):
+    rng = np.random.default_rng(1)
+    for _ in range(3000):
+        th = np.float32(rng.uniform(1.4, 3.3))
+        rho = np.float32(rng.uniform(-400, 400))
+        xo, yo = int(rng.integers(0, 640)), int(rng.integers(0, 480))
+        assert oracle.line_by_shifting_origin(rho, th, xo, yo) == reference.line_by_shifting_origin(rho, th, xo, yo)
+    # the canonical box origins and the FLT_MAX "none" line
+    fmax = np.finfo(np.float32).max
+    for xo, yo in [(125, 91), (125, 360), (87, 119), (514, 119), (0, 5), (63, 46)]:
+        assert oracle.line_by_shifting_origin(fmax, fmax, xo, yo)[1] == reference.line_by_shifting_origin(fmax, fmax, xo, yo)[1]
+
+
+def test_parametric_intersect_bit_exact(oracle, reference):
+    rng = np.random.default_rng(2)
+    for _ in range(3000):
+        t1 = np.float32(rng.uniform(1.45, 1.70))
+        t2 = np.float32(rng.uniform(3.0, 3.3))
+        r1 = np.float32(rng.uniform(50, 420))
+        r2 = np.float32(rng.uniform(-640, 640))
+        assert oracle.parametric_intersect(r1, t1, r2, t2) == reference.parametric_intersect(r1, t1, r2, t2)
+    # parallel lines and negative determinant are rejected (geometry.cpp:24)
+    assert oracle.parametric_intersect(10, 1.5, 20, 1.5)[0] == reference.parametric_intersect(10, 1.5, 20, 1.5)[0] == 0
+    assert oracle.parametric_intersect(10, 3.1, 20, 1.5)[0] == reference.parametric_intersect(10, 3.1, 20, 1.5)[0]
+
+
+def test_calc_persp_transform_bit_exact(oracle, reference):
+    """Eigen 3.2.4 HouseholderQR<Matrix8f>::solve restated in scalar order."""
+    rng = np.random.default_rng(3)
+    dst = reference.card_dest_points()
+    assert dst.tolist() == [0, 0, 427, 0, 0, 269, 427, 269]
+    base = np.array([106, 105, 533, 105, 106, 374, 533, 374], np.float32)
+    for k in range(3000):
+        src = base + rng.uniform(-12, 12, 8).astype(np.float32)
+        if k % 5 == 0:
+            src = np.trunc(src)  # integer corners (cython_dmz/dmz.pyx:267-270)
+        a, b = oracle.calc_persp_transform(src, dst), reference.calc_persp_transform(src, dst)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, a, b)
+
+
+def test_vseg_box_sum_bit_exact(oracle, reference):
+    rng = np.random.default_rng(4)
+    for _ in range(500):
+        v = (rng.uniform(0, 1, 270) * (rng.uniform(0, 1, 270) > 0.4)).astype(np.float32)
+        a = (rng.uniform(0, 1, 270) * (rng.uniform(0, 1, 270) > 0.7)).astype(np.float32)
+        assert oracle.best_segmentation_for_vseg_scores(v, a) == reference.best_segmentation_for_vseg_scores(v, a)
+    z = np.zeros(270, np.float32)
+    assert oracle.best_segmentation_for_vseg_scores(z, z) == reference.best_segmentation_for_vseg_scores(z, z) == (0.0, 0, 0)
+
+
+def test_hseg_four_pass_search_bit_exact(oracle, reference):
+    """best_n_hseg_constrained with the four slices of best_n_hseg (n_hseg.cpp:104-147)."""
+    rng = np.random.default_rng(5)
+    f = np.float32
+    for t in range(40):
+        g = rng.uniform(0, 1, 428).astype(np.float32)
+        pat = 1 + t % 2
+        nd = 16 if pat == 1 else 15
+        sa = (np.zeros(16, np.uint16), 428.0, 0.0, 0)
+        sb = (np.zeros(16, np.uint16), 428.0, 0.0, 0)
+        for step in range(4):
+            if step == 0:
+                w, o = (f(17.1), f(19.7), f(0.5)), (0, 0xFFFF, 10)
+            else:
+                dw, st, do = [(f(0.5), f(0.2), 10), (f(0.2), f(0.1), 3), (f(0.1), f(0.05), 3)][step - 1]
+                nw, po = f(sa[2]), sa[3]
+                w, o = (nw - dw, nw + dw, st), (0 if po < do else po - do, po + do, 1)
+            sa = oracle.best_n_hseg_constrained(g, pat, w, o, *sa)
+            sb = reference.best_n_hseg_constrained(g, pat, w, o, *sb)
+            # offsets beyond the pattern's digit count are uninitialised stack in the reference
+            assert np.array_equal(sa[0][:nd], sb[0][:nd]) and sa[1:] == sb[1:], (t, step, sa, sb)
+
+
+def test_luhn_matches_reference(oracle, reference):
+    rng = np.random.default_rng(6)
+    for _ in range(500):
+        n = 15 + int(rng.integers(0, 2))
+        d = rng.integers(0, 10, n).astype(np.uint8)
+        assert oracle.passes_luhn(d) == reference.passes_luhn(d)
