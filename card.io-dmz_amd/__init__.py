@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdmz_hip.so")
+# DMZ_HIP_LIB: developer override used by tools/ablate.sh to time kernel variants
+LIB_PATH = os.environ.get("DMZ_HIP_LIB") or os.path.join(HERE, "libdmz_hip.so")
 
 FRAME_W, FRAME_H = 640, 480
 CARD_W, CARD_H = 428, 270

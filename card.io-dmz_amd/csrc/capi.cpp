@@ -140,14 +140,19 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
   int y1 = box[1] + box[3] > plane_h ? plane_h : box[1] + box[3];
   bp.x = x0; bp.y = y0; bp.w = x1 - x0; bp.h = y1 - y0;
   if (bp.w < 8 || bp.h < 8) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "detection box smaller than 8 px");
-  const int off = 4 + (bp.x & 3);
-  const int sp = (off + bp.w + 3 + 3) & ~3;
-  if (bp.w * bp.h > kDetectMaxPixels || sp * bp.h > kDetectSrcBytes)
-    return fail(ctx, DMZ_HIP_EUNSUPPORTED,
-                "detection box does not fit the LDS-resident detect kernel (max 11264 px)");
+  // LDS layout of k_detect_walk (detect.hip): source tile | edge map | accumulator
+  // The tile and the edge map live in "walk space": row = step along the short axis,
+  // column = lane across the long axis (the left/right boxes are transposed on load).
+  bp.lanes = vertical ? bp.h : bp.w;
+  bp.steps = vertical ? bp.w : bp.h;
+  const int off = vertical ? 4 : 4 + (bp.x & 3);  // horizontal boxes copy aligned words as they are
+  const int sp = (off + bp.lanes + 3 + 3) & ~3;
+  bp.tile_off = off;
+  bp.tile_stride = sp;
+  bp.nthreads = 64 * ((bp.lanes + 61) / 62);
   bp.vertical = vertical;
   bp.rho_multiplier = rho_multiplier;
-  bp.inv_w = (uint32_t)((0x100000000ull + (uint64_t)bp.w - 1) / (uint64_t)bp.w);
+  bp.inv_w = (uint32_t)((0x100000000ull + (uint64_t)bp.lanes - 1) / (uint64_t)bp.lanes);
   // dmz.cpp:246-258 + hough.cpp:98-124
   const float rho = 1.0f;
   const float theta = (float)DMZ_PI / 180.0f;
@@ -159,8 +164,19 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
   const int numangle = (int)lrint((double)((theta_max - theta_min) / theta));
   if (numangle != kNumAngle) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "unexpected Hough angle count");
   bp.numrho = (int)lrint((double)(((bp.w + bp.h) * 2 + 1) / rho));
-  if (bp.numrho * kNumAngle > kDetectMaxPixels)
-    return fail(ctx, DMZ_HIP_EUNSUPPORTED, "Hough accumulator does not fit LDS");
+  {
+    const int tile_bytes = (sp * bp.steps + 15) & ~15;
+    const int map_bytes = (bp.w * bp.h + 15) & ~15;
+    const int acc_bytes = (bp.numrho * kNumAngle * 2 + 15) & ~15;  // u16 vote counters
+    bp.lds_map = tile_bytes;
+    bp.lds_acc = tile_bytes + map_bytes;
+    bp.lds_red = bp.lds_acc + acc_bytes;
+    bp.lds_total = bp.lds_red + 512;
+    bp.list_cap = acc_bytes / 2;
+    if (bp.lds_total > kDetectMaxLds || bp.nthreads > kDetectMaxThreads || bp.w * bp.h > 65535)
+      return fail(ctx, DMZ_HIP_EUNSUPPORTED,
+                  "detection box does not fit the LDS-resident detect kernel");
+  }
   float ang = theta_min;
   for (int n = 0; n < kNumAngle; ang += theta, n++) {
     bp.tab_sin[n] = (int)floorf(1024 * sinf(ang) * irho);
@@ -281,7 +297,8 @@ int run_detect(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int 
   DmzBoxHit *hits = (DmzBoxHit *)ctx->hits.p;
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_DETECT);
-    dmz_launch_detect(ctx->stream, y, frame_stride, row_stride, n, ctx->h_params[0], hits, nullptr);
+    if (dmz_launch_detect(ctx->stream, y, frame_stride, row_stride, n, ctx->h_params[0], hits, nullptr))
+      return fail(ctx, DMZ_HIP_ERUNTIME, "detect launch failed");
     if (nplanes == 3) {
       // chroma fallback (dmz.cpp:351-367): a box is searched on Cb only if Y found nothing,
       // on Cr only if neither Y nor Cb did.  hits[] doubles as the skip mask: DmzBoxHit.found
@@ -293,13 +310,15 @@ int run_detect(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int 
       // skip1 = found on Y
       HIP_TRY(ctx, hipMemcpy2DAsync(skip, sizeof(int), hits, sizeof(DmzBoxHit), sizeof(int),
                                     (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      dmz_launch_detect(ctx->stream, cb, cstride, crow, n, ctx->h_params[1], hits + (size_t)n * 4, skip);
+      if (dmz_launch_detect(ctx->stream, cb, cstride, crow, n, ctx->h_params[1], hits + (size_t)n * 4, skip))
+        return fail(ctx, DMZ_HIP_ERUNTIME, "detect launch failed");
       // skip2 = found on Y or Cb: k_geometry takes the first plane that found the edge, so it
       // is enough for correctness that Cr is searched wherever Cb found nothing.
       int *skip2 = skip + (size_t)n * 4;
       HIP_TRY(ctx, hipMemcpy2DAsync(skip2, sizeof(int), hits + (size_t)n * 4, sizeof(DmzBoxHit),
                                     sizeof(int), (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      dmz_launch_detect(ctx->stream, cr, cstride, crow, n, ctx->h_params[2], hits + (size_t)n * 8, skip2);
+      if (dmz_launch_detect(ctx->stream, cr, cstride, crow, n, ctx->h_params[2], hits + (size_t)n * 8, skip2))
+        return fail(ctx, DMZ_HIP_ERUNTIME, "detect launch failed");
     }
   }
   {

@@ -9,269 +9,382 @@
 //     int32 accumulate, saturate to int16.
 //   * Canny: the reference's stack flood fill is order independent in its
 //     result: edge set = 8-connected components of {NMS survivors with m > low}
-//     that contain a survivor with m > high.  Components are found with a
-//     lock-free union-find in LDS (path halving + CAS hooking).
+//     that contain a survivor with m > high.  Here: seeds are marked, then the
+//     mark is propagated over the candidate list (each hit is chased along its
+//     chain) until an iteration changes nothing.
 //   * Hough: votes are LDS integer atomics (order independent); the arg-max
 //     reproduces the reference's r-outer / n-inner / strict-> scan by breaking
 //     ties towards the smallest (r, n).
 //
-// CDNA4 mapping: the whole box lives in LDS (<= 11264 px): padded source tile,
-// one buffer of packed (h-derivative, h-smooth) int16 pairs, one of packed
-// (dx, dy) pairs; the union-find labels and later the Hough accumulator reuse
-// the dead buffers (101.5 KB per workgroup, 16 waves).  Rows are fetched from
-// HBM as aligned 32-bit words so that a wave reads contiguous row segments.
+// CDNA4 mapping ("walk" kernel).  The box is thin (28 or 38 px) and long (389 or
+// 241 px).  Everything is done in WALK SPACE: lanes are laid across the long
+// axis (one lane per column for the top/bottom boxes, one per row for the
+// left/right boxes, whose tile is transposed while it is loaded; 62 outputs + 2
+// halo lanes per wave) and every lane walks the short axis with a 7-deep
+// register window.  The across-axis 7-tap pair is three aligned LDS dwords, two
+// v_alignbyte and five v_dot4_u32_u8; the separable Sobel, the |dx|+|dy|
+// magnitude and the 3x3 non-maximum suppression never leave registers:
+// neighbours along the walk are the lane's own previous/next step, neighbours
+// across are the adjacent lanes (two wave shifts per step).  LDS holds only the
+// u8 source tile, the u8 edge map and the u16 vote counters (39 KB / 30 KB per
+// workgroup => 4 workgroups, 28 / 16 waves per CU), so one workgroup's barriers
+// are covered by the others.  The adaptive thresholds need the box-wide mean of
+// |dx|+|dy| before NMS, so the walk runs twice (sum pass, NMS pass): recomputing
+// ~30 integer ops per pixel is cheaper than parking 44 KB of gradients per
+// workgroup in LDS.
 #include "dmz_hip_internal.h"
 
 namespace {
 
-constexpr int NT = kDetectThreads;
+// developer ablation (tools/ablate.sh): -DDMZ_DETECT_STOP=k returns after phase k
+#ifndef DMZ_DETECT_STOP
+#define DMZ_DETECT_STOP 99
+#endif
+#define DMZ_STOP_AFTER(k, expr)                                   \
+  if (DMZ_DETECT_STOP == (k)) {                                   \
+    if (tid == 0) {                                               \
+      DmzBoxHit hh__ = {0, 0, 0, (int)(expr)};                    \
+      hits[frame * 4 + box_id] = hh__;                            \
+    }                                                             \
+    return;                                                       \
+  }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
-__device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
-__device__ __forceinline__ int hi16(int v) { return v >> 16; }
-
-// union-find on LDS labels (ECL-CC style): labels only ever decrease.
-__device__ __forceinline__ int uf_rep(volatile int *lab, int v) {
-  int cur = lab[v];
-  if (cur != v) {
-    int prev = v, next;
-    while (cur > (next = lab[cur])) {
-      lab[prev] = next;  // path halving
-      prev = cur;
-      cur = next;
-    }
-  }
-  return cur;
-}
-
-__device__ __forceinline__ void uf_unite(int *lab, int a, int b) {
-  int ra = uf_rep(lab, a), rb = uf_rep(lab, b);
-  while (ra != rb) {
-    if (ra < rb) { int t = ra; ra = rb; rb = t; }  // ra > rb: hook the larger root under the smaller
-    int old = atomicCAS(&lab[ra], ra, rb);
-    if (old == ra) break;
-    ra = uf_rep(lab, old);
-    rb = uf_rep(lab, rb);
-  }
-}
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
 // map byte bits
-constexpr int MAP_CAND = 1;    // survived NMS with m > low
-constexpr int MAP_STRONG = 2;  // ... and m > high
-constexpr int MAP_GATE = 4;    // gradient direction accepted by the Hough gate
-constexpr int MAP_ROOT_STRONG = 8;
+constexpr int MAP_CAND = 1;   // survived NMS with m > low
+constexpr int MAP_EDGE = 2;   // final edge pixel (seeded with m > high, then propagated)
+constexpr int MAP_GATE = 4;   // gradient direction accepted by the Hough gate
 
-__global__ __launch_bounds__(NT) void k_detect_box(const uint8_t *__restrict__ planes,
-                                                    size_t frame_stride, int row_stride,
-                                                    DmzDetectParams params,
-                                                    DmzBoxHit *__restrict__ hits,
-                                                    const int *__restrict__ skip_mask) {
-  // All LDS is carved from the dynamic region (keeps its base 16-byte aligned).
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  long long *s_red = (long long *)(lds + kDetectLdsBytes);                      // NT/64
-  unsigned long long *s_best = (unsigned long long *)(lds + kDetectLdsBytes + 128);  // NT/64
-  int *s_thr = (int *)(lds + kDetectLdsBytes + 256);                            // low, high
+struct WalkCtx {
+  const unsigned char *row0;  // LDS: aligned dword that holds tile byte (step 0, lane - 3)
+  int sh;                     // byte offset of (lane - 3) inside that dword
+  int sp;                     // tile row stride
+  int L, S;                   // lanes across, steps along
+  int l;                      // this lane's across coordinate (may be -1 or >= L on halo lanes)
+};
 
-  const int box_id = blockIdx.x & 3;  // 1-D grid: gridDim.y is limited to 65535
-  const int frame = blockIdx.x >> 2;
+// across-axis 7-tap pair (derivative {-1,-4,-5,0,5,4,1}, smooth {1,6,15,20,15,6,1}) of the
+// tile row `a` (already clamped to [0, S-1]) centred on this lane.
+__device__ __forceinline__ void across_taps(const WalkCtx &c, int a, int &ad, int &as) {
+  const uint32_t *p = (const uint32_t *)(c.row0 + a * c.sp);
+  const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, c.sh);  // taps 0..3
+  const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, c.sh);  // taps 4..6 (+1 unused)
+  as = (int)__builtin_amdgcn_udot4(lo, 0x140F0601u, __builtin_amdgcn_udot4(hi, 0x0001060Fu, 0u, false), false);
+  ad = (int)__builtin_amdgcn_udot4(hi, 0x00010405u, 0u, false) -
+       (int)__builtin_amdgcn_udot4(lo, 0x00050401u, 0u, false);
+}
+
+// The 7-deep window keeps the entry of along-position a in slot (a + 3) mod 7, so that
+// with the step loop unrolled by 7 every slot index is a compile-time constant.
+struct Window {
+  int d[7];  // across-derivative
+  int s[7];  // across-smooth
+};
+
+__device__ __forceinline__ void window_init(const WalkCtx &c, Window &wn) {
+  // along positions -3..+2 -> slots 0..5 (position +3 is pushed by the first window_step)
+#pragma unroll
+  for (int i = 0; i < 6; i++) across_taps(c, clampi(i - 3, 0, c.S - 1), wn.d[i], wn.s[i]);
+  wn.d[6] = wn.s[6] = 0;
+}
+
+// step s = s0 + K (s0 a multiple of 7): push position s+3, return the saturated (dx, dy)
+template <bool VERT, int K>
+__device__ __forceinline__ void window_step(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
+  across_taps(c, clampi(s + 3, 0, c.S - 1), wn.d[(K + 6) % 7], wn.s[(K + 6) % 7]);
+  // along axis: smooth the derivative, differentiate the smooth
+  const int g_ds = (wn.d[K % 7] + wn.d[(K + 6) % 7]) + 6 * (wn.d[(K + 1) % 7] + wn.d[(K + 5) % 7]) +
+                   15 * (wn.d[(K + 2) % 7] + wn.d[(K + 4) % 7]) + 20 * wn.d[(K + 3) % 7];
+  const int g_sd = (wn.s[(K + 6) % 7] - wn.s[K % 7]) + 4 * (wn.s[(K + 5) % 7] - wn.s[(K + 1) % 7]) +
+                   5 * (wn.s[(K + 4) % 7] - wn.s[(K + 2) % 7]);
+  // top/bottom boxes: across = x  => dx = g_ds, dy = g_sd ; left/right boxes: across = y
+  dx = clampi(VERT ? g_sd : g_ds, -32768, 32767);
+  dy = clampi(VERT ? g_ds : g_sd, -32768, 32767);
+}
+
+// NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
+// given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
+template <bool VERT>
+__device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, int low,
+                                          int high, int dxc, int dyc, int mp, int mp_lo, int mp_hi,
+                                          int mc, int mc_lo, int mc_hi, int mn, int mn_lo, int mn_hi,
+                                          unsigned char *map, unsigned short *list, int *s_int) {
+  const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
+  const int m = mc;
+  // neighbours in image coordinates
+  int mN, mS, mW, mE, mNW, mNE, mSW, mSE;
+  if (!VERT) {  // row = step, col = lane
+    mN = mp; mS = mn; mW = mc_lo; mE = mc_hi;
+    mNW = mp_lo; mNE = mp_hi; mSW = mn_lo; mSE = mn_hi;
+  } else {      // row = lane, col = step
+    mN = mc_lo; mS = mc_hi; mW = mp; mE = mn;
+    mNW = mp_lo; mSW = mp_hi; mNE = mn_lo; mSE = mn_hi;
+  }
+  int flags = 0;
+  if (m > low) {
+    const int ax = iabs(dxc), ay = iabs(dyc);
+    const long long tg22x = (long long)ax * TG22;
+    const long long tg67x = tg22x + ((long long)(ax + ax) << 15);
+    const long long yy = (long long)ay << 15;
+    bool is_max;
+    if (yy < tg22x) {
+      is_max = m > mW && m >= mE;
+    } else if (yy > tg67x) {
+      is_max = m > mN && m >= mS;
+    } else {
+      const bool neg = (dxc ^ dyc) < 0;  // s = -1
+      is_max = neg ? (m > mNE && m > mSW) : (m > mNW && m > mSE);
+    }
+    if (is_max) flags = MAP_CAND | (m > high ? MAP_EDGE : 0);
+  }
+  bool use;
+  if (dxc != 0) {
+    const float slope = (float)dyc / (float)dxc;
+    use = VERT ? (slope >= bp.slope_a && slope <= bp.slope_b)
+               : (slope >= bp.slope_a || slope <= bp.slope_b);
+  } else {
+    use = !VERT;
+  }
+  if (use) flags |= MAP_GATE;
+  const int q = s * c.L + c.l;  // walk-space index
+  map[q] = (unsigned char)flags;
+  if ((flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND) {  // seeds need no propagation
+    const int slot = atomicAdd(&s_int[2], 1);
+    if (slot < bp.list_cap) list[slot] = (unsigned short)q;
+    else s_int[3] = 1;
+  }
+}
+
+template <bool VERT, int NT>
+__device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_stride, int row_stride,
+                            const DmzBoxParams &bp, int frame, int box_id,
+                            DmzBoxHit *__restrict__ hits, unsigned char *lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int w = bp.w, h = bp.h;
+  const int L = bp.lanes, S = bp.steps, N = L * S;
+  const uint32_t inv_L = bp.inv_w;
+  const int off = bp.tile_off, sp = bp.tile_stride;
 
-  if (skip_mask && skip_mask[frame * 4 + box_id]) return;
+  unsigned char *tile = lds;
+  unsigned char *map = lds + bp.lds_map;
+  unsigned int *acc32 = (unsigned int *)(lds + bp.lds_acc);
+  unsigned short *list = (unsigned short *)(lds + bp.lds_acc);  // candidate list, before voting
+  long long *s_red = (long long *)(lds + bp.lds_red);                    // 16 x 8 B
+  unsigned long long *s_best = (unsigned long long *)(lds + bp.lds_red + 128);  // 16 x 8 B
+  int *s_int = (int *)(lds + bp.lds_red + 256);                          // low, high, ncand, overflow
 
-  const DmzBoxParams &bp = params.box[box_id];
-  const int w = bp.w, h = bp.h, N = w * h;
-  const uint32_t inv_w = bp.inv_w;
-
-  unsigned char *srcp = lds;                           // padded source rows, later the map
-  int *bufA = (int *)(lds + kDetectSrcBytes);          // (hderiv, hsmooth) -> labels
-  int *bufB = bufA + kDetectMaxPixels;                 // (dx, dy) -> hough accumulator
-
-  // ---- A. ROI -> LDS, aligned 32-bit words, then replicate 3 px left/right ----
-  const int off = 4 + (bp.x & 3);                      // LDS column of ROI pixel 0
-  const int sp = (off + w + 3 + 3) & ~3;               // LDS row stride (bytes)
-  const int wpr = ((bp.x + w - 1) >> 2) - (bp.x >> 2) + 1;  // global words per row
-  const uint8_t *plane = planes + (size_t)frame * frame_stride;
-  for (int i = tid; i < wpr * h; i += NT) {
-    int r = i / wpr, j = i - r * wpr;
-    const uint8_t *g = plane + (size_t)(bp.y + r) * row_stride + ((bp.x >> 2) + j) * 4;
-    uint32_t v;
-    if ((((uintptr_t)g) & 3) == 0) {
-      v = *(const uint32_t *)g;
-    } else {  // plane base / row stride not 4-byte aligned: assemble from bytes
-      v = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
-    }
-    *(uint32_t *)(srcp + r * sp + 4 + j * 4) = v;
-  }
-  __syncthreads();
-  for (int i = tid; i < h * 6; i += NT) {
-    int r = i / 6, k = i - r * 6;
-    unsigned char *row = srcp + r * sp;
-    if (k < 3) row[off - 1 - k] = row[off];
-    else row[off + w + (k - 3)] = row[off + w - 1];
-  }
-  __syncthreads();
-
-  // ---- B. horizontal 7-tap pass: deriv {-1,-4,-5,0,5,4,1}, smooth {1,6,15,20,15,6,1} ----
-  for (int p = tid; p < N; p += NT) {
-    int r = __umulhi((uint32_t)p, inv_w);
-    int c = p - r * w;
-    if (c >= w) { c -= w; r++; }  // guard the (never hit for p*w < 2^32) rounding case
-    const unsigned char *s = srcp + r * sp + off + c - 3;
-    int a0 = s[0], a1 = s[1], a2 = s[2], a3 = s[3], a4 = s[4], a5 = s[5], a6 = s[6];
-    int hd = (a6 - a0) + 4 * (a5 - a1) + 5 * (a4 - a2);
-    int hs = (a0 + a6) + 6 * (a1 + a5) + 15 * (a2 + a4) + 20 * a3;
-    bufA[p] = pack16(hd, hs);
-  }
-  __syncthreads();
-
-  // ---- C. vertical pass -> dx, dy (saturated int16) + sum of saturated |.| ----
-  long long local_sum = 0;
-  for (int p = tid; p < N; p += NT) {
-    int r = __umulhi((uint32_t)p, inv_w);
-    int c = p - r * w;
-    if (c >= w) { c -= w; r++; }
-    int v0 = bufA[clampi(r - 3, 0, h - 1) * w + c];
-    int v1 = bufA[clampi(r - 2, 0, h - 1) * w + c];
-    int v2 = bufA[clampi(r - 1, 0, h - 1) * w + c];
-    int v3 = bufA[p];
-    int v4 = bufA[clampi(r + 1, 0, h - 1) * w + c];
-    int v5 = bufA[clampi(r + 2, 0, h - 1) * w + c];
-    int v6 = bufA[clampi(r + 3, 0, h - 1) * w + c];
-    int dx = (lo16(v0) + lo16(v6)) + 6 * (lo16(v1) + lo16(v5)) + 15 * (lo16(v2) + lo16(v4)) + 20 * lo16(v3);
-    int dy = (hi16(v6) - hi16(v0)) + 4 * (hi16(v5) - hi16(v1)) + 5 * (hi16(v4) - hi16(v2));
-    dx = clampi(dx, -32768, 32767);
-    dy = clampi(dy, -32768, 32767);
-    bufB[p] = pack16(dx, dy);
-    int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;  // cvAbs saturates 32768 -> 32767
-    local_sum += (ax > 32767 ? 32767 : ax) + (ay > 32767 ? 32767 : ay);
-  }
-  for (int o = 32; o > 0; o >>= 1) local_sum += __shfl_down(local_sum, o, 64);
-  if (lane == 0) s_red[wave] = local_sum;
-  __syncthreads();
-  if (tid == 0) {
-    long long tot = 0;
-    for (int i = 0; i < NT / 64; i++) tot += s_red[i];
-    // canny.cpp:573-578: mean in double; low = cvFloor(mean), high = cvFloor(3.0f * mean)
-    double mean = (double)tot / (double)N;
-    double lowt = mean, hight = 3.0f * mean;
-    s_thr[0] = (int)floor(lowt);
-    s_thr[1] = (int)floor(hight);
-  }
-  __syncthreads();
-  const int low = s_thr[0], high = s_thr[1];
-
-  // ---- D. non-maximum suppression (canny.cpp:213-285) + Hough slope gate ----
-  unsigned char *map = srcp;  // source tile is dead
-  int *lab = bufA;            // (hderiv, hsmooth) is dead
-  const int TG22 = 13573;     // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
-  for (int p = tid; p < N; p += NT) {
-    int r = __umulhi((uint32_t)p, inv_w);
-    int c = p - r * w;
-    if (c >= w) { c -= w; r++; }
-    const int v = bufB[p];
-    const int dxv = lo16(v), dyv = hi16(v);
-    const int ax = dxv < 0 ? -dxv : dxv, ay = dyv < 0 ? -dyv : dyv;
-    const int m = ax + ay;
-    int flags = 0;
-    if (m > low) {
-      const long long tg22x = (long long)ax * TG22;
-      const long long tg67x = tg22x + ((long long)(ax + ax) << 15);
-      const long long yy = (long long)ay << 15;
-      int q1, q2, ge2;  // neighbour pixel indices (-1 = outside, magnitude 0)
-      if (yy < tg22x) {          // sector 0: compare left / right
-        q1 = c > 0 ? p - 1 : -1;
-        q2 = c < w - 1 ? p + 1 : -1;
-        ge2 = 1;
-      } else if (yy > tg67x) {   // sector 2: compare up / down
-        q1 = r > 0 ? p - w : -1;
-        q2 = r < h - 1 ? p + w : -1;
-        ge2 = 1;
-      } else {                   // diagonal sectors
-        const int s = ((dxv ^ dyv) < 0) ? -1 : 1;
-        const int c1 = c - s, c2 = c + s;
-        q1 = (r > 0 && c1 >= 0 && c1 < w) ? p - w - s : -1;
-        q2 = (r < h - 1 && c2 >= 0 && c2 < w) ? p + w + s : -1;
-        ge2 = 0;
+  // ---- A. ROI -> LDS tile in walk space (aligned 32-bit global words), replicate 3 lanes ----
+  {
+    const int wpr = ((bp.x + w - 1) >> 2) - (bp.x >> 2) + 1;  // global words per image row
+    const uint8_t *plane = planes + (size_t)frame * frame_stride;
+    for (int i = tid; i < wpr * h; i += NT) {
+      const int r = i / wpr, j = i - r * wpr;
+      const uint8_t *g = plane + (size_t)(bp.y + r) * row_stride + ((bp.x >> 2) + j) * 4;
+      uint32_t v;
+      if ((((uintptr_t)g) & 3) == 0) {
+        v = *(const uint32_t *)g;
+      } else {  // plane base / row stride not 4-byte aligned: assemble from bytes
+        v = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
       }
-      int m1 = 0, m2 = 0;
-      if (q1 >= 0) { int u = bufB[q1]; int a = lo16(u), b = hi16(u); m1 = (a < 0 ? -a : a) + (b < 0 ? -b : b); }
-      if (q2 >= 0) { int u = bufB[q2]; int a = lo16(u), b = hi16(u); m2 = (a < 0 ? -a : a) + (b < 0 ? -b : b); }
-      const bool is_max = (m > m1) && (ge2 ? (m >= m2) : (m > m2));
-      if (is_max) flags = MAP_CAND | (m > high ? MAP_STRONG : 0);
-    }
-    // hough.cpp:133-150
-    bool use;
-    if (dxv != 0) {
-      const float slope = (float)dyv / (float)dxv;
-      use = bp.vertical ? (slope >= bp.slope_a && slope <= bp.slope_b)
-                        : (slope >= bp.slope_a || slope <= bp.slope_b);
-    } else {
-      use = !bp.vertical;
-    }
-    if (use) flags |= MAP_GATE;
-    map[p] = (unsigned char)flags;
-    lab[p] = p;
-  }
-  __syncthreads();
-
-  // ---- E. hysteresis: 8-connected components of candidates (union-find) ----
-  for (int p = tid; p < N; p += NT) {
-    if (!(map[p] & MAP_CAND)) continue;
-    int r = __umulhi((uint32_t)p, inv_w);
-    int c = p - r * w;
-    if (c >= w) { c -= w; r++; }
-    if (c > 0 && (map[p - 1] & MAP_CAND)) uf_unite(lab, p, p - 1);
-    if (r > 0) {
-      if (map[p - w] & MAP_CAND) uf_unite(lab, p, p - w);
-      if (c > 0 && (map[p - w - 1] & MAP_CAND)) uf_unite(lab, p, p - w - 1);
-      if (c < w - 1 && (map[p - w + 1] & MAP_CAND)) uf_unite(lab, p, p - w + 1);
-    }
-  }
-  __syncthreads();
-  for (int p = tid; p < N; p += NT) {
-    if ((map[p] & (MAP_CAND | MAP_STRONG)) == (MAP_CAND | MAP_STRONG)) {
-      int root = uf_rep(lab, p);
-      // byte-wise OR through the containing 32-bit word
-      atomicOr((unsigned int *)(map + (root & ~3)), (unsigned int)MAP_ROOT_STRONG << ((root & 3) * 8));
-    }
-  }
-  // ---- F. Hough accumulator (hough.cpp:127-161) ----
-  int *accum = bufB;  // (dx, dy) no longer needed: the gate bit is in the map
-  const int numrho = bp.numrho;
-  __syncthreads();
-  for (int i = tid; i < kNumAngle * numrho; i += NT) accum[i] = 0;
-  __syncthreads();
-  const int half = (numrho - 1) / 2;
-  for (int p = tid; p < N; p += NT) {
-    const int f = map[p];
-    if ((f & (MAP_CAND | MAP_GATE)) != (MAP_CAND | MAP_GATE)) continue;
-    const int root = uf_rep(lab, p);
-    if (!(((volatile unsigned char *)map)[root] & MAP_ROOT_STRONG)) continue;
-    int r = __umulhi((uint32_t)p, inv_w);
-    int c = p - r * w;
-    if (c >= w) { c -= w; r++; }
+      if (!VERT) {
+        *(uint32_t *)(tile + r * sp + 4 + j * 4) = v;  // off = 4 + (x & 3) keeps the alignment
+      } else {
+        // transpose: image (row r, col x) -> tile (step = x - box.x, lane = r)
+        const int c0 = j * 4 - (bp.x & 3);
 #pragma unroll
-    for (int n = 0; n < kNumAngle; n++) {
-      int rr = ((c * bp.tab_cos[n] + r * bp.tab_sin[n]) >> 10) + half;
-      atomicAdd(&accum[n * numrho + rr], 1);
+        for (int k = 0; k < 4; k++) {
+          const int cc = c0 + k;
+          if (cc >= 0 && cc < w) tile[cc * sp + off + r] = (unsigned char)(v >> (8 * k));
+        }
+      }
+    }
+    if (tid < 4) s_int[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < S * 6; i += NT) {
+      const int a = i / 6, k = i - a * 6;
+      unsigned char *row = tile + a * sp;
+      if (k < 3) row[off - 1 - k] = row[off];
+      else row[off + L + (k - 3)] = row[off + L - 1];
+    }
+    __syncthreads();
+  }
+  DMZ_STOP_AFTER(1, tile[off] + tile[(S - 1) * sp + off + L - 1])
+
+  WalkCtx c;
+  c.sp = sp; c.L = L; c.S = S;
+  c.l = 62 * wave - 1 + lane;
+  {
+    const int b = off + clampi(c.l, 0, L - 1) - 3;  // tile byte column of tap 0
+    c.row0 = tile + (b & ~3);
+    c.sh = b & 3;
+  }
+  const bool inbox = c.l >= 0 && c.l < L;
+  const bool owner = inbox && lane >= 1 && lane <= 62;  // produces output for its coordinate
+
+  // ---- B. pass 1: sum of saturated |dx| + |dy| (cvAbs: 32768 -> 32767) -> thresholds ----
+  {
+    long long local_sum = 0;
+    if (owner) {
+      Window wn;
+      window_init(c, wn);
+      int acc = 0;
+#define DMZ_P1_STEP(K)                                              \
+  if (s0 + K < S) {                                                  \
+    int dx, dy;                                                      \
+    window_step<VERT, K>(c, wn, s0 + K, dx, dy);                     \
+    const int ax = iabs(dx), ay = iabs(dy);                          \
+    acc += (ax > 32767 ? 32767 : ax) + (ay > 32767 ? 32767 : ay);    \
+  }
+      for (int s0 = 0; s0 < S; s0 += 7) {
+        DMZ_P1_STEP(0) DMZ_P1_STEP(1) DMZ_P1_STEP(2) DMZ_P1_STEP(3)
+        DMZ_P1_STEP(4) DMZ_P1_STEP(5) DMZ_P1_STEP(6)
+      }
+#undef DMZ_P1_STEP
+      local_sum = acc;  // steps * 65534 fits an int for any box that fits LDS
+    }
+    for (int o = 32; o > 0; o >>= 1) local_sum += __shfl_down(local_sum, o, 64);
+    if (lane == 0) s_red[wave] = local_sum;
+    __syncthreads();
+    if (tid == 0) {
+      long long tot = 0;
+      for (int i = 0; i < NT / 64; i++) tot += s_red[i];
+      // canny.cpp:573-578: mean in double; low = cvFloor(mean), high = cvFloor(3.0f * mean)
+      const double mean = (double)tot / (double)N;
+      const double lowt = mean, hight = 3.0f * mean;
+      s_int[0] = (int)floor(lowt);
+      s_int[1] = (int)floor(hight);
+    }
+    __syncthreads();
+  }
+  const int low = s_int[0], high = s_int[1];
+  DMZ_STOP_AFTER(2, low + high)
+
+  // ---- C. pass 2: gradients again, NMS + slope gate -> edge map (walk space) ----
+  {
+    Window wn;
+    window_init(c, wn);
+    // magnitudes of (own, lane-1, lane+1) at steps s-1 (p), s (c), s+1 (n)
+    int mp = 0, mp_lo = 0, mp_hi = 0;
+    int mc = 0, mc_lo = 0, mc_hi = 0;
+    int dxc = 0, dyc = 0;
+#define DMZ_P2_STEP(K)                                                                   \
+  if (s0 + K <= S) {                                                                      \
+    const int sn = s0 + K;                                                                \
+    int dxn = 0, dyn = 0, mn = 0;                                                         \
+    if (sn < S) {                                                                         \
+      window_step<VERT, K>(c, wn, sn, dxn, dyn);                                          \
+      mn = inbox ? iabs(dxn) + iabs(dyn) : 0; /* outside the ROI the magnitude is 0 */   \
+    }                                                                                     \
+    const int mn_lo = __shfl_up(mn, 1, 64);   /* lane - 1 */                              \
+    const int mn_hi = __shfl_down(mn, 1, 64); /* lane + 1 */                              \
+    if (sn >= 1 && owner)                                                                 \
+      nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo,    \
+                      mc_hi, mn, mn_lo, mn_hi, map, list, s_int);                         \
+    mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;                                                \
+    mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;                                                \
+    dxc = dxn; dyc = dyn;                                                                 \
+  }
+    for (int s0 = 0; s0 <= S; s0 += 7) {
+      DMZ_P2_STEP(0) DMZ_P2_STEP(1) DMZ_P2_STEP(2) DMZ_P2_STEP(3)
+      DMZ_P2_STEP(4) DMZ_P2_STEP(5) DMZ_P2_STEP(6)
+    }
+#undef DMZ_P2_STEP
+    __syncthreads();
+  }
+  DMZ_STOP_AFTER(3, map[0] + map[N - 1] + s_int[2])
+
+  // ---- D. hysteresis: propagate MAP_EDGE over 8-connected candidates until stable ----
+  // (8-adjacency is the same in walk space: rows = steps, columns = lanes)
+  {
+    const bool overflow = s_int[3] != 0;
+    const int nitems = overflow ? N : (s_int[2] < bp.list_cap ? s_int[2] : bp.list_cap);
+    volatile unsigned char *vmap = map;
+    for (;;) {
+      int changed = 0;
+      for (int i = tid; i < nitems; i += NT) {
+        int q = overflow ? i : (int)list[i];
+        if ((vmap[q] & (MAP_CAND | MAP_EDGE)) != MAP_CAND) continue;
+        int a = __umulhi((uint32_t)q, inv_L);
+        int l = q - a * L;
+        if (l >= L) { l -= L; a++; }
+        // is one of the 8 neighbours an edge?
+        bool hit = false;
+        for (int da = -1; da <= 1 && !hit; da++) {
+          const int aa = a + da;
+          if (aa < 0 || aa >= S) continue;
+          for (int dl = -1; dl <= 1; dl++) {
+            const int ll = l + dl;
+            if (ll < 0 || ll >= L || (da == 0 && dl == 0)) continue;
+            if (vmap[aa * L + ll] & MAP_EDGE) { hit = true; break; }
+          }
+        }
+        if (!hit) continue;
+        changed = 1;
+        // mark, then chase the chain of still-unmarked candidates from here
+        for (;;) {
+          vmap[q] = (unsigned char)(vmap[q] | MAP_EDGE);
+          int next = -1, na = 0, nl = 0;
+          for (int da = -1; da <= 1 && next < 0; da++) {
+            const int aa = a + da;
+            if (aa < 0 || aa >= S) continue;
+            for (int dl = -1; dl <= 1; dl++) {
+              const int ll = l + dl;
+              if (ll < 0 || ll >= L || (da == 0 && dl == 0)) continue;
+              if ((vmap[aa * L + ll] & (MAP_CAND | MAP_EDGE)) == MAP_CAND) {
+                next = aa * L + ll; na = aa; nl = ll;
+                break;
+              }
+            }
+          }
+          if (next < 0) break;
+          q = next; a = na; l = nl;
+        }
+      }
+      if (!__syncthreads_or(changed)) break;
+    }
+  }
+  DMZ_STOP_AFTER(4, map[0] + map[N - 1])
+
+  // ---- E. Hough accumulator (hough.cpp:127-161), u16 counters packed in 32-bit words ----
+  const int numrho = bp.numrho;
+  const int ncell = kNumAngle * numrho;
+  for (int i = tid; i < (ncell + 1) / 2; i += NT) acc32[i] = 0;
+  __syncthreads();
+  {
+    const int half = (numrho - 1) / 2;
+    for (int q = tid; q < N; q += NT) {
+      const int f = map[q];
+      if ((f & (MAP_EDGE | MAP_GATE)) != (MAP_EDGE | MAP_GATE)) continue;
+      int a = __umulhi((uint32_t)q, inv_L);
+      int l = q - a * L;
+      if (l >= L) { l -= L; a++; }
+      const int r = VERT ? l : a, col = VERT ? a : l;  // image coordinates inside the ROI
+#pragma unroll
+      for (int n = 0; n < kNumAngle; n++) {
+        const int rr = ((col * bp.tab_cos[n] + r * bp.tab_sin[n]) >> 10) + half;
+        const int cell = n * numrho + rr;
+        atomicAdd(&acc32[cell >> 1], 1u << ((cell & 1) * 16));  // counts < 65536: no carry
+      }
     }
   }
   __syncthreads();
+  DMZ_STOP_AFTER(5, acc32[0] + acc32[numrho])
 
-  // ---- G. arg-max with the reference's scan order (hough.cpp:163-176) ----
+  // ---- F. arg-max with the reference's scan order (hough.cpp:163-176) ----
   unsigned long long best = 0;
-  for (int i = tid; i < kNumAngle * numrho; i += NT) {
+  for (int i = tid; i < ncell; i += NT) {
     const int n = i / numrho, rr = i - n * numrho;
-    const unsigned int val = (unsigned int)accum[i];
+    const unsigned int val = (acc32[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
     const unsigned int order = (unsigned int)(rr * kNumAngle + n);  // scan position
     const unsigned long long key = ((unsigned long long)val << 32) | (0xffffffffu - order);
     best = key > best ? key : best;
   }
   for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long other = __shfl_down(best, o, 64);
+    const unsigned long long other = __shfl_down(best, o, 64);
     best = other > best ? other : best;
   }
   if (lane == 0) s_best[wave] = best;
@@ -294,16 +407,54 @@ __global__ __launch_bounds__(NT) void k_detect_box(const uint8_t *__restrict__ p
   }
 }
 
+// VERT = false: boxes 0 and 2 (top, bottom: horizontal lines, lanes = columns);
+// VERT = true:  boxes 1 and 3 (left, right: vertical lines, lanes = rows).
+template <bool VERT, int NT>
+__global__ __launch_bounds__(NT) void k_detect_walk(const uint8_t *__restrict__ planes,
+                                                     size_t frame_stride, int row_stride,
+                                                     DmzDetectParams params,
+                                                     DmzBoxHit *__restrict__ hits,
+                                                     const int *__restrict__ skip_mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int frame = blockIdx.x >> 1;  // 1-D grid: gridDim.y is limited to 65535
+  const int box_id = (blockIdx.x & 1) * 2 + (VERT ? 1 : 0);
+  if (skip_mask && skip_mask[frame * 4 + box_id]) return;
+  detect_body<VERT, NT>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
+}
+
+template <bool VERT, int NT>
+int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
+                const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask, int lds_bytes) {
+  static int configured_lds = 0;  // per instantiation
+  if (lds_bytes > configured_lds) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    configured_lds = lds_bytes;
+  }
+  hipLaunchKernelGGL((k_detect_walk<VERT, NT>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
+                     frame_stride, row_stride, p, hits, skip_mask);
+  return 0;
+}
+
+template <bool VERT>
+int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
+                   const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask) {
+  const DmzBoxParams &a = p.box[VERT ? 1 : 0], &b = p.box[VERT ? 3 : 2];
+  const int nt = a.nthreads > b.nthreads ? a.nthreads : b.nthreads;
+  const int lds = a.lds_total > b.lds_total ? a.lds_total : b.lds_total;
+  if (nt <= 256) return launch_pair<VERT, 256>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  if (nt <= 448) return launch_pair<VERT, 448>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  return launch_pair<VERT, 1024>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+}
+
 }  // namespace
 
-void dmz_launch_detect(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
-                       int n, const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask) {
-  dim3 grid(4u * (unsigned)n);
-  hipLaunchKernelGGL(k_detect_box, grid, dim3(NT), kDetectLdsBytes + 512, s, planes, frame_stride,
-                     row_stride, p, hits, skip_mask);
+int dmz_launch_detect(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
+                      int n, const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask) {
+  int e = launch_pair_nt<false>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask);
+  if (e) return e;
+  return launch_pair_nt<true>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask);
 }
 
-int dmz_configure_detect(void) {
-  return (int)hipFuncSetAttribute((const void *)k_detect_box,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kDetectLdsBytes + 512);
-}
+int dmz_configure_detect(void) { return 0; }  // LDS limits are raised per launch geometry

@@ -51,8 +51,14 @@ struct DmzBoxParams {
   float cos_t[kNumAngle];        // cosf(theta_n), geometry.cpp:22
   float sin_t[kNumAngle];        // sinf(theta_n)
   float rho_multiplier;          // dmz.cpp:383
-  uint32_t inv_w;                // ceil(2^32 / w): flat index -> (row, col)
-  int pad_;
+  uint32_t inv_w;                // ceil(2^32 / lanes): flat walk-space index -> (step, lane)
+  // LDS layout of k_detect_walk for this box (bytes from the dynamic LDS base)
+  int lanes, steps;              // across / along extents: (w, h) for horizontal-line boxes, (h, w) otherwise
+  int tile_off, tile_stride;     // LDS column of ROI pixel 0, row stride of the source tile
+  int lds_map, lds_acc, lds_red; // offsets of the edge map, the accumulator/candidate list, the scratch
+  int lds_total;
+  int list_cap;                  // candidate list capacity (u16 entries)
+  int nthreads;                  // 64 * ceil(lanes / 62)
 };
 
 struct DmzDetectParams {
@@ -74,16 +80,14 @@ struct DmzWarpMat {
   int pad_;
 };
 
-// LDS capacity of the detect kernel (one (frame, box) per workgroup).
-constexpr int kDetectMaxPixels = 11264;
-constexpr int kDetectSrcBytes = 13824;
-constexpr int kDetectThreads = 1024;
-constexpr int kDetectLdsBytes = kDetectSrcBytes + 2 * kDetectMaxPixels * 4;
+// Limits of the detect kernel (one (frame, box) per workgroup, box resident in LDS).
+constexpr int kDetectMaxLds = 160 * 1024;
+constexpr int kDetectMaxThreads = 1024;
 
 // ---- launchers (defined in the .hip files) --------------------------------
-void dmz_launch_detect(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
-                       int n, const DmzDetectParams &p, DmzBoxHit *hits /* n x 4 */,
-                       const int *skip_mask /* n x 4 or null: nonzero = already found */);
+int dmz_launch_detect(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
+                      int n, const DmzDetectParams &p, DmzBoxHit *hits /* n x 4 */,
+                      const int *skip_mask /* n x 4 or null: nonzero = already found */);
 void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params_by_plane /* 3, device */,
                          const DmzBoxHit *hits /* 3 planes x n x 4 */, int nplanes,
                          dmz_hip_frame_result *results);

@@ -175,5 +175,26 @@ def test_bad_arguments_are_errors_not_crashes(ctx, pkg):
     res = np.zeros(1, pkg.RESULT_DTYPE)
     with pytest.raises(pkg.DmzHipError):
         ctx.pipeline(np.zeros((1, 480, 640), np.uint8), 0, res)
-    with pytest.raises(pkg.DmzHipError):  # 1280x720: boxes exceed the LDS-resident detect kernel
-        ctx.detect(np.zeros((1, 720, 1280), np.uint8), 1, res, width=1280, height=720)
+    with pytest.raises(pkg.DmzHipError):  # 4000x3000: boxes exceed the LDS-resident detect kernel
+        ctx.detect(np.zeros((1, 3000, 4000), np.uint8), 1, res, width=4000, height=3000)
+
+
+def test_detect_other_frame_geometries(ctx, pkg, oracle):
+    """dmz.cpp:279-341 works on the central 4:3 region of any frame size; 1280x720 gives
+    583x43 / 58x361 boxes (bigger workgroups, different LDS layout), portrait swaps insets."""
+    y, _ = oracle.synth_frame(SEED, 50)
+    big = np.full((720, 1280), 60, np.uint8)
+    big[:, 160:1120] = np.repeat(np.repeat(y, 3, axis=0), 3, axis=1)[::2, ::2][:720, :960]
+    small = np.ascontiguousarray(y[::2, ::2])  # 320x240 (the chroma-plane geometry)
+    portrait = np.ascontiguousarray(y.T)       # 480x640, orientation 1
+    for frame, orientation in ((big, 3), (small, 3), (portrait, 1), (y, 4)):
+        h, w = frame.shape
+        res = np.zeros(1, pkg.RESULT_DTYPE)
+        ctx.detect(frame[None], 1, res, width=w, height=h, orientation=orientation)
+        want = oracle.detect_edges(frame, orientation=orientation)
+        assert np.array_equal(res[0]["found"], want["found"]), (w, h, orientation)
+        m = want["found"] != 0
+        assert np.array_equal(res[0]["rho"][m].view(np.uint32), want["rho"][m].view(np.uint32)), (w, h)
+        assert np.array_equal(res[0]["theta"][m].view(np.uint32), want["theta"][m].view(np.uint32))
+        assert np.array_equal(res[0]["corners"].view(np.uint32), want["corners"].view(np.uint32))
+        assert res[0]["found_all"] == want["found_all"]
