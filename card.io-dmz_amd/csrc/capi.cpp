@@ -28,7 +28,6 @@ struct dmz_hip_context {
   std::string err;
 
   float *d_weights = nullptr;  // blob
-  float *d_w1t = nullptr;      // vseg hidden W transposed [204][64]
   float *d_hidwt = nullptr;    // digit hidden W transposed 3 x [320][32]
 
   // detection tables for the current (width, height, orientation)
@@ -351,7 +350,7 @@ int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int
              dmz_hip_frame_result *results) {
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_VSEG);
-    dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_w1t, cards, card_stride, n, only_warped, results);
+    dmz_launch_vseg(ctx->stream, ctx->d_weights, cards, card_stride, n, only_warped, results);
   }
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_HSEG);
@@ -408,18 +407,14 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     return DMZ_HIP_ENODEVICE;
   }
   const float *w = (const float *)(dmz_weights_blob + 16);
-  std::vector<float> w1t(204 * 64, 0.0f), hidwt(3 * 320 * 32);
-  for (int j = 0; j < 50; j++)
-    for (int k = 0; k < 204; k++) w1t[k * 64 + j] = w[dmzw::VSEG_W1 + j * 204 + k];
+  std::vector<float> hidwt(3 * 320 * 32);
   for (int m = 0; m < 3; m++)
     for (int j = 0; j < 32; j++)
       for (int i = 0; i < 320; i++)
         hidwt[(size_t)m * 320 * 32 + i * 32 + j] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
   bool ok = hipMalloc((void **)&ctx->d_weights, sizeof(float) * dmzw::TOTAL) == hipSuccess &&
-            hipMalloc((void **)&ctx->d_w1t, sizeof(float) * w1t.size()) == hipSuccess &&
             hipMalloc((void **)&ctx->d_hidwt, sizeof(float) * hidwt.size()) == hipSuccess &&
             hipMemcpy(ctx->d_weights, w, sizeof(float) * dmzw::TOTAL, hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(ctx->d_w1t, w1t.data(), sizeof(float) * w1t.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(ctx->d_hidwt, hidwt.data(), sizeof(float) * hidwt.size(), hipMemcpyHostToDevice) == hipSuccess &&
             dmz_configure_detect() == 0 && dmz_configure_scan() == 0;
   if (!ok) {
@@ -443,7 +438,6 @@ void dmz_hip_context_destroy(dmz_hip_context *ctx) {
     if (b->p) (void)hipFree(b->p);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   if (ctx->d_weights) (void)hipFree(ctx->d_weights);
-  if (ctx->d_w1t) (void)hipFree(ctx->d_w1t);
   if (ctx->d_hidwt) (void)hipFree(ctx->d_hidwt);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -662,7 +656,7 @@ static int run_model(dmz_hip_context *ctx, int which, int model, const float *x,
     dout = (float *)ctx->misc.p;
   }
   if (which == 0)
-    dmz_launch_vseg_model(ctx->stream, ctx->d_weights, ctx->d_w1t, (const float *)dx, n, dout);
+    dmz_launch_vseg_model(ctx->stream, ctx->d_weights, (const float *)dx, n, dout);
   else
     dmz_launch_digit_model(ctx->stream, ctx->d_weights, ctx->d_hidwt, model, (const float *)dx, n, dout);
   HIP_TRY(ctx, hipGetLastError());

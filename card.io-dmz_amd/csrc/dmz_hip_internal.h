@@ -98,16 +98,14 @@ void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMa
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, const DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride);
-void dmz_launch_vseg(hipStream_t s, const float *weights, const float *w1t /* [204][64] */,
-                     const uint8_t *cards, size_t card_stride, int n, int only_warped,
-                     dmz_hip_frame_result *results);
+void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
+                     int n, int only_warped, dmz_hip_frame_result *results);
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results);
 void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidwt /* 3 x [320][32] */,
                        const uint8_t *cards, size_t card_stride, int n,
                        dmz_hip_frame_result *results);
-void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *w1t, const float *x,
-                           int n, float *out);
+void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *x, int n, float *out);
 void dmz_launch_digit_model(hipStream_t s, const float *weights, const float *hidwt, int model,
                             const float *x, int n, float *out);
 size_t dmz_synth_params_bytes(int n);
@@ -116,3 +114,4 @@ void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *
 void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards);
 int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
 int dmz_configure_scan(void);
+int dmz_configure_vseg(void);

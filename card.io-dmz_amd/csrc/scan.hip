@@ -1,13 +1,7 @@
-// scan.hip -- the card-number half of the hot path on a batch of rectified
-// 428 x 270 cards: number-row search, digit segmentation, digit categorisation.
+// scan.hip -- digit segmentation and digit categorisation on a batch of rectified
+// 428 x 270 cards whose number row was found by k_vseg (vseg.hip).
 //
 // Replaces, for a whole batch, scan_card_image's number path (scan/frame.cpp:24-81):
-//   k_vseg   = best_n_vseg (scan/n_vseg.cpp:94-168): per row ROI (10,y,408,1):
-//              3-tap morphological gradient (cv/morph.cpp:108-112), x0.5 linear
-//              down-sample (cv/convert.cpp:195-197), min-max normalise
-//              (cv/convert.cpp:380-383), MLP 204-50-3 (modelm_befe75da.cpp:1770-1786),
-//              27-row running box sum (n_vseg.cpp:49-92), coarse then fine pass;
-//              then the frame gates frame.cpp:38-47.
 //   k_hseg   = best_n_hseg (scan/n_hseg.cpp:88-151): 5-tap cross gradient of the
 //              428x27 strip (cv/morph.cpp:190-220), column sums, min-max, 4-pass L1
 //              template search with the reference's float loop increments.
@@ -46,238 +40,6 @@ __constant__ float c_grad_sum_pattern[19] = {
     0.45258447f, 0.43045216f, 0.42430462f, 0.44796554f, 0.47726529f, 0.48471646f, 0.46457738f,
     0.42799847f, 0.38851183f, 0.33966308f, 0.28802608f, 0.25377602f,
 };
-
-// ===========================================================================
-// vseg
-// ===========================================================================
-constexpr int VS_THREADS = 256;
-constexpr int VS_WAVES = VS_THREADS / 64;
-constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
-constexpr int VS_FSTRIDE = 208;  // feature row stride in floats (16-byte aligned rows)
-
-// One wave turns one card row into the 204 normalised features (n_vseg.cpp:39-43).
-__device__ void vseg_row_features(const uint8_t *__restrict__ row /* card row + 10 */,
-                                  float *__restrict__ feat, int lane) {
-  int d[4];
-  int vmin = 255, vmax = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int o = lane + 64 * k;  // down-sampled index
-    d[k] = 0;
-    if (o < 204) {
-      const int i0 = 2 * o;
-      const int a = row[i0 > 0 ? i0 - 1 : 0], b = row[i0], c = row[i0 + 1],
-                e = row[i0 + 2 < 408 ? i0 + 2 : 407];
-      const int g0 = imax(a, imax(b, c)) - imin(a, imin(b, c));  // grad[2o]
-      const int g1 = imax(b, imax(c, e)) - imin(b, imin(c, e));  // grad[2o+1]
-      d[k] = (g0 + g1 + 1) >> 1;
-      vmin = imin(vmin, d[k]);
-      vmax = imax(vmax, d[k]);
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    vmin = imin(vmin, __shfl_xor(vmin, o, 64));
-    vmax = imax(vmax, __shfl_xor(vmax, o, 64));
-  }
-  // cvConvertScale(1/255) then cvNormalize(0,1,MINMAX): SURVEY A7/A8
-  const float s255 = 1.0f / 255.0f;
-  const double smin = (double)((float)vmin * s255), smax = (double)((float)vmax * s255);
-  const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.;
-  const double shift = 0.0 - smin * scale;
-  const float fs = (float)scale, fb = (float)shift;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int o = lane + 64 * k;
-    if (o < 204) {
-      const float f = (float)d[k] * s255;
-      feat[o] = f * fs + fb;
-    }
-  }
-}
-
-// MLP 204-50-3 on `nrows` feature rows held in LDS; lane j < 50 owns hidden unit j.
-// w1t is the hidden weight matrix transposed to [204][64] (coalesced across lanes).
-__device__ void vseg_mlp_rows(const float *__restrict__ w1t, const float *__restrict__ wts,
-                              const float *__restrict__ feat, const int *__restrict__ row_y,
-                              int nrows, float *__restrict__ vis, float *__restrict__ amx, int wave,
-                              int lane) {
-  constexpr int RMAX = (VS_MAXROWS + VS_WAVES - 1) / VS_WAVES;  // 17 rows per wave
-  float acc[RMAX];
-#pragma unroll
-  for (int r = 0; r < RMAX; r++) acc[r] = 0.0f;
-  const int my_rows = (nrows - wave + VS_WAVES - 1) / VS_WAVES;  // rows wave, wave+4, ...
-  if (my_rows <= 0) return;
-  for (int k = 0; k < 204; k += 4) {
-    const float wa = w1t[(k + 0) * 64 + lane], wb = w1t[(k + 1) * 64 + lane],
-                wc = w1t[(k + 2) * 64 + lane], wd = w1t[(k + 3) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-      if (r < my_rows) {
-        const float4 x = *(const float4 *)(feat + (wave + r * VS_WAVES) * VS_FSTRIDE + k);
-        acc[r] = fmaf(wa, x.x, acc[r]);
-        acc[r] = fmaf(wb, x.y, acc[r]);
-        acc[r] = fmaf(wc, x.z, acc[r]);
-        acc[r] = fmaf(wd, x.w, acc[r]);
-      }
-    }
-  }
-  const float b1 = lane < 50 ? wts[dmzw::VSEG_B1 + lane] : 0.0f;
-  const float w20 = lane < 50 ? wts[dmzw::VSEG_W2 + 0 * 50 + lane] : 0.0f;
-  const float w21 = lane < 50 ? wts[dmzw::VSEG_W2 + 1 * 50 + lane] : 0.0f;
-  const float w22 = lane < 50 ? wts[dmzw::VSEG_W2 + 2 * 50 + lane] : 0.0f;
-  const float b20 = wts[dmzw::VSEG_B2 + 0], b21 = wts[dmzw::VSEG_B2 + 1], b22 = wts[dmzw::VSEG_B2 + 2];
-#pragma unroll
-  for (int r = 0; r < RMAX; r++) {
-    if (r < my_rows) {
-      const float hv = lane < 50 ? tanhf(acc[r] + b1) : 0.0f;
-      float o0 = w20 * hv, o1 = w21 * hv, o2 = w22 * hv;
-      for (int o = 32; o > 0; o >>= 1) {
-        o0 += __shfl_xor(o0, o, 64);
-        o1 += __shfl_xor(o1, o, 64);
-        o2 += __shfl_xor(o2, o, 64);
-      }
-      if (lane == 0) {
-        const float e0 = expf(o0 + b20), e1 = expf(o1 + b21), e2 = expf(o2 + b22);
-        const float sum = e0 + (e1 + e2);  // Eigen 3-element redux tree
-        const int y = row_y[wave + r * VS_WAVES];
-        vis[y] = e1 / sum;
-        amx[y] = e2 / sum;
-      }
-    }
-  }
-}
-
-// n_vseg.cpp:49-92, literally (one thread).
-__device__ void vseg_best_segmentation(const float *vis, const float *amx, float *ring /* 54 */,
-                                       float *score, int *y_off, int *pattern) {
-  float vsum = 0.0f, asum = 0.0f;
-  float best = 0.0f;
-  int bp = 0, by = 0;
-  for (int y = 0; y < 270; y++) {
-    const float v = vis[y], a = amx[y];
-    vsum = vsum + v;
-    asum = asum + a;
-    const int bi = y % 27;
-    ring[bi] = v;
-    ring[27 + bi] = a;
-    if (y >= 26) {
-      if (vsum > best) { best = vsum; bp = 1; by = y - 27 + 1; }
-      if (asum > best) { best = asum; bp = 2; by = y - 27 + 1; }
-      const int nbi = (y + 1) % 27;
-      vsum = vsum - ring[nbi];
-      asum = asum - ring[27 + nbi];
-    }
-  }
-  *score = best;
-  *y_off = by;
-  *pattern = bp;
-}
-
-__global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ wts,
-                                                      const float *__restrict__ w1t,
-                                                      const uint8_t *__restrict__ cards,
-                                                      size_t card_stride, int n, int only_warped,
-                                                      dmz_hip_frame_result *__restrict__ results) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  float *feat = (float *)lds;                         // VS_MAXROWS x VS_FSTRIDE
-  float *vis = feat + VS_MAXROWS * VS_FSTRIDE;        // 272
-  float *amx = vis + 272;                             // 272
-  float *ring = amx + 272;                            // 54 (+2)
-  int *row_y = (int *)(ring + 56);                    // VS_MAXROWS
-  int *s_int = row_y + VS_MAXROWS;                    // nrows, y_off, pattern, (score bits)
-
-  const int f = blockIdx.x;
-  if (f >= n) return;
-  dmz_hip_frame_result *res = results + f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int in_flags = res->flags;
-  if (only_warped && !(in_flags & DMZ_HIP_FLAG_WARPED)) {
-    if (tid == 0) {
-      res->vseg_score = 0.0f;
-      res->vseg_y_offset = 0;
-      res->pattern_type = 0;
-    }
-    return;
-  }
-  const uint8_t *card = cards + (size_t)f * card_stride;
-
-  for (int i = tid; i < 272; i += VS_THREADS) { vis[i] = 0.0f; amx[i] = 0.0f; }
-  // coarse pass: rows 0, 4, ..., 268 (n_vseg.cpp:116-125)
-  for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = 4 * i;
-  for (int i = wave; i < VS_MAXROWS; i += VS_WAVES)
-    vseg_row_features(card + (size_t)(4 * i) * DMZ_CARD_WIDTH + 10, feat + i * VS_FSTRIDE, lane);
-  __syncthreads();
-  vseg_mlp_rows(w1t, wts, feat, row_y, VS_MAXROWS, vis, amx, wave, lane);
-  __syncthreads();
-  if (tid == 0) {
-    float score;
-    int y_off, pattern;
-    vseg_best_segmentation(vis, amx, ring, &score, &y_off, &pattern);
-    // fine pass rows (n_vseg.cpp:140-152)
-    int ymin = y_off < 8 ? 0 : y_off - 8;
-    ymin = imin(270, ymin);
-    const int ymax = imin(270, y_off + 27 + 8);
-    int cnt = 0;
-    for (int y = ymin; y < ymax; y++)
-      if (vis[y] == 0.0f && amx[y] == 0.0f) row_y[cnt++] = y;
-    s_int[0] = cnt;
-  }
-  __syncthreads();
-  const int nfine = s_int[0];
-  for (int i = wave; i < nfine; i += VS_WAVES)
-    vseg_row_features(card + (size_t)row_y[i] * DMZ_CARD_WIDTH + 10, feat + i * VS_FSTRIDE, lane);
-  __syncthreads();
-  vseg_mlp_rows(w1t, wts, feat, row_y, nfine, vis, amx, wave, lane);
-  __syncthreads();
-  if (tid == 0) {
-    float score;
-    int y_off, pattern;
-    vseg_best_segmentation(vis, amx, ring, &score, &y_off, &pattern);
-    int flags = in_flags & DMZ_HIP_FLAG_WARPED;
-    if (y_off < (DMZ_CARD_HEIGHT - 27) / 2) flags |= DMZ_HIP_FLAG_UPSIDE_DOWN;  // frame.cpp:38
-    else if (score > 15.0f) flags |= DMZ_HIP_FLAG_VSEG_OK;                       // frame.cpp:43
-    res->vseg_score = score;
-    res->vseg_y_offset = y_off;
-    res->pattern_type = pattern;
-    res->flags = flags;
-    // defaults of the later stages (frames that stop here)
-    res->n_offsets = 0;
-    res->hseg_score = 0.0f;
-    res->number_width = 0.0f;
-    res->pattern_offset = 0;
-    res->number_score = 0.0f;
-  }
-  // clear the per-digit outputs (NumberScores::Zero(), n_categorize.cpp:93)
-  for (int i = tid; i < 160; i += VS_THREADS) (&res->scores[0][0])[i] = 0.0f;
-  if (tid < 16) { res->digits[tid] = 0; res->offsets[tid] = 0; }
-}
-
-// Stand-alone model entry point (KAT): one wave per input vector.
-__global__ __launch_bounds__(64) void k_vseg_model(const float *__restrict__ wts,
-                                                    const float *__restrict__ w1t,
-                                                    const float *__restrict__ x, int n,
-                                                    float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float feat[VS_FSTRIDE];
-  const int i = blockIdx.x, lane = threadIdx.x;
-  if (i >= n) return;
-  for (int k = lane; k < 204; k += 64) feat[k] = x[(size_t)i * 204 + k];
-  __syncthreads();
-  float acc = 0.0f;
-  for (int k = 0; k < 204; k++) acc = fmaf(w1t[k * 64 + lane], feat[k], acc);
-  const float hv = lane < 50 ? tanhf(acc + wts[dmzw::VSEG_B1 + lane]) : 0.0f;
-  float o[3];
-  for (int c = 0; c < 3; c++) {
-    float v = lane < 50 ? wts[dmzw::VSEG_W2 + c * 50 + lane] * hv : 0.0f;
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-    o[c] = expf(v + wts[dmzw::VSEG_B2 + c]);
-  }
-  if (lane == 0) {
-    const float sum = o[0] + (o[1] + o[2]);
-    out[i * 3 + 0] = o[0] / sum;
-    out[i * 3 + 1] = o[1] / sum;
-    out[i * 3 + 2] = o[2] / sum;
-  }
-}
 
 // ===========================================================================
 // hseg
@@ -707,16 +469,9 @@ __global__ __launch_bounds__(64) void k_digit_model(const float *__restrict__ wt
   }
 }
 
-constexpr int kVsegLds = (VS_MAXROWS * VS_FSTRIDE + 272 * 2 + 56) * 4 + (VS_MAXROWS + 4) * 4;
 constexpr int kDigitsLds = (16 * DG_XSTRIDE + 16 * 320) * 4 + 16 * 528 + (16 * 32 + 480 + 4) * 4;
 
 }  // namespace
-
-void dmz_launch_vseg(hipStream_t s, const float *weights, const float *w1t, const uint8_t *cards,
-                     size_t card_stride, int n, int only_warped, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), kVsegLds, s, weights, w1t, cards,
-                     card_stride, n, only_warped, results);
-}
 
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results) {
@@ -729,19 +484,13 @@ void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidwt, 
                      card_stride, n, results);
 }
 
-void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *w1t, const float *x,
-                           int n, float *out) {
-  hipLaunchKernelGGL(k_vseg_model, dim3(n), dim3(64), 0, s, weights, w1t, x, n, out);
-}
-
 void dmz_launch_digit_model(hipStream_t s, const float *weights, const float *hidwt, int model,
                             const float *x, int n, float *out) {
   hipLaunchKernelGGL(k_digit_model, dim3(n), dim3(64), 0, s, weights, hidwt, model, x, n, out);
 }
 
 int dmz_configure_scan(void) {
-  int e = (int)hipFuncSetAttribute((const void *)k_vseg, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kVsegLds);
+  int e = dmz_configure_vseg();
   if (e) return e;
   return (int)hipFuncSetAttribute((const void *)k_digits,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kDigitsLds);

@@ -1,0 +1,353 @@
+// vseg.hip -- number-row search on a batch of rectified 428 x 270 cards.
+//
+// Replaces best_n_vseg (scan/n_vseg.cpp:94-168) and the frame gates that follow it
+// (scan/frame.cpp:38-47): per row ROI (10,y,408,1): 3-tap morphological gradient
+// (cv/morph.cpp:108-112), x0.5 linear down-sample (cv/convert.cpp:195-197), min-max
+// normalise (cv/convert.cpp:380-383), MLP 204-50-3 (modelm_befe75da.cpp:1770-1786),
+// 27-row running box sum (n_vseg.cpp:49-92) -- coarse pass on every 4th row, then the
+// fine pass around the best offset, exactly as the reference schedules them.
+//
+// CDNA4 mapping: one workgroup (4 waves) per card.
+//   * row features: a wave per row; lane t loads three aligned dwords (12 bytes) of the
+//     row and produces 4 of the 204 features in registers (v_max3/v_min3), a wave
+//     min/max reduction, one 16-byte LDS store per lane.
+//   * hidden layer = the one real contraction of the stage, [rows x 204] x [204 x 50]:
+//     v_mfma_f32_16x16x4_f32 (exact f32, the vector rate without the VALU's operand
+//     traffic).  Wave w owns hidden units 16w..16w+15: its B operands (13 float4 per
+//     lane, straight from the row-major weight matrix) stay in registers for the whole
+//     card; A operands are one ds_read_b128 per four MFMAs; two row tiles are
+//     accumulated at a time so the 40-cycle dependent latency is covered.
+//   * tanh, the 50->3 logistic layer (wave-local 16-lane reductions + a 4-wave LDS
+//     sum), softmax, and the literal running box sum on one lane.
+// Scores are float probabilities: contract |delta| <= 1e-4 (the reference's own KAT
+// tolerance is 1e-5); the arg-max over window sums is exact except for float near-ties.
+#include <float.h>
+
+#include "dmz_hip_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return imax(a, imax(b, c)); }
+__device__ __forceinline__ int min3i(int a, int b, int c) { return imin(a, imin(b, c)); }
+
+constexpr int VS_THREADS = 256;
+constexpr int VS_WAVES = 4;
+constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
+constexpr int VS_FSTRIDE = 208;  // feature row stride in floats (13 x 16 k-values)
+constexpr int VS_FROWS = VS_MAXROWS;      // every row carries its own zero k-tail 204..207
+constexpr int VS_KSTEPS = 13;    // 13 x 16 = 208 >= 204
+
+// One wave turns one card row into the 204 normalised features (n_vseg.cpp:39-43).
+// `row` = card row start (4-byte aligned); ROI columns 10..417.
+__device__ __forceinline__ void vseg_row_features(const uint8_t *__restrict__ row,
+                                                  float *__restrict__ feat, int lane) {
+  // lane t (< 51) owns down-sampled outputs 4t..4t+3, i.e. card columns 9+8t .. 20+8t
+  uint32_t w0 = 0, w1 = 0, w2 = 0;
+  if (lane < 51) {
+    const uint32_t *p = (const uint32_t *)(row + 8 + 8 * lane);
+    w0 = p[0]; w1 = p[1]; w2 = p[2];
+  }
+  int b[12];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    b[k] = (w0 >> (8 * k)) & 255;
+    b[4 + k] = (w1 >> (8 * k)) & 255;
+    b[8 + k] = (w2 >> (8 * k)) & 255;
+  }
+  // replicate at the ROI ends: column 9 -> column 10 (lane 0), column 418 -> 417 (lane 50)
+  if (lane == 0) b[1] = b[2];
+  if (lane == 50) b[10] = b[9];
+  int d[4];
+  int vmin = 255, vmax = 0;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int a = b[1 + 2 * m], bb = b[2 + 2 * m], c = b[3 + 2 * m], e = b[4 + 2 * m];
+    const int g0 = max3i(a, bb, c) - min3i(a, bb, c);  // grad[2o]
+    const int g1 = max3i(bb, c, e) - min3i(bb, c, e);  // grad[2o+1]
+    d[m] = (g0 + g1 + 1) >> 1;
+    if (lane < 51) {
+      vmin = imin(vmin, d[m]);
+      vmax = imax(vmax, d[m]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    vmin = imin(vmin, __shfl_xor(vmin, o, 64));
+    vmax = imax(vmax, __shfl_xor(vmax, o, 64));
+  }
+  // cvConvertScale(1/255) then cvNormalize(0,1,MINMAX): SURVEY A7/A8
+  const float s255 = 1.0f / 255.0f;
+  const double smin = (double)((float)vmin * s255), smax = (double)((float)vmax * s255);
+  const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.;
+  const double shift = 0.0 - smin * scale;
+  const float fs = (float)scale, fb = (float)shift;
+  if (lane < 52) {  // lane 51 writes the zero k-tail 204..207
+    f32x4 o;
+    o.x = lane < 51 ? ((float)d[0] * s255) * fs + fb : 0.0f;
+    o.y = lane < 51 ? ((float)d[1] * s255) * fs + fb : 0.0f;
+    o.z = lane < 51 ? ((float)d[2] * s255) * fs + fb : 0.0f;
+    o.w = lane < 51 ? ((float)d[3] * s255) * fs + fb : 0.0f;
+    *(f32x4 *)(feat + 4 * lane) = o;
+  }
+}
+
+// Hidden + logistic layers for `nrows` feature rows in LDS.  Wave `wave` owns hidden units
+// 16*wave .. 16*wave+15; bw[u] holds W1[j][16u + 4kk .. +3] for this lane's (kk, j).
+__device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], float b1, float w20,
+                                              float w21, float w22, const float *__restrict__ feat,
+                                              int nrows, float *__restrict__ part /* [4][80][4] */,
+                                              int wave, int lane) {
+  const int ii = lane & 15, kk = lane >> 4;
+  const int ntiles = (nrows + 15) >> 4;
+  for (int mt = 0; mt < ntiles; mt += 2) {
+    const int r0 = imin(mt * 16 + ii, nrows - 1), r1 = imin(mt * 16 + 16 + ii, nrows - 1);
+    const float *a0p = feat + r0 * VS_FSTRIDE + 4 * kk;
+    const float *a1p = feat + r1 * VS_FSTRIDE + 4 * kk;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < VS_KSTEPS; u++) {
+      const f32x4 a0 = *(const f32x4 *)(a0p + 16 * u);
+      const f32x4 a1 = *(const f32x4 *)(a1p + 16 * u);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bw[u].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bw[u].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bw[u].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bw[u].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bw[u].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bw[u].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bw[u].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bw[u].w, acc1, 0, 0, 0);
+    }
+    // D layout: column (hidden unit) = lane & 15, row = 4 * (lane >> 4) + v
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const f32x4 acc = t ? acc1 : acc0;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const float hv = tanhf(acc[v] + b1);  // units >= 50 have zero logistic weights
+        float o0 = w20 * hv, o1 = w21 * hv, o2 = w22 * hv;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {  // sum over the 16 hidden units of this wave
+          o0 += __shfl_xor(o0, o, 64);
+          o1 += __shfl_xor(o1, o, 64);
+          o2 += __shfl_xor(o2, o, 64);
+        }
+        const int row = (mt + t) * 16 + 4 * kk + v;
+        if (ii == 0 && row < nrows) {
+          float *p = part + (wave * 80 + row) * 4;
+          p[0] = o0; p[1] = o1; p[2] = o2;
+        }
+      }
+    }
+  }
+}
+
+// n_vseg.cpp:49-92, literally (one thread).
+__device__ void vseg_best_segmentation(const float *vis, const float *amx, float *ring /* 54 */,
+                                       float *score, int *y_off, int *pattern) {
+  float vsum = 0.0f, asum = 0.0f;
+  float best = 0.0f;
+  int bp = 0, by = 0;
+  for (int y = 0; y < 270; y++) {
+    const float v = vis[y], a = amx[y];
+    vsum = vsum + v;
+    asum = asum + a;
+    const int bi = y % 27;
+    ring[bi] = v;
+    ring[27 + bi] = a;
+    if (y >= 26) {
+      if (vsum > best) { best = vsum; bp = 1; by = y - 27 + 1; }
+      if (asum > best) { best = asum; bp = 2; by = y - 27 + 1; }
+      const int nbi = (y + 1) % 27;
+      vsum = vsum - ring[nbi];
+      asum = asum - ring[27 + nbi];
+    }
+  }
+  *score = best;
+  *y_off = by;
+  *pattern = bp;
+}
+
+// logistic bias + softmax of the rows just evaluated (modelm_befe75da.cpp:1781-1784)
+__device__ __forceinline__ void vseg_finish_rows(const float *__restrict__ wts,
+                                                 const float *__restrict__ part,
+                                                 const int *__restrict__ row_y, int nrows,
+                                                 float *__restrict__ vis, float *__restrict__ amx,
+                                                 int tid) {
+  if (tid < nrows) {
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      o[c] = ((part[(0 * 80 + tid) * 4 + c] + part[(1 * 80 + tid) * 4 + c]) +
+              (part[(2 * 80 + tid) * 4 + c] + part[(3 * 80 + tid) * 4 + c])) + wts[dmzw::VSEG_B2 + c];
+    const float e0 = expf(o[0]), e1 = expf(o[1]), e2 = expf(o[2]);
+    const float sum = e0 + (e1 + e2);  // Eigen 3-element redux tree
+    const int y = row_y[tid];
+    vis[y] = e1 / sum;
+    amx[y] = e2 / sum;
+  }
+}
+
+__global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ wts,
+                                                      const uint8_t *__restrict__ cards,
+                                                      size_t card_stride, int n, int only_warped,
+                                                      dmz_hip_frame_result *__restrict__ results) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float *feat = (float *)lds;                         // VS_FROWS x VS_FSTRIDE
+  float *part = feat + VS_FROWS * VS_FSTRIDE;         // 4 x 80 x 4
+  float *vis = part + 4 * 80 * 4;                     // 272
+  float *amx = vis + 272;                             // 272
+  float *ring = amx + 272;                            // 54 (+2)
+  int *row_y = (int *)(ring + 56);                    // VS_MAXROWS
+  int *s_int = row_y + VS_MAXROWS;                    // 4
+
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  dmz_hip_frame_result *res = results + f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int in_flags = res->flags;
+  if (only_warped && !(in_flags & DMZ_HIP_FLAG_WARPED)) {
+    if (tid == 0) {
+      res->vseg_score = 0.0f;
+      res->vseg_y_offset = 0;
+      res->pattern_type = 0;
+    }
+    return;
+  }
+  const uint8_t *card = cards + (size_t)f * card_stride;
+
+  // this wave's slice of the weights: hidden units 16*wave + (lane & 15)
+  const int j = 16 * wave + (lane & 15), kk = lane >> 4;
+  const bool unit = j < 50;
+  f32x4 bw[VS_KSTEPS];
+#pragma unroll
+  for (int u = 0; u < VS_KSTEPS; u++) {
+    const int k0 = 16 * u + 4 * kk;
+    if (unit && k0 < 204) bw[u] = *(const f32x4 *)(wts + dmzw::VSEG_W1 + j * 204 + k0);
+    else bw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
+  const float w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
+  const float w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
+  const float w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
+
+  for (int i = tid; i < 272; i += VS_THREADS) { vis[i] = 0.0f; amx[i] = 0.0f; }
+  // coarse pass: rows 0, 4, ..., 268 (n_vseg.cpp:116-125)
+  for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = 4 * i;
+  for (int i = wave; i < VS_MAXROWS; i += VS_WAVES)
+    vseg_row_features(card + (size_t)(4 * i) * DMZ_CARD_WIDTH, feat + i * VS_FSTRIDE, lane);
+  __syncthreads();
+  vseg_mlp_rows(bw, b1, w20, w21, w22, feat, VS_MAXROWS, part, wave, lane);
+  __syncthreads();
+  vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
+  __syncthreads();
+  if (tid == 0) {
+    float score;
+    int y_off, pattern;
+    vseg_best_segmentation(vis, amx, ring, &score, &y_off, &pattern);
+    // fine pass rows (n_vseg.cpp:140-152)
+    int ymin = y_off < 8 ? 0 : y_off - 8;
+    ymin = imin(270, ymin);
+    const int ymax = imin(270, y_off + 27 + 8);
+    int cnt = 0;
+    for (int y = ymin; y < ymax; y++)
+      if (vis[y] == 0.0f && amx[y] == 0.0f) row_y[cnt++] = y;
+    s_int[0] = cnt;
+  }
+  __syncthreads();
+  const int nfine = s_int[0];
+  if (nfine > 0) {
+    for (int i = wave; i < nfine; i += VS_WAVES)
+      vseg_row_features(card + (size_t)row_y[i] * DMZ_CARD_WIDTH, feat + i * VS_FSTRIDE, lane);
+    __syncthreads();
+    vseg_mlp_rows(bw, b1, w20, w21, w22, feat, nfine, part, wave, lane);
+    __syncthreads();
+    vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float score;
+    int y_off, pattern;
+    vseg_best_segmentation(vis, amx, ring, &score, &y_off, &pattern);
+    int flags = in_flags & DMZ_HIP_FLAG_WARPED;
+    if (y_off < (DMZ_CARD_HEIGHT - 27) / 2) flags |= DMZ_HIP_FLAG_UPSIDE_DOWN;  // frame.cpp:38
+    else if (score > 15.0f) flags |= DMZ_HIP_FLAG_VSEG_OK;                       // frame.cpp:43
+    res->vseg_score = score;
+    res->vseg_y_offset = y_off;
+    res->pattern_type = pattern;
+    res->flags = flags;
+    // defaults of the later stages (frames that stop here)
+    res->n_offsets = 0;
+    res->hseg_score = 0.0f;
+    res->number_width = 0.0f;
+    res->pattern_offset = 0;
+    res->number_score = 0.0f;
+  }
+  // clear the per-digit outputs (NumberScores::Zero(), n_categorize.cpp:93)
+  for (int i = tid; i < 160; i += VS_THREADS) (&res->scores[0][0])[i] = 0.0f;
+  if (tid < 16) { res->digits[tid] = 0; res->offsets[tid] = 0; }
+}
+
+// Stand-alone model entry point (KAT): up to 16 input vectors per workgroup, same MFMA path.
+__global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restrict__ wts,
+                                                            const float *__restrict__ x, int n,
+                                                            float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float feat[16 * VS_FSTRIDE];
+  __shared__ float part[4 * 80 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = blockIdx.x * 16;
+  const int rows = imin(16, n - base);
+  if (rows <= 0) return;
+  const int j = 16 * wave + (lane & 15), kk = lane >> 4;
+  const bool unit = j < 50;
+  f32x4 bw[VS_KSTEPS];
+#pragma unroll
+  for (int u = 0; u < VS_KSTEPS; u++) {
+    const int k0 = 16 * u + 4 * kk;
+    if (unit && k0 < 204) bw[u] = *(const f32x4 *)(wts + dmzw::VSEG_W1 + j * 204 + k0);
+    else bw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
+  const float w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
+  const float w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
+  const float w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
+  for (int i = tid; i < 16 * VS_FSTRIDE; i += VS_THREADS) {
+    const int r = i / VS_FSTRIDE, k = i - r * VS_FSTRIDE;
+    feat[i] = (r < rows && k < 204) ? x[(size_t)(base + r) * 204 + k] : 0.0f;
+  }
+  __syncthreads();
+  vseg_mlp_rows(bw, b1, w20, w21, w22, feat, rows, part, wave, lane);
+  __syncthreads();
+  if (tid < rows) {
+    float o[3];
+    for (int c = 0; c < 3; c++)
+      o[c] = ((part[(0 * 80 + tid) * 4 + c] + part[(1 * 80 + tid) * 4 + c]) +
+              (part[(2 * 80 + tid) * 4 + c] + part[(3 * 80 + tid) * 4 + c])) + wts[dmzw::VSEG_B2 + c];
+    const float e0 = expf(o[0]), e1 = expf(o[1]), e2 = expf(o[2]);
+    const float sum = e0 + (e1 + e2);
+    out[(size_t)(base + tid) * 3 + 0] = e0 / sum;
+    out[(size_t)(base + tid) * 3 + 1] = e1 / sum;
+    out[(size_t)(base + tid) * 3 + 2] = e2 / sum;
+  }
+}
+
+constexpr int kVsegLds = (VS_FROWS * VS_FSTRIDE + 4 * 80 * 4 + 272 * 2 + 56) * 4 + (VS_MAXROWS + 4) * 4;
+
+}  // namespace
+
+void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
+                     int n, int only_warped, dmz_hip_frame_result *results) {
+  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), kVsegLds, s, weights, cards, card_stride, n,
+                     only_warped, results);
+}
+
+void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *x, int n, float *out) {
+  hipLaunchKernelGGL(k_vseg_model, dim3((n + 15) / 16), dim3(VS_THREADS), 0, s, weights, x, n, out);
+}
+
+int dmz_configure_vseg(void) {
+  return (int)hipFuncSetAttribute((const void *)k_vseg, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kVsegLds);
+}
