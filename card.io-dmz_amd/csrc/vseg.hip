@@ -7,18 +7,23 @@
 // 27-row running box sum (n_vseg.cpp:49-92) -- coarse pass on every 4th row, then the
 // fine pass around the best offset, exactly as the reference schedules them.
 //
-// CDNA4 mapping: one workgroup (4 waves) per card.
-//   * row features: a wave per row; lane t loads three aligned dwords (12 bytes) of the
-//     row and produces 4 of the 204 features in registers (v_max3/v_min3), a wave
-//     min/max reduction, one 16-byte LDS store per lane.
+// CDNA4 mapping: one workgroup (4 waves) per card, ~21 KB of LDS so that four to
+// five cards are resident per CU and one card's serial phases hide behind the others'.
+//   * row features: a wave per row, six rows in flight; lane t loads three aligned
+//     dwords (12 bytes) of the row and produces 4 of the 204 down-sampled gradient
+//     bytes in registers (v_max3/v_min3); a wave min/max reduction gives the row's
+//     normalisation (scale, shift).  LDS keeps the u8 gradients + (scale, shift) per
+//     row -- 1/4 of the float features -- and the float feature is rebuilt (same three
+//     IEEE operations as the reference) when it is fed to the matrix core.
 //   * hidden layer = the one real contraction of the stage, [rows x 204] x [204 x 50]:
 //     v_mfma_f32_16x16x4_f32 (exact f32, the vector rate without the VALU's operand
 //     traffic).  Wave w owns hidden units 16w..16w+15: its B operands (13 float4 per
 //     lane, straight from the row-major weight matrix) stay in registers for the whole
-//     card; A operands are one ds_read_b128 per four MFMAs; two row tiles are
-//     accumulated at a time so the 40-cycle dependent latency is covered.
+//     card; A operands are one ds_read_b32 (4 k-values) per four MFMAs; two row tiles
+//     are accumulated at a time so the 40-cycle dependent latency is covered.
 //   * tanh, the 50->3 logistic layer (wave-local 16-lane reductions + a 4-wave LDS
-//     sum), softmax, and the literal running box sum on one lane.
+//     sum), softmax, and the literal running box sum on one lane (its LDS reads are
+//     independent of the float chain and are issued nine steps ahead).
 // Scores are float probabilities: contract |delta| <= 1e-4 (the reference's own KAT
 // tolerance is 1e-5); the arg-max over window sums is exact except for float near-ties.
 #include <float.h>
@@ -37,26 +42,34 @@ __device__ __forceinline__ int min3i(int a, int b, int c) { return imin(a, imin(
 constexpr int VS_THREADS = 256;
 constexpr int VS_WAVES = 4;
 constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
-constexpr int VS_FSTRIDE = 208;  // feature row stride in floats (13 x 16 k-values)
-constexpr int VS_FROWS = VS_MAXROWS;      // every row carries its own zero k-tail 204..207
+constexpr int VS_GSTRIDE = 208;  // gradient row stride in bytes (13 x 16 k-values, zero tail)
 constexpr int VS_KSTEPS = 13;    // 13 x 16 = 208 >= 204
+constexpr int VS_RIF = 6;        // rows in flight per wave while loading
 
-// One wave turns one card row into the 204 normalised features (n_vseg.cpp:39-43).
-// `row` = card row start (4-byte aligned); ROI columns 10..417.
-__device__ __forceinline__ void vseg_row_features(const uint8_t *__restrict__ row,
-                                                  float *__restrict__ feat, int lane) {
-  // lane t (< 51) owns down-sampled outputs 4t..4t+3, i.e. card columns 9+8t .. 20+8t
-  uint32_t w0 = 0, w1 = 0, w2 = 0;
+struct RowRaw {
+  uint32_t w0, w1, w2;
+};
+
+// lane t (< 51) owns down-sampled outputs 4t..4t+3 = card columns 9+8t .. 20+8t of the row
+__device__ __forceinline__ RowRaw vseg_row_load(const uint8_t *__restrict__ row, int lane) {
+  RowRaw r = {0u, 0u, 0u};
   if (lane < 51) {
     const uint32_t *p = (const uint32_t *)(row + 8 + 8 * lane);
-    w0 = p[0]; w1 = p[1]; w2 = p[2];
+    r.w0 = p[0]; r.w1 = p[1]; r.w2 = p[2];
   }
+  return r;
+}
+
+// n_vseg.cpp:39-43 for one row: gradient, down-sample, and the min-max normalisation
+// constants; writes 4 gradient bytes per lane and (scale, shift) of the row.
+__device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned char *__restrict__ grow,
+                                                  float *__restrict__ norm /* 2 */, int lane) {
   int b[12];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    b[k] = (w0 >> (8 * k)) & 255;
-    b[4 + k] = (w1 >> (8 * k)) & 255;
-    b[8 + k] = (w2 >> (8 * k)) & 255;
+    b[k] = (rw.w0 >> (8 * k)) & 255;
+    b[4 + k] = (rw.w1 >> (8 * k)) & 255;
+    b[8 + k] = (rw.w2 >> (8 * k)) & 255;
   }
   // replicate at the ROI ends: column 9 -> column 10 (lane 0), column 418 -> 417 (lane 50)
   if (lane == 0) b[1] = b[2];
@@ -78,47 +91,74 @@ __device__ __forceinline__ void vseg_row_features(const uint8_t *__restrict__ ro
     vmin = imin(vmin, __shfl_xor(vmin, o, 64));
     vmax = imax(vmax, __shfl_xor(vmax, o, 64));
   }
-  // cvConvertScale(1/255) then cvNormalize(0,1,MINMAX): SURVEY A7/A8
-  const float s255 = 1.0f / 255.0f;
-  const double smin = (double)((float)vmin * s255), smax = (double)((float)vmax * s255);
-  const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.;
-  const double shift = 0.0 - smin * scale;
-  const float fs = (float)scale, fb = (float)shift;
-  if (lane < 52) {  // lane 51 writes the zero k-tail 204..207
-    f32x4 o;
-    o.x = lane < 51 ? ((float)d[0] * s255) * fs + fb : 0.0f;
-    o.y = lane < 51 ? ((float)d[1] * s255) * fs + fb : 0.0f;
-    o.z = lane < 51 ? ((float)d[2] * s255) * fs + fb : 0.0f;
-    o.w = lane < 51 ? ((float)d[3] * s255) * fs + fb : 0.0f;
-    *(f32x4 *)(feat + 4 * lane) = o;
+  if (lane < 52)  // lane 51 writes the zero k-tail 204..207
+    *(uint32_t *)(grow + 4 * lane) =
+        lane < 51 ? (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24) : 0u;
+  if (lane == 0) {
+    // cvConvertScale(1/255) then cvNormalize(0,1,MINMAX): SURVEY A7/A8
+    const float s255 = 1.0f / 255.0f;
+    const double smin = (double)((float)vmin * s255), smax = (double)((float)vmax * s255);
+    const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.;
+    const double shift = 0.0 - smin * scale;
+    norm[0] = (float)scale;
+    norm[1] = (float)shift;
   }
 }
 
-// Hidden + logistic layers for `nrows` feature rows in LDS.  Wave `wave` owns hidden units
+// wave `wave` prepares rows wave, wave+4, ... of the list row_y[0..nrows)
+__device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ card,
+                                                  const int *__restrict__ row_y, int nrows,
+                                                  unsigned char *__restrict__ grad,
+                                                  float *__restrict__ norm, int wave, int lane) {
+  for (int i0 = wave; i0 < nrows; i0 += VS_WAVES * VS_RIF) {
+    RowRaw raw[VS_RIF];
+#pragma unroll
+    for (int k = 0; k < VS_RIF; k++) {
+      const int i = i0 + k * VS_WAVES;
+      if (i < nrows) raw[k] = vseg_row_load(card + (size_t)row_y[i] * DMZ_CARD_WIDTH, lane);
+    }
+#pragma unroll
+    for (int k = 0; k < VS_RIF; k++) {
+      const int i = i0 + k * VS_WAVES;
+      if (i < nrows) vseg_row_features(raw[k], grad + i * VS_GSTRIDE, norm + 2 * i, lane);
+    }
+  }
+}
+
+// the float feature of gradient byte `d`: (d * (1/255)) * scale + shift, three IEEE ops
+__device__ __forceinline__ float feat_of(uint32_t word, int byte, float fs, float fb) {
+  const float f = (float)((word >> (8 * byte)) & 255u) * (1.0f / 255.0f);
+  return f * fs + fb;
+}
+
+// Hidden + logistic layers for `nrows` rows.  Wave `wave` owns hidden units
 // 16*wave .. 16*wave+15; bw[u] holds W1[j][16u + 4kk .. +3] for this lane's (kk, j).
 __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], float b1, float w20,
-                                              float w21, float w22, const float *__restrict__ feat,
-                                              int nrows, float *__restrict__ part /* [4][80][4] */,
-                                              int wave, int lane) {
+                                              float w21, float w22,
+                                              const unsigned char *__restrict__ grad,
+                                              const float *__restrict__ norm, int nrows,
+                                              float *__restrict__ part /* [4][80][4] */, int wave,
+                                              int lane) {
   const int ii = lane & 15, kk = lane >> 4;
   const int ntiles = (nrows + 15) >> 4;
   for (int mt = 0; mt < ntiles; mt += 2) {
     const int r0 = imin(mt * 16 + ii, nrows - 1), r1 = imin(mt * 16 + 16 + ii, nrows - 1);
-    const float *a0p = feat + r0 * VS_FSTRIDE + 4 * kk;
-    const float *a1p = feat + r1 * VS_FSTRIDE + 4 * kk;
+    const uint32_t *a0p = (const uint32_t *)(grad + r0 * VS_GSTRIDE + 4 * kk);
+    const uint32_t *a1p = (const uint32_t *)(grad + r1 * VS_GSTRIDE + 4 * kk);
+    const float fs0 = norm[2 * r0], fb0 = norm[2 * r0 + 1];
+    const float fs1 = norm[2 * r1], fb1 = norm[2 * r1 + 1];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < VS_KSTEPS; u++) {
-      const f32x4 a0 = *(const f32x4 *)(a0p + 16 * u);
-      const f32x4 a1 = *(const f32x4 *)(a1p + 16 * u);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bw[u].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bw[u].x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bw[u].y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bw[u].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bw[u].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bw[u].z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bw[u].w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bw[u].w, acc1, 0, 0, 0);
+      const uint32_t g0 = a0p[4 * u], g1 = a1p[4 * u];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), bw[u].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 0, fs1, fb1), bw[u].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), bw[u].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 1, fs1, fb1), bw[u].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), bw[u].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 2, fs1, fb1), bw[u].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), bw[u].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 3, fs1, fb1), bw[u].w, acc1, 0, 0, 0);
     }
     // D layout: column (hidden unit) = lane & 15, row = 4 * (lane >> 4) + v
 #pragma unroll
@@ -144,25 +184,39 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
   }
 }
 
-// n_vseg.cpp:49-92, literally (one thread).
-__device__ void vseg_best_segmentation(const float *vis, const float *amx, float *ring /* 54 */,
+// n_vseg.cpp:49-92 on one lane.  The reference's ring buffer entry read at step y is
+// the score of row y - 26, so the window is fed from the score arrays directly; the float
+// add / compare / subtract sequence is literal.  Scores live in arrays padded to 288.
+__device__ void vseg_best_segmentation(const float *__restrict__ vis, const float *__restrict__ amx,
                                        float *score, int *y_off, int *pattern) {
   float vsum = 0.0f, asum = 0.0f;
   float best = 0.0f;
   int bp = 0, by = 0;
-  for (int y = 0; y < 270; y++) {
-    const float v = vis[y], a = amx[y];
-    vsum = vsum + v;
-    asum = asum + a;
-    const int bi = y % 27;
-    ring[bi] = v;
-    ring[27 + bi] = a;
-    if (y >= 26) {
-      if (vsum > best) { best = vsum; bp = 1; by = y - 27 + 1; }
-      if (asum > best) { best = asum; bp = 2; by = y - 27 + 1; }
-      const int nbi = (y + 1) % 27;
-      vsum = vsum - ring[nbi];
-      asum = asum - ring[27 + nbi];
+  // rows 0..25: the window is not full yet
+  for (int y0 = 0; y0 < 26; y0 += 13) {
+    float v[13], a[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) { v[k] = vis[y0 + k]; a[k] = amx[y0 + k]; }
+#pragma unroll
+    for (int k = 0; k < 13; k++) { vsum = vsum + v[k]; asum = asum + a[k]; }
+  }
+  // rows 26..269 (244 = 4 * 61 steps... processed 4 at a time with the loads up front)
+  for (int y0 = 26; y0 < 270; y0 += 4) {
+    float v[4], a[4], ov[4], oa[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k] = vis[y0 + k]; a[k] = amx[y0 + k];
+      ov[k] = vis[y0 + k - 26]; oa[k] = amx[y0 + k - 26];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int y = y0 + k;
+      vsum = vsum + v[k];
+      asum = asum + a[k];
+      if (vsum > best) { best = vsum; bp = 1; by = y - 26; }
+      if (asum > best) { best = asum; bp = 2; by = y - 26; }
+      vsum = vsum - ov[k];
+      asum = asum - oa[k];
     }
   }
   *score = best;
@@ -190,18 +244,37 @@ __device__ __forceinline__ void vseg_finish_rows(const float *__restrict__ wts,
   }
 }
 
+struct VsegWeights {
+  f32x4 bw[VS_KSTEPS];
+  float b1, w20, w21, w22;
+};
+
+__device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts, int wave, int lane,
+                                                  VsegWeights &w) {
+  const int j = 16 * wave + (lane & 15), kk = lane >> 4;
+  const bool unit = j < 50;
+#pragma unroll
+  for (int u = 0; u < VS_KSTEPS; u++) {
+    const int k0 = 16 * u + 4 * kk;
+    if (unit && k0 < 204) w.bw[u] = *(const f32x4 *)(wts + dmzw::VSEG_W1 + j * 204 + k0);
+    else w.bw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  w.b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
+  w.w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
+  w.w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
+  w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
+}
+
 __global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ wts,
                                                       const uint8_t *__restrict__ cards,
                                                       size_t card_stride, int n, int only_warped,
                                                       dmz_hip_frame_result *__restrict__ results) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  float *feat = (float *)lds;                         // VS_FROWS x VS_FSTRIDE
-  float *part = feat + VS_FROWS * VS_FSTRIDE;         // 4 x 80 x 4
-  float *vis = part + 4 * 80 * 4;                     // 272
-  float *amx = vis + 272;                             // 272
-  float *ring = amx + 272;                            // 54 (+2)
-  int *row_y = (int *)(ring + 56);                    // VS_MAXROWS
-  int *s_int = row_y + VS_MAXROWS;                    // 4
+  __shared__ __attribute__((aligned(16))) unsigned char grad[VS_MAXROWS * VS_GSTRIDE];  // 14,144 B
+  __shared__ float norm[2 * VS_MAXROWS];
+  __shared__ float part[4 * 80 * 4];  // 5,120 B
+  __shared__ float vis[288], amx[288];
+  __shared__ int row_y[VS_MAXROWS];
+  __shared__ int s_int[4];
 
   const int f = blockIdx.x;
   if (f >= n) return;
@@ -218,35 +291,22 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ w
   }
   const uint8_t *card = cards + (size_t)f * card_stride;
 
-  // this wave's slice of the weights: hidden units 16*wave + (lane & 15)
-  const int j = 16 * wave + (lane & 15), kk = lane >> 4;
-  const bool unit = j < 50;
-  f32x4 bw[VS_KSTEPS];
-#pragma unroll
-  for (int u = 0; u < VS_KSTEPS; u++) {
-    const int k0 = 16 * u + 4 * kk;
-    if (unit && k0 < 204) bw[u] = *(const f32x4 *)(wts + dmzw::VSEG_W1 + j * 204 + k0);
-    else bw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  const float b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
-  const float w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
-  const float w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
-  const float w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
-
-  for (int i = tid; i < 272; i += VS_THREADS) { vis[i] = 0.0f; amx[i] = 0.0f; }
+  for (int i = tid; i < 288; i += VS_THREADS) { vis[i] = 0.0f; amx[i] = 0.0f; }
   // coarse pass: rows 0, 4, ..., 268 (n_vseg.cpp:116-125)
   for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = 4 * i;
-  for (int i = wave; i < VS_MAXROWS; i += VS_WAVES)
-    vseg_row_features(card + (size_t)(4 * i) * DMZ_CARD_WIDTH, feat + i * VS_FSTRIDE, lane);
   __syncthreads();
-  vseg_mlp_rows(bw, b1, w20, w21, w22, feat, VS_MAXROWS, part, wave, lane);
+  vseg_prepare_rows(card, row_y, VS_MAXROWS, grad, norm, wave, lane);
+  VsegWeights w;
+  vseg_load_weights(wts, wave, lane, w);
+  __syncthreads();
+  vseg_mlp_rows(w.bw, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
   __syncthreads();
   vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
   __syncthreads();
   if (tid == 0) {
     float score;
     int y_off, pattern;
-    vseg_best_segmentation(vis, amx, ring, &score, &y_off, &pattern);
+    vseg_best_segmentation(vis, amx, &score, &y_off, &pattern);
     // fine pass rows (n_vseg.cpp:140-152)
     int ymin = y_off < 8 ? 0 : y_off - 8;
     ymin = imin(270, ymin);
@@ -259,10 +319,9 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ w
   __syncthreads();
   const int nfine = s_int[0];
   if (nfine > 0) {
-    for (int i = wave; i < nfine; i += VS_WAVES)
-      vseg_row_features(card + (size_t)row_y[i] * DMZ_CARD_WIDTH, feat + i * VS_FSTRIDE, lane);
+    vseg_prepare_rows(card, row_y, nfine, grad, norm, wave, lane);
     __syncthreads();
-    vseg_mlp_rows(bw, b1, w20, w21, w22, feat, nfine, part, wave, lane);
+    vseg_mlp_rows(w.bw, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
     __syncthreads();
     vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
     __syncthreads();
@@ -270,7 +329,7 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ w
   if (tid == 0) {
     float score;
     int y_off, pattern;
-    vseg_best_segmentation(vis, amx, ring, &score, &y_off, &pattern);
+    vseg_best_segmentation(vis, amx, &score, &y_off, &pattern);
     int flags = in_flags & DMZ_HIP_FLAG_WARPED;
     if (y_off < (DMZ_CARD_HEIGHT - 27) / 2) flags |= DMZ_HIP_FLAG_UPSIDE_DOWN;  // frame.cpp:38
     else if (score > 15.0f) flags |= DMZ_HIP_FLAG_VSEG_OK;                       // frame.cpp:43
@@ -290,35 +349,53 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ w
   if (tid < 16) { res->digits[tid] = 0; res->offsets[tid] = 0; }
 }
 
-// Stand-alone model entry point (KAT): up to 16 input vectors per workgroup, same MFMA path.
+// Stand-alone model entry point (KAT): up to 16 input vectors per workgroup, same MFMA
+// path fed with float features.
 __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restrict__ wts,
                                                             const float *__restrict__ x, int n,
                                                             float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float feat[16 * VS_FSTRIDE];
+  __shared__ __attribute__((aligned(16))) float feat[16 * 208];
   __shared__ float part[4 * 80 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int base = blockIdx.x * 16;
   const int rows = imin(16, n - base);
   if (rows <= 0) return;
-  const int j = 16 * wave + (lane & 15), kk = lane >> 4;
-  const bool unit = j < 50;
-  f32x4 bw[VS_KSTEPS];
-#pragma unroll
-  for (int u = 0; u < VS_KSTEPS; u++) {
-    const int k0 = 16 * u + 4 * kk;
-    if (unit && k0 < 204) bw[u] = *(const f32x4 *)(wts + dmzw::VSEG_W1 + j * 204 + k0);
-    else bw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  const float b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
-  const float w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
-  const float w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
-  const float w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
-  for (int i = tid; i < 16 * VS_FSTRIDE; i += VS_THREADS) {
-    const int r = i / VS_FSTRIDE, k = i - r * VS_FSTRIDE;
+  VsegWeights w;
+  vseg_load_weights(wts, wave, lane, w);
+  for (int i = tid; i < 16 * 208; i += VS_THREADS) {
+    const int r = i / 208, k = i - r * 208;
     feat[i] = (r < rows && k < 204) ? x[(size_t)(base + r) * 204 + k] : 0.0f;
   }
   __syncthreads();
-  vseg_mlp_rows(bw, b1, w20, w21, w22, feat, rows, part, wave, lane);
+  {
+    const int ii = lane & 15, kk = lane >> 4;
+    const float *ap = feat + imin(ii, rows - 1) * 208 + 4 * kk;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < VS_KSTEPS; u++) {
+      const f32x4 a = *(const f32x4 *)(ap + 16 * u);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.bw[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.bw[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.bw[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.bw[u].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float hv = tanhf(acc[v] + w.b1);
+      float o0 = w.w20 * hv, o1 = w.w21 * hv, o2 = w.w22 * hv;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        o0 += __shfl_xor(o0, o, 64);
+        o1 += __shfl_xor(o1, o, 64);
+        o2 += __shfl_xor(o2, o, 64);
+      }
+      const int row = 4 * kk + v;
+      if (ii == 0 && row < rows) {
+        float *p = part + (wave * 80 + row) * 4;
+        p[0] = o0; p[1] = o1; p[2] = o2;
+      }
+    }
+  }
   __syncthreads();
   if (tid < rows) {
     float o[3];
@@ -333,13 +410,11 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
   }
 }
 
-constexpr int kVsegLds = (VS_FROWS * VS_FSTRIDE + 4 * 80 * 4 + 272 * 2 + 56) * 4 + (VS_MAXROWS + 4) * 4;
-
 }  // namespace
 
 void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
                      int n, int only_warped, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), kVsegLds, s, weights, cards, card_stride, n,
+  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), 0, s, weights, cards, card_stride, n,
                      only_warped, results);
 }
 
@@ -347,7 +422,4 @@ void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *x, 
   hipLaunchKernelGGL(k_vseg_model, dim3((n + 15) / 16), dim3(VS_THREADS), 0, s, weights, x, n, out);
 }
 
-int dmz_configure_vseg(void) {
-  return (int)hipFuncSetAttribute((const void *)k_vseg, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kVsegLds);
-}
+int dmz_configure_vseg(void) { return 0; }
