@@ -1,0 +1,275 @@
+// geometry.hip -- per-frame geometry (edges -> corners -> homography); the warp itself
+// (perspective rectification of the card to 428 x 270) is in warp.hip.
+//
+// Replaces, for a whole batch:
+//   find_line_in_detection_rects' origin shift (dmz.cpp:364-366, geometry.cpp:34-43),
+//   parametricIntersect (geometry.cpp:14-32, Eigen 2x2 inverse Inverse.h:70-89),
+//   dmz_transform_card's corner ordering (dmz.cpp:443-471),
+//   llcv_calc_persp_transform (warp.cpp:34-125; Eigen 3.2.4 HouseholderQR<8x8 float>
+//   in scalar evaluation order: HouseholderQR.h:219-250,306-334, Householder.h:65-130),
+//   cvWarpPerspective(INTER_LINEAR | FILL_OUTLIERS, 0) (warp.cpp:165; OpenCV 2.4
+//   semantics).
+//
+// Bit-exactness: this file is compiled with -ffp-contract=off; every float /
+// double expression is a sequence of single IEEE operations in the reference's
+// order (fp32 sqrt and division are correctly rounded by default under hipcc).
+// No transcendental is evaluated on the device: cosf/sinf of the ten possible
+// line angles and the origin-shift terms arrive as host-computed tables.
+#include <float.h>
+
+#include "dmz_hip_internal.h"
+
+namespace {
+
+#define QA(r, c) a[(c) * 8 + (r)]
+
+// x = A.householderQr().solve(b), column-major 8x8 float, scalar Eigen order.
+__device__ void householder_qr_solve8(float *a, float *b) {
+  float hcoef[8];
+  for (int k = 0; k < 8; k++) {
+    const int rem = 8 - k;
+    float tail_sq = 0.0f;
+    for (int i = 1; i < rem; i++) {
+      float v = QA(k + i, k);
+      tail_sq = tail_sq + v * v;
+    }
+    const float c0 = QA(k, k);
+    float tau, beta;
+    if (rem == 1 || tail_sq == 0.0f) {
+      tau = 0.0f;
+      beta = c0;
+      for (int i = 1; i < rem; i++) QA(k + i, k) = 0.0f;
+    } else {
+      beta = sqrtf(c0 * c0 + tail_sq);
+      if (c0 >= 0.0f) beta = -beta;
+      const float denom = c0 - beta;
+      for (int i = 1; i < rem; i++) QA(k + i, k) = QA(k + i, k) / denom;
+      tau = (beta - c0) / beta;
+    }
+    hcoef[k] = tau;
+    QA(k, k) = beta;
+    const int rcols = 8 - k - 1;
+    if (rcols > 0 && rem > 1) {
+      for (int c = 0; c < rcols; c++) {
+        const int col = k + 1 + c;
+        float tmp = 0.0f;
+        for (int i = 1; i < rem; i++) tmp = tmp + QA(k + i, k) * QA(k + i, col);
+        tmp = tmp + QA(k, col);
+        QA(k, col) = QA(k, col) - tau * tmp;
+        for (int i = 1; i < rem; i++) QA(k + i, col) = QA(k + i, col) - (tau * QA(k + i, k)) * tmp;
+      }
+    }
+  }
+  for (int k = 0; k < 8; k++) {
+    const int rem = 8 - k;
+    const float tau = hcoef[k];
+    if (rem == 1) {
+      b[k] = b[k] * (1.0f - tau);
+    } else {
+      float tmp = 0.0f;
+      for (int i = 1; i < rem; i++) tmp = tmp + QA(k + i, k) * b[k + i];
+      tmp = tmp + b[k];
+      b[k] = b[k] - tau * tmp;
+      for (int i = 1; i < rem; i++) b[k + i] = b[k + i] - (tau * QA(k + i, k)) * tmp;
+    }
+  }
+  for (int i = 7; i >= 0; i--) {
+    b[i] = b[i] / QA(i, i);
+    for (int r = 0; r < i; r++) b[r] = b[r] - b[i] * QA(r, i);
+  }
+}
+
+__device__ void calc_persp_transform(const float *sp, const float *dp, float *m) {
+  float a[64], b[8];
+  for (int i = 0; i < 4; i++) {
+    const float sx = sp[2 * i], sy = sp[2 * i + 1], dx = dp[2 * i], dy = dp[2 * i + 1];
+    QA(i, 0) = sx; QA(i, 1) = sy; QA(i, 2) = 1; QA(i, 3) = 0; QA(i, 4) = 0; QA(i, 5) = 0;
+    QA(i, 6) = -sx * dx; QA(i, 7) = -sy * dx;
+    QA(i + 4, 0) = 0; QA(i + 4, 1) = 0; QA(i + 4, 2) = 0;
+    QA(i + 4, 3) = sx; QA(i + 4, 4) = sy; QA(i + 4, 5) = 1;
+    QA(i + 4, 6) = -sx * dy; QA(i + 4, 7) = -sy * dy;
+    b[i] = dx;
+    b[i + 4] = dy;
+  }
+  householder_qr_solve8(a, b);
+  m[0] = b[0]; m[1] = b[1]; m[2] = b[2];
+  m[3] = b[3]; m[4] = b[4]; m[5] = b[5];
+  m[6] = b[6]; m[7] = b[7]; m[8] = 1.0f;
+}
+
+// cv::invert of the 3x3 (float -> double) matrix, as cvWarpPerspective does when
+// CV_WARP_INVERSE_MAP is absent.
+__device__ void invert3x3(const float *mf, DmzWarpMat *out) {
+  double s[9];
+  for (int i = 0; i < 9; i++) s[i] = (double)mf[i];
+  const double det = s[0] * (s[4] * s[8] - s[5] * s[7]) - s[1] * (s[3] * s[8] - s[5] * s[6]) +
+                     s[2] * (s[3] * s[7] - s[4] * s[6]);
+  if (det != 0.) {
+    const double d = 1. / det;
+    out->m[0] = (s[4] * s[8] - s[5] * s[7]) * d;
+    out->m[1] = (s[2] * s[7] - s[1] * s[8]) * d;
+    out->m[2] = (s[1] * s[5] - s[2] * s[4]) * d;
+    out->m[3] = (s[5] * s[6] - s[3] * s[8]) * d;
+    out->m[4] = (s[0] * s[8] - s[2] * s[6]) * d;
+    out->m[5] = (s[2] * s[3] - s[0] * s[5]) * d;
+    out->m[6] = (s[3] * s[7] - s[4] * s[6]) * d;
+    out->m[7] = (s[1] * s[6] - s[0] * s[7]) * d;
+    out->m[8] = (s[0] * s[4] - s[1] * s[3]) * d;
+  } else {
+    for (int i = 0; i < 9; i++) out->m[i] = 0.;
+  }
+}
+
+// geometry.cpp:14-32
+__device__ bool parametric_intersect(float rho1, float c1, float s1, float rho2, float c2, float s2,
+                                     float *x, float *y) {
+  const float det = c1 * s2 - c2 * s1;
+  if ((double)det < 1e-10) return false;
+  const float invdet = 1.0f / det;
+  const float i00 = s2 * invdet, i10 = -c2 * invdet, i01 = -s1 * invdet, i11 = c1 * invdet;
+  *x = i00 * rho1 + i01 * rho2;
+  *y = i10 * rho1 + i11 * rho2;
+  return true;
+}
+
+__global__ void k_geometry(int n, const DmzDetectParams *__restrict__ params,
+                           const DmzBoxHit *__restrict__ hits, int nplanes,
+                           dmz_hip_frame_result *__restrict__ results) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  dmz_hip_frame_result *res = results + f;
+  float rho[4], ct[4], st[4];
+  int found[4];
+  for (int e = 0; e < 4; e++) {
+    found[e] = 0;
+    rho[e] = FLT_MAX;  // ParametricLineNone(), geometry.h:24-29
+    ct[e] = 0.0f;
+    st[e] = 0.0f;
+    float theta = FLT_MAX;
+    for (int pl = 0; pl < nplanes && !found[e]; pl++) {
+      const DmzBoxHit hit = hits[((size_t)pl * n + f) * 4 + e];
+      if (!hit.found) continue;
+      const DmzBoxParams &bp = params[pl].box[e];
+      // hough.cpp:190-191, then geometry.cpp:41, then dmz.cpp:365
+      const float rho_local = ((float)hit.r - (float)(bp.numrho - 1) * 0.5f) * 1.0f;
+      float shifted = (float)((double)rho_local + bp.delta_rho[hit.n]);
+      shifted = shifted * bp.rho_multiplier;
+      rho[e] = shifted;
+      theta = bp.theta_n[hit.n];
+      ct[e] = bp.cos_t[hit.n];
+      st[e] = bp.sin_t[hit.n];
+      found[e] = 1;
+    }
+    res->found[e] = found[e];
+    res->rho[e] = rho[e];
+    res->theta[e] = theta;
+  }
+  bool all = found[0] && found[1] && found[2] && found[3];
+  float cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+  if (all) {
+    // edges: 0 top, 1 left, 2 bottom, 3 right; corners: tl, bl, tr, br (dmz.cpp:420-423)
+    const bool a = parametric_intersect(rho[0], ct[0], st[0], rho[1], ct[1], st[1], &cx[0], &cy[0]);
+    const bool b = parametric_intersect(rho[2], ct[2], st[2], rho[1], ct[1], st[1], &cx[1], &cy[1]);
+    const bool c = parametric_intersect(rho[0], ct[0], st[0], rho[3], ct[3], st[3], &cx[2], &cy[2]);
+    const bool d = parametric_intersect(rho[2], ct[2], st[2], rho[3], ct[3], st[3], &cx[3], &cy[3]);
+    all = a && b && c && d;
+  }
+  for (int i = 0; i < 4; i++) {
+    res->corners[2 * i] = cx[i];
+    res->corners[2 * i + 1] = cy[i];
+  }
+  res->found_all = all ? 1 : 0;
+  res->flags = 0;
+}
+
+// dmz_transform_card's part before the warp: corners -> source points -> float
+// homography -> inverse double matrix (dmz.cpp:446-471, warp.cpp:153-165).
+__global__ void k_homography(int n, int orientation, int options,
+                             dmz_hip_frame_result *__restrict__ results,
+                             DmzWarpMat *__restrict__ mats) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  dmz_hip_frame_result *res = results + f;
+  const bool all = res->found_all != 0;
+  DmzWarpMat wm;
+  wm.valid = all ? 1 : 0;
+  wm.pad_ = 0;
+  for (int i = 0; i < 9; i++) wm.m[i] = 0.;
+  if (all) {
+    int o0, o1, o2, o3;
+    switch (orientation) {
+      case 1: o0 = 1; o1 = 0; o2 = 3; o3 = 2; break;  // portrait: bl, tl, br, tr
+      case 2: o0 = 2; o1 = 3; o2 = 0; o3 = 1; break;  // upside down: tr, br, tl, bl
+      case 4: o0 = 3; o1 = 1; o2 = 2; o3 = 0; break;  // landscape left: br, bl, tr, tl
+      default: o0 = 0; o1 = 2; o2 = 1; o3 = 3; break; // landscape right: tl, tr, bl, br
+    }
+    const int ord[4] = {o0, o1, o2, o3};
+    float sp[8], dp[8], m[9];
+    for (int i = 0; i < 4; i++) {
+      float px = res->corners[2 * ord[i]], py = res->corners[2 * ord[i] + 1];
+      if (options & DMZ_HIP_OPT_TRUNCATE_CORNERS) {
+        px = (float)(int)px;
+        py = (float)(int)py;
+      }
+      sp[2 * i] = px;
+      sp[2 * i + 1] = py;
+    }
+    const float rw = (float)(DMZ_CARD_WIDTH - 1), rh = (float)(DMZ_CARD_HEIGHT - 1);
+    dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f + rw; dp[3] = 0.0f;
+    dp[4] = 0.0f; dp[5] = 0.0f + rh; dp[6] = 0.0f + rw; dp[7] = 0.0f + rh;
+    calc_persp_transform(sp, dp, m);
+    invert3x3(m, &wm);
+    res->flags = (res->flags & ~DMZ_HIP_FLAG_WARPED) | DMZ_HIP_FLAG_WARPED;
+  } else {
+    res->flags = res->flags & ~DMZ_HIP_FLAG_WARPED;
+  }
+  mats[f] = wm;
+}
+
+__global__ void k_persp(int n, const float *__restrict__ src_pts, const float *__restrict__ dst_pts,
+                        float *__restrict__ m9) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  float sp[8], dp[8], m[9];
+  for (int i = 0; i < 8; i++) {
+    sp[i] = src_pts[f * 8 + i];
+    dp[i] = dst_pts[f * 8 + i];
+  }
+  calc_persp_transform(sp, dp, m);
+  for (int i = 0; i < 9; i++) m9[f * 9 + i] = m[i];
+}
+
+__global__ void k_mats_from_float(int n, const float *__restrict__ m9, DmzWarpMat *__restrict__ mats) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  float m[9];
+  for (int i = 0; i < 9; i++) m[i] = m9[f * 9 + i];
+  DmzWarpMat wm;
+  wm.valid = 1;
+  wm.pad_ = 0;
+  invert3x3(m, &wm);
+  mats[f] = wm;
+}
+
+}  // namespace
+
+void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params, const DmzBoxHit *hits,
+                         int nplanes, dmz_hip_frame_result *results) {
+  hipLaunchKernelGGL(k_geometry, dim3((n + 63) / 64), dim3(64), 0, s, n, params, hits, nplanes,
+                     results);
+}
+
+void dmz_launch_homography(hipStream_t s, int n, int orientation, int options,
+                           dmz_hip_frame_result *results, DmzWarpMat *mats) {
+  hipLaunchKernelGGL(k_homography, dim3((n + 63) / 64), dim3(64), 0, s, n, orientation, options,
+                     results, mats);
+}
+
+void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9) {
+  hipLaunchKernelGGL(k_persp, dim3((n + 63) / 64), dim3(64), 0, s, n, src_pts, dst_pts, m9);
+}
+
+void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMat *mats) {
+  hipLaunchKernelGGL(k_mats_from_float, dim3((n + 63) / 64), dim3(64), 0, s, n, m9, mats);
+}
+

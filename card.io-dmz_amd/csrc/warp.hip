@@ -1,272 +1,63 @@
-// warp.hip -- per-frame geometry (edges -> corners -> homography) and the
-// perspective rectification of the card to 428 x 270.
+// warp.hip -- perspective rectification of the card to 428 x 270.
 //
-// Replaces, for a whole batch:
-//   find_line_in_detection_rects' origin shift (dmz.cpp:364-366, geometry.cpp:34-43),
-//   parametricIntersect (geometry.cpp:14-32, Eigen 2x2 inverse Inverse.h:70-89),
-//   dmz_transform_card's corner ordering (dmz.cpp:443-471),
-//   llcv_calc_persp_transform (warp.cpp:34-125; Eigen 3.2.4 HouseholderQR<8x8 float>
-//   in scalar evaluation order: HouseholderQR.h:219-250,306-334, Householder.h:65-130),
-//   cvWarpPerspective(INTER_LINEAR | FILL_OUTLIERS, 0) (warp.cpp:165; OpenCV 2.4
-//   semantics).
+// Replaces, for a whole batch, llcv_unwarp's CPU branch (cv/warp.cpp:153-166):
+// cvWarpPerspective(src, dst, M, CV_INTER_LINEAR + CV_WARP_FILL_OUTLIERS, 0) with the
+// OpenCV 2.4 semantics restated in SURVEY.md Appendix A10: per destination pixel in
+// 64-wide blocks  X0 = M0*x + M1*y + M2 (fp64), then (X0 + M0*x1) * (32 / W), cvRound
+// to 1/32 px, 5-bit fractions, (sum p*w + 2^14) >> 15 bilinear blend, zero outside the
+// source.  fp64 operations are single IEEE operations in that order (-ffp-contract=off),
+// so the card is byte-exact.
 //
-// Bit-exactness: this file is compiled with -ffp-contract=off; every float /
-// double expression is a sequence of single IEEE operations in the reference's
-// order (fp32 sqrt and division are correctly rounded by default under hipcc).
-// No transcendental is evaluated on the device: cosf/sinf of the ten possible
-// line angles and the origin-shift terms arrive as host-computed tables.
-#include <float.h>
-
+// CDNA4 mapping: one workgroup per 64 x 32 destination tile (two of OpenCV's 64 x 16
+// blocks; the x block origin -- the only one that enters the fp64 association -- is the
+// same).  Each thread first computes the fixed-point source coordinates of its 8 pixels;
+// a wave/LDS reduction gives the tile's exact source bounding box, which is staged into
+// LDS with aligned 32-bit row loads (zero outside the image = BORDER_CONSTANT 0), and
+// the four bilinear taps per pixel become LDS byte reads instead of 4 scattered global
+// byte loads (the v1 kernel was bound by vector-memory address processing).  Tiles
+// whose bounding box exceeds the LDS window (extreme, caller-supplied matrices) take
+// the direct global path.  Blocks are renumbered so that all tiles of a frame run on one
+// XCD (block b is dispatched to XCD b % 8) and share its L2.
 #include "dmz_hip_internal.h"
 
 namespace {
 
-#define QA(r, c) a[(c) * 8 + (r)]
-
-// x = A.householderQr().solve(b), column-major 8x8 float, scalar Eigen order.
-__device__ void householder_qr_solve8(float *a, float *b) {
-  float hcoef[8];
-  for (int k = 0; k < 8; k++) {
-    const int rem = 8 - k;
-    float tail_sq = 0.0f;
-    for (int i = 1; i < rem; i++) {
-      float v = QA(k + i, k);
-      tail_sq = tail_sq + v * v;
-    }
-    const float c0 = QA(k, k);
-    float tau, beta;
-    if (rem == 1 || tail_sq == 0.0f) {
-      tau = 0.0f;
-      beta = c0;
-      for (int i = 1; i < rem; i++) QA(k + i, k) = 0.0f;
-    } else {
-      beta = sqrtf(c0 * c0 + tail_sq);
-      if (c0 >= 0.0f) beta = -beta;
-      const float denom = c0 - beta;
-      for (int i = 1; i < rem; i++) QA(k + i, k) = QA(k + i, k) / denom;
-      tau = (beta - c0) / beta;
-    }
-    hcoef[k] = tau;
-    QA(k, k) = beta;
-    const int rcols = 8 - k - 1;
-    if (rcols > 0 && rem > 1) {
-      for (int c = 0; c < rcols; c++) {
-        const int col = k + 1 + c;
-        float tmp = 0.0f;
-        for (int i = 1; i < rem; i++) tmp = tmp + QA(k + i, k) * QA(k + i, col);
-        tmp = tmp + QA(k, col);
-        QA(k, col) = QA(k, col) - tau * tmp;
-        for (int i = 1; i < rem; i++) QA(k + i, col) = QA(k + i, col) - (tau * QA(k + i, k)) * tmp;
-      }
-    }
-  }
-  for (int k = 0; k < 8; k++) {
-    const int rem = 8 - k;
-    const float tau = hcoef[k];
-    if (rem == 1) {
-      b[k] = b[k] * (1.0f - tau);
-    } else {
-      float tmp = 0.0f;
-      for (int i = 1; i < rem; i++) tmp = tmp + QA(k + i, k) * b[k + i];
-      tmp = tmp + b[k];
-      b[k] = b[k] - tau * tmp;
-      for (int i = 1; i < rem; i++) b[k + i] = b[k + i] - (tau * QA(k + i, k)) * tmp;
-    }
-  }
-  for (int i = 7; i >= 0; i--) {
-    b[i] = b[i] / QA(i, i);
-    for (int r = 0; r < i; r++) b[r] = b[r] - b[i] * QA(r, i);
-  }
-}
-
-__device__ void calc_persp_transform(const float *sp, const float *dp, float *m) {
-  float a[64], b[8];
-  for (int i = 0; i < 4; i++) {
-    const float sx = sp[2 * i], sy = sp[2 * i + 1], dx = dp[2 * i], dy = dp[2 * i + 1];
-    QA(i, 0) = sx; QA(i, 1) = sy; QA(i, 2) = 1; QA(i, 3) = 0; QA(i, 4) = 0; QA(i, 5) = 0;
-    QA(i, 6) = -sx * dx; QA(i, 7) = -sy * dx;
-    QA(i + 4, 0) = 0; QA(i + 4, 1) = 0; QA(i + 4, 2) = 0;
-    QA(i + 4, 3) = sx; QA(i + 4, 4) = sy; QA(i + 4, 5) = 1;
-    QA(i + 4, 6) = -sx * dy; QA(i + 4, 7) = -sy * dy;
-    b[i] = dx;
-    b[i + 4] = dy;
-  }
-  householder_qr_solve8(a, b);
-  m[0] = b[0]; m[1] = b[1]; m[2] = b[2];
-  m[3] = b[3]; m[4] = b[4]; m[5] = b[5];
-  m[6] = b[6]; m[7] = b[7]; m[8] = 1.0f;
-}
-
-// cv::invert of the 3x3 (float -> double) matrix, as cvWarpPerspective does when
-// CV_WARP_INVERSE_MAP is absent.
-__device__ void invert3x3(const float *mf, DmzWarpMat *out) {
-  double s[9];
-  for (int i = 0; i < 9; i++) s[i] = (double)mf[i];
-  const double det = s[0] * (s[4] * s[8] - s[5] * s[7]) - s[1] * (s[3] * s[8] - s[5] * s[6]) +
-                     s[2] * (s[3] * s[7] - s[4] * s[6]);
-  if (det != 0.) {
-    const double d = 1. / det;
-    out->m[0] = (s[4] * s[8] - s[5] * s[7]) * d;
-    out->m[1] = (s[2] * s[7] - s[1] * s[8]) * d;
-    out->m[2] = (s[1] * s[5] - s[2] * s[4]) * d;
-    out->m[3] = (s[5] * s[6] - s[3] * s[8]) * d;
-    out->m[4] = (s[0] * s[8] - s[2] * s[6]) * d;
-    out->m[5] = (s[2] * s[3] - s[0] * s[5]) * d;
-    out->m[6] = (s[3] * s[7] - s[4] * s[6]) * d;
-    out->m[7] = (s[1] * s[6] - s[0] * s[7]) * d;
-    out->m[8] = (s[0] * s[4] - s[1] * s[3]) * d;
-  } else {
-    for (int i = 0; i < 9; i++) out->m[i] = 0.;
-  }
-}
-
-// geometry.cpp:14-32
-__device__ bool parametric_intersect(float rho1, float c1, float s1, float rho2, float c2, float s2,
-                                     float *x, float *y) {
-  const float det = c1 * s2 - c2 * s1;
-  if ((double)det < 1e-10) return false;
-  const float invdet = 1.0f / det;
-  const float i00 = s2 * invdet, i10 = -c2 * invdet, i01 = -s1 * invdet, i11 = c1 * invdet;
-  *x = i00 * rho1 + i01 * rho2;
-  *y = i10 * rho1 + i11 * rho2;
-  return true;
-}
-
-__global__ void k_geometry(int n, const DmzDetectParams *__restrict__ params,
-                           const DmzBoxHit *__restrict__ hits, int nplanes,
-                           dmz_hip_frame_result *__restrict__ results) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  dmz_hip_frame_result *res = results + f;
-  float rho[4], ct[4], st[4];
-  int found[4];
-  for (int e = 0; e < 4; e++) {
-    found[e] = 0;
-    rho[e] = FLT_MAX;  // ParametricLineNone(), geometry.h:24-29
-    ct[e] = 0.0f;
-    st[e] = 0.0f;
-    float theta = FLT_MAX;
-    for (int pl = 0; pl < nplanes && !found[e]; pl++) {
-      const DmzBoxHit hit = hits[((size_t)pl * n + f) * 4 + e];
-      if (!hit.found) continue;
-      const DmzBoxParams &bp = params[pl].box[e];
-      // hough.cpp:190-191, then geometry.cpp:41, then dmz.cpp:365
-      const float rho_local = ((float)hit.r - (float)(bp.numrho - 1) * 0.5f) * 1.0f;
-      float shifted = (float)((double)rho_local + bp.delta_rho[hit.n]);
-      shifted = shifted * bp.rho_multiplier;
-      rho[e] = shifted;
-      theta = bp.theta_n[hit.n];
-      ct[e] = bp.cos_t[hit.n];
-      st[e] = bp.sin_t[hit.n];
-      found[e] = 1;
-    }
-    res->found[e] = found[e];
-    res->rho[e] = rho[e];
-    res->theta[e] = theta;
-  }
-  bool all = found[0] && found[1] && found[2] && found[3];
-  float cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
-  if (all) {
-    // edges: 0 top, 1 left, 2 bottom, 3 right; corners: tl, bl, tr, br (dmz.cpp:420-423)
-    const bool a = parametric_intersect(rho[0], ct[0], st[0], rho[1], ct[1], st[1], &cx[0], &cy[0]);
-    const bool b = parametric_intersect(rho[2], ct[2], st[2], rho[1], ct[1], st[1], &cx[1], &cy[1]);
-    const bool c = parametric_intersect(rho[0], ct[0], st[0], rho[3], ct[3], st[3], &cx[2], &cy[2]);
-    const bool d = parametric_intersect(rho[2], ct[2], st[2], rho[3], ct[3], st[3], &cx[3], &cy[3]);
-    all = a && b && c && d;
-  }
-  for (int i = 0; i < 4; i++) {
-    res->corners[2 * i] = cx[i];
-    res->corners[2 * i + 1] = cy[i];
-  }
-  res->found_all = all ? 1 : 0;
-  res->flags = 0;
-}
-
-// dmz_transform_card's part before the warp: corners -> source points -> float
-// homography -> inverse double matrix (dmz.cpp:446-471, warp.cpp:153-165).
-__global__ void k_homography(int n, int orientation, int options,
-                             dmz_hip_frame_result *__restrict__ results,
-                             DmzWarpMat *__restrict__ mats) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  dmz_hip_frame_result *res = results + f;
-  const bool all = res->found_all != 0;
-  DmzWarpMat wm;
-  wm.valid = all ? 1 : 0;
-  wm.pad_ = 0;
-  for (int i = 0; i < 9; i++) wm.m[i] = 0.;
-  if (all) {
-    int o0, o1, o2, o3;
-    switch (orientation) {
-      case 1: o0 = 1; o1 = 0; o2 = 3; o3 = 2; break;  // portrait: bl, tl, br, tr
-      case 2: o0 = 2; o1 = 3; o2 = 0; o3 = 1; break;  // upside down: tr, br, tl, bl
-      case 4: o0 = 3; o1 = 1; o2 = 2; o3 = 0; break;  // landscape left: br, bl, tr, tl
-      default: o0 = 0; o1 = 2; o2 = 1; o3 = 3; break; // landscape right: tl, tr, bl, br
-    }
-    const int ord[4] = {o0, o1, o2, o3};
-    float sp[8], dp[8], m[9];
-    for (int i = 0; i < 4; i++) {
-      float px = res->corners[2 * ord[i]], py = res->corners[2 * ord[i] + 1];
-      if (options & DMZ_HIP_OPT_TRUNCATE_CORNERS) {
-        px = (float)(int)px;
-        py = (float)(int)py;
-      }
-      sp[2 * i] = px;
-      sp[2 * i + 1] = py;
-    }
-    const float rw = (float)(DMZ_CARD_WIDTH - 1), rh = (float)(DMZ_CARD_HEIGHT - 1);
-    dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f + rw; dp[3] = 0.0f;
-    dp[4] = 0.0f; dp[5] = 0.0f + rh; dp[6] = 0.0f + rw; dp[7] = 0.0f + rh;
-    calc_persp_transform(sp, dp, m);
-    invert3x3(m, &wm);
-    res->flags = (res->flags & ~DMZ_HIP_FLAG_WARPED) | DMZ_HIP_FLAG_WARPED;
-  } else {
-    res->flags = res->flags & ~DMZ_HIP_FLAG_WARPED;
-  }
-  mats[f] = wm;
-}
-
-__global__ void k_persp(int n, const float *__restrict__ src_pts, const float *__restrict__ dst_pts,
-                        float *__restrict__ m9) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  float sp[8], dp[8], m[9];
-  for (int i = 0; i < 8; i++) {
-    sp[i] = src_pts[f * 8 + i];
-    dp[i] = dst_pts[f * 8 + i];
-  }
-  calc_persp_transform(sp, dp, m);
-  for (int i = 0; i < 9; i++) m9[f * 9 + i] = m[i];
-}
-
-__global__ void k_mats_from_float(int n, const float *__restrict__ m9, DmzWarpMat *__restrict__ mats) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  float m[9];
-  for (int i = 0; i < 9; i++) m[i] = m9[f * 9 + i];
-  DmzWarpMat wm;
-  wm.valid = 1;
-  wm.pad_ = 0;
-  invert3x3(m, &wm);
-  mats[f] = wm;
-}
-
-// ---------------------------------------------------------------------------
-// Warp: one workgroup per 64 x 16 destination tile (OpenCV's block, so that the
-// fp64 association X0 + M0*x1 has the same block origin), 4 px per thread,
-// 32-bit stores.  Blocks are renumbered so that all tiles of a frame run on one
-// XCD (block b is dispatched to XCD b % 8) and share its L2 for the gathers.
-// ---------------------------------------------------------------------------
-constexpr int kTilesX = (DMZ_CARD_WIDTH + 63) / 64;    // 7
-constexpr int kTilesY = (DMZ_CARD_HEIGHT + 15) / 16;   // 17
-constexpr int kTiles = kTilesX * kTilesY;              // 119
+constexpr int TW = 64, TH = 32;
+constexpr int kTilesX = (DMZ_CARD_WIDTH + TW - 1) / TW;   // 7
+constexpr int kTilesY = (DMZ_CARD_HEIGHT + TH - 1) / TH;  // 9
+constexpr int kTiles = kTilesX * kTilesY;                 // 63
+constexpr int LW = 112;  // LDS window: bytes per row (28 dwords)
+constexpr int LH = 64;   // rows
 
 __device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// direct global bilinear tap fetch with BORDER_CONSTANT 0 (fallback path)
+__device__ __forceinline__ void taps_global(const uint8_t *__restrict__ src, int row_stride, int sw,
+                                            int sh, int sx, int sy, int &v0, int &v1, int &v2, int &v3) {
+  if ((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1)) {
+    const uint8_t *p = src + (size_t)sy * row_stride + sx;
+    v0 = p[0]; v1 = p[1]; v2 = p[row_stride]; v3 = p[row_stride + 1];
+  } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+    v0 = v1 = v2 = v3 = 0;
+  } else {
+    const bool x0ok = sx >= 0 && sx < sw, x1ok = sx + 1 >= 0 && sx + 1 < sw;
+    const bool y0ok = sy >= 0 && sy < sh, y1ok = sy + 1 >= 0 && sy + 1 < sh;
+    v0 = (x0ok && y0ok) ? src[(size_t)sy * row_stride + sx] : 0;
+    v1 = (x1ok && y0ok) ? src[(size_t)sy * row_stride + sx + 1] : 0;
+    v2 = (x0ok && y1ok) ? src[(size_t)(sy + 1) * row_stride + sx] : 0;
+    v3 = (x1ok && y1ok) ? src[(size_t)(sy + 1) * row_stride + sx + 1] : 0;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes, size_t frame_stride,
                                                int row_stride, int sw, int sh, int n, int n_pad,
                                                const DmzWarpMat *__restrict__ mats,
                                                uint8_t *__restrict__ cards, size_t card_stride) {
+  __shared__ __attribute__((aligned(16))) unsigned char win[LW * LH + 8];
+  __shared__ int s_box[4];  // min sx, max sx, min sy, max sy
+
   // XCD-aware renumbering: logical id = xcd * (blocks/8) + k
   const unsigned int nblk = (unsigned int)n_pad * kTiles;
   const unsigned int b = blockIdx.x;
@@ -275,81 +66,129 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   const int tile = (int)(logical - (unsigned int)frame * kTiles);
   if (frame >= n) return;
   const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
-  const int x = tx * 64;                          // block origin
-  const int y = ty * 16 + (threadIdx.x >> 4);     // row handled by this thread
-  const int xq = (threadIdx.x & 15) * 4;          // first of 4 pixels, relative to x
-  if (y >= DMZ_CARD_HEIGHT || x + xq >= DMZ_CARD_WIDTH) return;
-  uint8_t *drow = cards + (size_t)frame * card_stride + (size_t)y * DMZ_CARD_WIDTH + x + xq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int x = tx * TW;                  // OpenCV block origin in x
+  const int xq = (tid & 15) * 4;          // first of 4 pixels, relative to x
+  const int yr = ty * TH + (tid >> 4);    // rows yr and yr + 16
+  uint8_t *dbase = cards + (size_t)frame * card_stride;
   const DmzWarpMat &wm = mats[frame];
+  const bool col_ok = x + xq < DMZ_CARD_WIDTH;  // 428 % 4 == 0: a 4-pixel group is all in or all out
   if (!wm.valid) {
-    *(uint32_t *)drow = 0u;
+    if (col_ok) {
+      if (yr < DMZ_CARD_HEIGHT) *(uint32_t *)(dbase + (size_t)yr * DMZ_CARD_WIDTH + x + xq) = 0u;
+      if (yr + 16 < DMZ_CARD_HEIGHT) *(uint32_t *)(dbase + (size_t)(yr + 16) * DMZ_CARD_WIDTH + x + xq) = 0u;
+    }
     return;
   }
   const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
-  const double X0 = M0 * x + M1 * y + M2;
-  const double Y0 = M3 * x + M4 * y + M5;
-  const double W0 = M6 * x + M7 * y + M8;
-  const uint8_t *src = planes + (size_t)frame * frame_stride;
-  uint32_t packed = 0;
+
+  // ---- fixed-point source coordinates of this thread's 2 x 4 pixels ----
+  int X[2][4], Y[2][4];
+  int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int x1 = xq + k;
-    double W = W0 + M6 * x1;
-    W = W ? 32. / W : 0;
-    double fX = (X0 + M0 * x1) * W;
-    double fY = (Y0 + M3 * x1) * W;
-    fX = fX < 2147483647.0 ? fX : 2147483647.0;
-    fX = fX > -2147483648.0 ? fX : -2147483648.0;
-    fY = fY < 2147483647.0 ? fY : 2147483647.0;
-    fY = fY > -2147483648.0 ? fY : -2147483648.0;
-    const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
-    const int sx = sat16(X >> 5), sy = sat16(Y >> 5);
-    const int ax = X & 31, ay = Y & 31;
-    const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
-    int v0, v1, v2, v3;
-    if ((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1)) {
-      const uint8_t *p = src + (size_t)sy * row_stride + sx;
-      v0 = p[0]; v1 = p[1]; v2 = p[row_stride]; v3 = p[row_stride + 1];
-    } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
-      v0 = v1 = v2 = v3 = 0;
-    } else {
-      const bool x0ok = sx >= 0 && sx < sw, x1ok = sx + 1 >= 0 && sx + 1 < sw;
-      const bool y0ok = sy >= 0 && sy < sh, y1ok = sy + 1 >= 0 && sy + 1 < sh;
-      v0 = (x0ok && y0ok) ? src[(size_t)sy * row_stride + sx] : 0;
-      v1 = (x1ok && y0ok) ? src[(size_t)sy * row_stride + sx + 1] : 0;
-      v2 = (x0ok && y1ok) ? src[(size_t)(sy + 1) * row_stride + sx] : 0;
-      v3 = (x1ok && y1ok) ? src[(size_t)(sy + 1) * row_stride + sx + 1] : 0;
+  for (int h = 0; h < 2; h++) {
+    const int y = yr + 16 * h;
+    const double X0 = M0 * x + M1 * y + M2;
+    const double Y0 = M3 * x + M4 * y + M5;
+    const double W0 = M6 * x + M7 * y + M8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int x1 = xq + k;
+      double W = W0 + M6 * x1;
+      W = W ? 32. / W : 0;
+      double fX = (X0 + M0 * x1) * W;
+      double fY = (Y0 + M3 * x1) * W;
+      // OpenCV clamps to [INT_MIN, INT_MAX] before cvRound; v_cvt_i32_f64 saturates the same way
+      X[h][k] = __double2int_rn(fX);
+      Y[h][k] = __double2int_rn(fY);
+      if (col_ok && y < DMZ_CARD_HEIGHT) {
+        const int sx = sat16(X[h][k] >> 5), sy = sat16(Y[h][k] >> 5);
+        bx0 = imin(bx0, sx); bx1 = imax(bx1, sx);
+        by0 = imin(by0, sy); by1 = imax(by1, sy);
+      }
     }
-    // (sum p*w*32 + 2^14) >> 15  ==  (sum p*w + 512) >> 10 with w = 5-bit products
-    int v = (v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10;
-    v = v > 255 ? 255 : v;
-    packed |= (uint32_t)v << (8 * k);
   }
-  *(uint32_t *)drow = packed;
+  // ---- tile bounding box ----
+  if (tid == 0) { s_box[0] = 1 << 30; s_box[1] = -(1 << 30); s_box[2] = 1 << 30; s_box[3] = -(1 << 30); }
+  for (int o = 32; o > 0; o >>= 1) {
+    bx0 = imin(bx0, __shfl_xor(bx0, o, 64)); bx1 = imax(bx1, __shfl_xor(bx1, o, 64));
+    by0 = imin(by0, __shfl_xor(by0, o, 64)); by1 = imax(by1, __shfl_xor(by1, o, 64));
+  }
+  __syncthreads();
+  if (lane == 0) {
+    atomicMin(&s_box[0], bx0); atomicMax(&s_box[1], bx1);
+    atomicMin(&s_box[2], by0); atomicMax(&s_box[3], by1);
+  }
+  __syncthreads();
+  const int wx0 = s_box[0] & ~3;          // window origin, 4-aligned in x
+  const int wy0 = s_box[2];
+  const int wcols = s_box[1] + 2 - wx0;   // + the right bilinear tap
+  const int wrows = s_box[3] + 2 - wy0;
+  const uint8_t *src = planes + (size_t)frame * frame_stride;
+  const bool staged = wcols <= LW && wrows <= LH;
+
+  if (staged) {
+    // ---- stage the window: aligned dwords where the whole word is inside the image ----
+    const int wdw = (wcols + 3) >> 2;
+    const bool aligned = ((((uintptr_t)src) | (uintptr_t)row_stride) & 3) == 0;
+    for (int i = tid; i < wdw * wrows; i += 256) {
+      const int j = i / wdw, q = i - j * wdw;
+      const int gy = wy0 + j, gx = wx0 + 4 * q;
+      uint32_t v = 0u;
+      if (gy >= 0 && gy < sh) {
+        const uint8_t *g = src + (size_t)gy * row_stride + gx;
+        if (aligned && gx >= 0 && gx + 3 < sw) {
+          v = *(const uint32_t *)g;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (gx + k >= 0 && gx + k < sw) v |= (uint32_t)g[k] << (8 * k);
+        }
+      }
+      *(uint32_t *)(win + j * LW + 4 * q) = v;
+    }
+    __syncthreads();
+  }
+
+  // ---- bilinear blend, 4 px -> one 32-bit store ----
+  // (sum p*w*32 + 2^14) >> 15 == (sum p*wx*wy + 512) >> 10 with 5-bit fractions; the two
+  // horizontal taps of a row are one v_dot4_u32_u8 on an aligned-dword pair (v_alignbyte).
+  const uint32_t *win32 = (const uint32_t *)win;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int y = yr + 16 * h;
+    if (!col_ok || y >= DMZ_CARD_HEIGHT) continue;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int Xv = X[h][k], Yv = Y[h][k];
+      const int sx = sat16(Xv >> 5), sy = sat16(Yv >> 5);
+      const int ax = Xv & 31, ay = Yv & 31;
+      int v;
+      if (staged) {
+        const int o = (sy - wy0) * LW + (sx - wx0);
+        const int di = o >> 2, sh = o & 3;
+        const uint32_t top = __builtin_amdgcn_alignbyte(win32[di + 1], win32[di], sh);
+        const uint32_t bot = __builtin_amdgcn_alignbyte(win32[di + LW / 4 + 1], win32[di + LW / 4], sh);
+        const uint32_t wx = (uint32_t)(32 - ax) | ((uint32_t)ax << 8);
+        const int t_top = (int)__builtin_amdgcn_udot4(top, wx, 0u, false);
+        const int t_bot = (int)__builtin_amdgcn_udot4(bot, wx, 0u, false);
+        v = (t_top * (32 - ay) + t_bot * ay + 512) >> 10;
+      } else {
+        int v0, v1, v2, v3;
+        taps_global(src, row_stride, sw, sh, sx, sy, v0, v1, v2, v3);
+        const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
+        v = (v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10;
+      }
+      v = v > 255 ? 255 : v;
+      packed |= (uint32_t)v << (8 * k);
+    }
+    *(uint32_t *)(dbase + (size_t)y * DMZ_CARD_WIDTH + x + xq) = packed;
+  }
 }
 
 }  // namespace
-
-void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params, const DmzBoxHit *hits,
-                         int nplanes, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_geometry, dim3((n + 63) / 64), dim3(64), 0, s, n, params, hits, nplanes,
-                     results);
-}
-
-void dmz_launch_homography(hipStream_t s, int n, int orientation, int options,
-                           dmz_hip_frame_result *results, DmzWarpMat *mats) {
-  hipLaunchKernelGGL(k_homography, dim3((n + 63) / 64), dim3(64), 0, s, n, orientation, options,
-                     results, mats);
-}
-
-void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9) {
-  hipLaunchKernelGGL(k_persp, dim3((n + 63) / 64), dim3(64), 0, s, n, src_pts, dst_pts, m9);
-}
-
-void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMat *mats) {
-  hipLaunchKernelGGL(k_mats_from_float, dim3((n + 63) / 64), dim3(64), 0, s, n, m9, mats);
-}
 
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, const DmzWarpMat *mats, uint8_t *cards,
