@@ -1,0 +1,176 @@
+// dmz.h -- HIP_DMZ flavour of the reference's public headers for the per-frame scan
+// path: dmz.h:13-101, dmz_olm.h:17-104, scan/scan.h:17-72, scan/frame.h:14-28,
+// scan/n_vseg.h:14-21, scan/n_hseg.h:13-19, cv/warp.h:20-25, mz.h:19-25.
+//
+// Same names, argument meaning, ownership and (lack of) error codes as the reference, so
+// that an SDK call site relinks against libdmz_host.so unchanged; every function is a
+// batch-of-1 wrapper over the C-ABI of include/dmz_hip.h.  `dmz_context.mz` holds the
+// dmz_hip_context exactly where the Android flavour keeps its GLES warp context
+// (mz_android.cpp:233-240).  Differences, all forced by dropping Eigen/OpenCV types:
+//   * NumberScores / NumberPredictions are plain arrays (reference: Eigen matrices,
+//     n_categorize.h:14, scan.h:17);
+//   * FrameScanResult has no expiry/name group vectors (expiry is not built yet);
+//   * IplImage is declared here with OpenCV 2.4's field layout (types_c.h:462-507) unless
+//     OpenCV's own header was included first.
+// There is NO CPU fallback: without a GPU dmz_context_create() returns NULL and the
+// per-frame calls report "not found"/"not usable" after logging once to stderr.
+#ifndef DMZ_HIP_HOST_DMZ_H
+#define DMZ_HIP_HOST_DMZ_H
+
+#include <stdint.h>
+
+#ifndef __OPENCV_CORE_TYPES_H__
+#define IPL_DEPTH_8U 8
+typedef struct _IplROI {
+  int coi, xOffset, yOffset, width, height;
+} IplROI;
+typedef struct _IplImage {
+  int nSize, ID, nChannels, alphaChannel, depth;
+  char colorModel[4], channelSeq[4];
+  int dataOrder, origin, align, width, height;
+  struct _IplROI *roi;
+  struct _IplImage *maskROI;
+  void *imageId;
+  struct _IplTileInfo *tileInfo;
+  int imageSize;
+  char *imageData;
+  int widthStep;
+  int BorderMode[4], BorderConst[4];
+  char *imageDataOrigin;
+} IplImage;
+#endif
+
+#define kCreditCardTargetWidth 428
+#define kCreditCardTargetHeight 270
+#define kNumberWidth 19
+#define kNumberHeight 27
+
+// ---- dmz_olm.h:17-62 ----
+typedef uint8_t FrameOrientation;
+enum {
+  FrameOrientationPortrait = 1,
+  FrameOrientationPortraitUpsideDown = 2,
+  FrameOrientationLandscapeRight = 3,
+  FrameOrientationLandscapeLeft = 4
+};
+typedef struct { float x, y; } dmz_point;
+typedef struct { float x, y, w, h; } dmz_rect;
+typedef struct { dmz_point top_left, bottom_left, top_right, bottom_right; } dmz_corner_points;
+typedef uint8_t CardType;
+enum {
+  CardTypeUnrecognized = 0, CardTypeAmbiguous, CardTypeAmex, CardTypeJCB, CardTypeVisa,
+  CardTypeMastercard, CardTypeDiscover, CardTypeMaestro
+};
+typedef struct {
+  CardType card_type;
+  int number_length, prefix_length;
+  long min_prefix, max_prefix;
+} dmz_card_info;
+
+// ---- dmz.h:17-37 ----
+typedef struct { void *mz; } dmz_context;
+typedef struct { float rho, theta; } ParametricLine;
+typedef struct { int found; ParametricLine location; } dmz_found_edge;
+typedef struct { dmz_found_edge top, left, bottom, right; } dmz_edges;
+
+// ---- scan/n_vseg.h:14-21, scan/n_hseg.h:13-19 ----
+typedef uint8_t NumberPatternType;
+typedef struct {
+  float score;
+  uint16_t y_offset;
+  NumberPatternType pattern_type;
+  uint8_t number_pattern[19];
+  uint8_t number_pattern_length;
+  uint8_t number_length;
+} NVerticalSegmentation;
+typedef struct {
+  uint8_t n_offsets;
+  uint16_t offsets[16];
+  float score;
+  float number_width;
+  uint16_t pattern_offset;
+} NHorizontalSegmentation;
+typedef struct { float v[16][10]; } NumberScores;        // row-major, n_categorize.h:14
+typedef struct { long v[16]; } NumberPredictions;        // scan.h:17
+
+// ---- scan/frame.h:14-28 ----
+typedef struct {
+  float focus_score;
+  NumberScores scores;
+  NHorizontalSegmentation hseg;
+  NVerticalSegmentation vseg;
+  bool usable;
+  bool upside_down;
+  bool flipped;
+  float brightness_score;
+  uint16_t iso_speed;
+  float shutter_speed;
+  bool torch_is_on;
+} FrameScanResult;
+
+// ---- scan/scan.h:19-48 ----
+typedef struct {
+  bool complete;
+  NumberPredictions predictions;
+  NHorizontalSegmentation hseg;
+  NVerticalSegmentation vseg;
+  uint8_t n_numbers;
+  int expiry_month, expiry_year;
+} ScannerResult;
+typedef struct ScannerState {
+  uint16_t count15, count16;
+  NumberScores aggregated15, aggregated16;
+  ScannerResult successfulCardNumberResult;
+  NHorizontalSegmentation mostRecentUsableHSeg;
+  NVerticalSegmentation mostRecentUsableVSeg;
+  unsigned long timeOfCardNumberCompletionInMilliseconds;
+  bool scan_expiry;
+  int expiry_month, expiry_year;
+  dmz_context *dmz;  // HIP flavour: the context the frames are scanned on (NULL = process default)
+} ScannerState;
+
+// life cycle (dmz.h:48-57, mz.h:19-25, processor_support.h pattern)
+dmz_context *dmz_context_create(void);
+void dmz_context_destroy(dmz_context *dmz);
+void dmz_prepare_for_backgrounding(dmz_context *dmz);
+void *mz_create(void);
+void mz_destroy(void *mz);
+void mz_prepare_for_backgrounding(void *mz);
+int dmz_has_hip_runtime(void);
+
+// detection / transformation (dmz.h:78-96, cv/warp.h:20-25)
+bool dmz_found_all_edges(dmz_edges found_edges);
+bool dmz_detect_edges(IplImage *y_sample, IplImage *cb_sample, IplImage *cr_sample,
+                      FrameOrientation orientation, dmz_edges *found_edges,
+                      dmz_corner_points *corner_points);
+void dmz_transform_card(dmz_context *dmz, IplImage *sample, dmz_corner_points corner_points,
+                        FrameOrientation orientation, bool upsample, IplImage **transformed);
+void llcv_calc_persp_transform(float *matrixData, int matrixDataSize, bool rowMajor,
+                               const dmz_point sourcePoints[], const dmz_point destPoints[]);
+void llcv_unwarp(dmz_context *dmz, IplImage *input, const dmz_point source_points[4],
+                 const dmz_rect to_rect, IplImage *output);
+bool llcv_warp_auto_upsamples(void);
+
+// scanning (scan/scan.h:51-72)
+void scanner_initialize(ScannerState *state);
+void scanner_reset(ScannerState *state);
+void scanner_add_frame(ScannerState *state, IplImage *y, FrameScanResult *result);
+void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_expiry,
+                                   FrameScanResult *result);
+void scanner_result(ScannerState *state, ScannerResult *result);
+void scanner_destroy(ScannerState *state);
+
+// dmz_olm.h:70-104
+dmz_point dmz_create_point(float x, float y);
+dmz_rect dmz_create_rect(float x, float y, float w, float h);
+void dmz_rect_get_points(dmz_rect rect, dmz_point points[4]);
+bool dmz_passes_luhn_checksum(uint8_t *number_array, uint8_t number_length);
+dmz_card_info dmz_card_info_for_prefix_and_length(uint8_t *number_array, uint8_t number_length,
+                                                  bool allow_incomplete_number);
+
+// image helpers standing in for cvCreateImage / cvReleaseImage on 8-bit images
+// (dmz_transform_card allocates *transformed when it is NULL; the caller frees it)
+IplImage *dmz_create_image_8u(int width, int height, int channels);
+void dmz_release_image(IplImage **image);
+
+#endif  // DMZ_HIP_HOST_DMZ_H

@@ -1,0 +1,433 @@
+// dmz_host.cpp -- host side of the HIP_DMZ flavour: the reference's per-frame entry
+// points (dmz.cpp:23-32,371-497; cv/warp.cpp:34-169; scan/scan.cpp:22-200;
+// dmz_olm.cpp:12-130; mz.cpp) as batch-of-1 wrappers over the C-ABI of
+// include/dmz_hip.h, plus the session aggregator, which is sequential per session and
+// O(160) flops per frame and therefore stays on the host.
+#include "dmz.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include "../../include/dmz_hip.h"
+
+namespace {
+
+dmz_hip_context *g_default_ctx = nullptr;  // for the entry points that take no dmz_context
+bool g_warned = false;
+
+dmz_hip_context *hip_of(dmz_context *dmz) {
+  if (dmz && dmz->mz) return (dmz_hip_context *)dmz->mz;
+  if (!g_default_ctx) {
+    if (dmz_hip_context_create(0, &g_default_ctx) != DMZ_HIP_OK) {
+      g_default_ctx = nullptr;
+      if (!g_warned) {
+        fprintf(stderr, "dmz (HIP): no usable MI355X context; there is no CPU fallback\n");
+        g_warned = true;
+      }
+    }
+  }
+  return g_default_ctx;
+}
+
+const uint8_t *image_origin(const IplImage *im, int *w, int *h) {
+  const uint8_t *p = (const uint8_t *)im->imageData;
+  *w = im->width;
+  *h = im->height;
+  if (im->roi) {  // cv/image_util.cpp:35-41
+    p += (size_t)im->roi->yOffset * im->widthStep + im->roi->xOffset;
+    *w = im->roi->width;
+    *h = im->roi->height;
+  }
+  return p;
+}
+
+// n_vseg.cpp:26-30 tables
+const uint8_t kNumberLength[3] = {0, 16, 15};
+const uint8_t kPatternLength[3] = {0, 19, 17};
+const uint8_t kPatterns[3][19] = {
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1},
+    {1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0},
+};
+
+void fill_frame_result(const dmz_hip_frame_result &r, FrameScanResult *out) {
+  out->usable = (r.flags & DMZ_HIP_FLAG_USABLE) != 0;
+  out->upside_down = (r.flags & DMZ_HIP_FLAG_UPSIDE_DOWN) != 0;
+  out->vseg.score = r.vseg_score;
+  out->vseg.y_offset = (uint16_t)r.vseg_y_offset;
+  out->vseg.pattern_type = (NumberPatternType)r.pattern_type;
+  memcpy(out->vseg.number_pattern, kPatterns[r.pattern_type], 19);
+  out->vseg.number_pattern_length = kPatternLength[r.pattern_type];
+  out->vseg.number_length = kNumberLength[r.pattern_type];
+  out->hseg.n_offsets = (uint8_t)r.n_offsets;
+  memcpy(out->hseg.offsets, r.offsets, sizeof(r.offsets));
+  out->hseg.score = r.hseg_score;
+  out->hseg.number_width = r.number_width;
+  out->hseg.pattern_offset = (uint16_t)r.pattern_offset;
+  memcpy(out->scores.v, r.scores, sizeof(r.scores));
+}
+
+}  // namespace
+
+// ---- life cycle (dmz.cpp:23-39, mz.h:19-25) ---------------------------------------
+void *mz_create(void) {
+  dmz_hip_context *c = nullptr;
+  return dmz_hip_context_create(0, &c) == DMZ_HIP_OK ? (void *)c : nullptr;
+}
+void mz_destroy(void *mz) { dmz_hip_context_destroy((dmz_hip_context *)mz); }
+void mz_prepare_for_backgrounding(void *mz) {
+  if (mz) dmz_hip_synchronize((dmz_hip_context *)mz);
+}
+int dmz_has_hip_runtime(void) { return dmz_hip_device_count() > 0; }
+
+dmz_context *dmz_context_create(void) {
+  dmz_context *dmz = (dmz_context *)calloc(1, sizeof(dmz_context));
+  if (!dmz) return NULL;
+  dmz->mz = mz_create();
+  if (!dmz->mz) {  // no GPU: fail loudly instead of falling back to a CPU path
+    free(dmz);
+    return NULL;
+  }
+  return dmz;
+}
+void dmz_context_destroy(dmz_context *dmz) {
+  if (!dmz) return;
+  mz_destroy(dmz->mz);
+  free(dmz);
+}
+void dmz_prepare_for_backgrounding(dmz_context *dmz) {
+  if (dmz) mz_prepare_for_backgrounding(dmz->mz);
+}
+
+// ---- dmz_olm.cpp:12-49 -------------------------------------------------------------
+dmz_point dmz_create_point(float x, float y) { dmz_point p; p.x = x; p.y = y; return p; }
+dmz_rect dmz_create_rect(float x, float y, float w, float h) {
+  dmz_rect r; r.x = x; r.y = y; r.w = w; r.h = h; return r;
+}
+void dmz_rect_get_points(dmz_rect rect, dmz_point points[4]) {
+  points[0] = dmz_create_point(rect.x, rect.y);
+  points[1] = dmz_create_point(rect.x + rect.w, rect.y);
+  points[2] = dmz_create_point(rect.x, rect.y + rect.h);
+  points[3] = dmz_create_point(rect.x + rect.w, rect.y + rect.h);
+}
+bool dmz_passes_luhn_checksum(uint8_t *number_array, uint8_t number_length) {
+  int sum = 0;
+  bool doubled = false;  // the rightmost digit is not doubled
+  for (int i = number_length - 1; i >= 0; i--) {
+    const int addend = number_array[i] * (doubled ? 2 : 1);
+    sum += addend % 10 + addend / 10;
+    doubled = !doubled;
+  }
+  return sum % 10 == 0;
+}
+
+// dmz_olm.cpp:51-130: issuer prefix ranges (data) and the single-match rule
+dmz_card_info dmz_card_info_for_prefix_and_length(uint8_t *number_array, uint8_t number_length,
+                                                  bool allow_incomplete_number) {
+  static const dmz_card_info table[] = {
+      {CardTypeMastercard, 16, 4, 2221, 2720}, {CardTypeDiscover, 14, 3, 300, 305},
+      {CardTypeDiscover, 14, 3, 309, 309},     {CardTypeAmex, 15, 2, 34, 34},
+      {CardTypeJCB, 16, 4, 3528, 3589},        {CardTypeDiscover, 14, 2, 36, 36},
+      {CardTypeDiscover, 14, 2, 38, 39},       {CardTypeAmex, 15, 2, 37, 37},
+      {CardTypeVisa, 16, 1, 4, 4},             {CardTypeMaestro, 16, 2, 50, 50},
+      {CardTypeMastercard, 16, 2, 51, 55},     {CardTypeMaestro, 16, 2, 56, 59},
+      {CardTypeDiscover, 16, 4, 6011, 6011},   {CardTypeMaestro, 16, 2, 61, 61},
+      {CardTypeDiscover, 16, 2, 62, 62},       {CardTypeMaestro, 16, 2, 63, 63},
+      {CardTypeDiscover, 16, 3, 644, 649},     {CardTypeDiscover, 16, 2, 65, 65},
+      {CardTypeMaestro, 16, 2, 66, 69},        {CardTypeDiscover, 16, 2, 88, 88},
+  };
+  const dmz_card_info unrecognized = {CardTypeUnrecognized, -1, 1, 9, 9};
+  const dmz_card_info ambiguous = {CardTypeAmbiguous, -1, 1, 9, 9};
+  if (number_length == 0) return unrecognized;
+  dmz_card_info match = unrecognized;
+  int matches = 0;
+  for (size_t t = 0; t < sizeof(table) / sizeof(table[0]); t++) {
+    const dmz_card_info &info = table[t];
+    if (allow_incomplete_number ? number_length > info.number_length
+                                : number_length != info.number_length)
+      continue;
+    int plen = info.prefix_length;
+    long factor = 1;
+    for (; plen > number_length; plen--) factor *= 10;  // compare only the digits we have
+    long prefix = 0;
+    for (int j = 0; j < plen; j++) prefix = prefix * 10 + number_array[j];
+    if (prefix >= info.min_prefix / factor && prefix <= info.max_prefix / factor) {
+      matches++;
+      match = info;
+    }
+  }
+  if (matches == 1) return match;
+  return matches > 1 ? ambiguous : unrecognized;
+}
+
+// ---- images --------------------------------------------------------------------------
+IplImage *dmz_create_image_8u(int width, int height, int channels) {
+  IplImage *im = (IplImage *)calloc(1, sizeof(IplImage));
+  if (!im) return NULL;
+  im->nSize = (int)sizeof(IplImage);
+  im->nChannels = channels;
+  im->depth = IPL_DEPTH_8U;
+  im->align = 4;
+  im->width = width;
+  im->height = height;
+  im->widthStep = (width * channels + 3) & ~3;  // cvCreateImage pads rows to 4 bytes
+  im->imageSize = im->widthStep * height;
+  im->imageData = im->imageDataOrigin = (char *)calloc(1, (size_t)im->imageSize);
+  if (!im->imageData) { free(im); return NULL; }
+  return im;
+}
+void dmz_release_image(IplImage **image) {
+  if (image && *image) {
+    free((*image)->imageDataOrigin);
+    free(*image);
+    *image = NULL;
+  }
+}
+
+// ---- detection (dmz.cpp:273-439) -----------------------------------------------------
+bool dmz_found_all_edges(dmz_edges e) { return e.top.found && e.bottom.found && e.left.found && e.right.found; }
+
+bool dmz_detect_edges(IplImage *y_sample, IplImage *cb_sample, IplImage *cr_sample,
+                      FrameOrientation orientation, dmz_edges *found_edges,
+                      dmz_corner_points *corner_points) {
+  if (!y_sample || !found_edges || !corner_points) return false;  // the reference asserts
+  memset(found_edges, 0, sizeof(*found_edges));
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx) return false;
+  int w, h, cw = 0, ch = 0;
+  const uint8_t *y = image_origin(y_sample, &w, &h);
+  const uint8_t *cb = NULL, *cr = NULL;
+  size_t cstride = 0;
+  int crow = 0;
+  if (cb_sample && cr_sample) {
+    cb = image_origin(cb_sample, &cw, &ch);
+    cr = image_origin(cr_sample, &cw, &ch);
+    if (cw != w / 2 || ch != h / 2 || cb_sample->widthStep != cr_sample->widthStep) cb = cr = NULL;
+    else { crow = cb_sample->widthStep; cstride = (size_t)crow * ch; }
+  }
+  dmz_hip_frame_result r;
+  memset(&r, 0, sizeof(r));
+  if (dmz_hip_detect_batch(ctx, y, (size_t)y_sample->widthStep * h, y_sample->widthStep, w, h, cb, cr,
+                           cstride, crow, 1, orientation, &r) != DMZ_HIP_OK) {
+    fprintf(stderr, "dmz (HIP): detect failed: %s\n", dmz_hip_last_error(ctx));
+    return false;
+  }
+  dmz_found_edge *e[4] = {&found_edges->top, &found_edges->left, &found_edges->bottom, &found_edges->right};
+  for (int i = 0; i < 4; i++) {
+    e[i]->found = r.found[i];
+    e[i]->location.rho = r.rho[i];
+    e[i]->location.theta = r.theta[i];
+  }
+  if (r.found_all) {
+    corner_points->top_left = dmz_create_point(r.corners[0], r.corners[1]);
+    corner_points->bottom_left = dmz_create_point(r.corners[2], r.corners[3]);
+    corner_points->top_right = dmz_create_point(r.corners[4], r.corners[5]);
+    corner_points->bottom_right = dmz_create_point(r.corners[6], r.corners[7]);
+  }
+  return r.found_all != 0;
+}
+
+// ---- transformation (dmz.cpp:443-497, cv/warp.cpp:26-169) ----------------------------
+bool llcv_warp_auto_upsamples(void) { return false; }  // warp.cpp:26-32, non-iOS
+
+void llcv_calc_persp_transform(float *matrixData, int matrixDataSize, bool rowMajor,
+                               const dmz_point sourcePoints[], const dmz_point destPoints[]) {
+  for (int i = 0; i < matrixDataSize; i++) matrixData[i] = 0.0f;
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx) return;
+  float s[8], d[8], m[9];
+  for (int i = 0; i < 4; i++) {
+    s[2 * i] = sourcePoints[i].x; s[2 * i + 1] = sourcePoints[i].y;
+    d[2 * i] = destPoints[i].x; d[2 * i + 1] = destPoints[i].y;
+  }
+  if (dmz_hip_calc_persp_transform(ctx, s, d, m) != DMZ_HIP_OK) return;
+  // warp.cpp:84-121: 3x3, or the 4x4 layout with the projective row/column moved out
+  const int size = matrixDataSize >= 16 ? 4 : 3;
+  float p[4][4];
+  memset(p, 0, sizeof(p));
+  const int o = size - 3;
+  p[0][0] = m[0]; p[0][1] = m[1]; p[1][0] = m[3]; p[1][1] = m[4]; p[2][2] = 1.0f;
+  p[0][2 + o] = m[2]; p[1][2 + o] = m[5]; p[2 + o][0] = m[6]; p[2 + o][1] = m[7]; p[2 + o][2 + o] = 1.0f;
+  for (int c = 0; c < size; c++)
+    for (int r = 0; r < size; r++) {
+      const int index = rowMajor ? (c + r * size) : (r + c * size);
+      if (index < matrixDataSize) matrixData[index] = p[r][c];
+    }
+}
+
+void llcv_unwarp(dmz_context *dmz, IplImage *input, const dmz_point source_points[4],
+                 const dmz_rect to_rect, IplImage *output) {
+  dmz_hip_context *ctx = hip_of(dmz);
+  if (!ctx || !input || !output || !output->imageData) return;
+  if (input->nChannels != 1 || output->nChannels != 1 || output->width != kCreditCardTargetWidth ||
+      output->height != kCreditCardTargetHeight || output->widthStep != kCreditCardTargetWidth) {
+    fprintf(stderr, "dmz (HIP): llcv_unwarp handles 1-channel 428x270 outputs only\n");
+    return;
+  }
+  dmz_point dest[4];
+  dmz_rect_get_points(to_rect, dest);
+  float m[9];
+  llcv_calc_persp_transform(m, 9, true, source_points, dest);
+  int w, h;
+  const uint8_t *p = image_origin(input, &w, &h);
+  if (dmz_hip_warp_perspective_batch(ctx, p, (size_t)input->widthStep * h, input->widthStep, w, h, 1, m,
+                                     (uint8_t *)output->imageData,
+                                     (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight) != DMZ_HIP_OK)
+    fprintf(stderr, "dmz (HIP): warp failed: %s\n", dmz_hip_last_error(ctx));
+}
+
+void dmz_transform_card(dmz_context *dmz, IplImage *sample, dmz_corner_points corner_points,
+                        FrameOrientation orientation, bool upsample, IplImage **transformed) {
+  dmz_point src[4];
+  switch (orientation) {  // dmz.cpp:446-471
+    case FrameOrientationPortrait:
+      src[0] = corner_points.bottom_left; src[1] = corner_points.top_left;
+      src[2] = corner_points.bottom_right; src[3] = corner_points.top_right;
+      break;
+    case FrameOrientationLandscapeLeft:
+      src[0] = corner_points.bottom_right; src[1] = corner_points.bottom_left;
+      src[2] = corner_points.top_right; src[3] = corner_points.top_left;
+      break;
+    case FrameOrientationPortraitUpsideDown:
+      src[0] = corner_points.top_right; src[1] = corner_points.bottom_right;
+      src[2] = corner_points.top_left; src[3] = corner_points.bottom_left;
+      break;
+    default:  // FrameOrientationLandscapeRight, "the canonical one"
+      src[0] = corner_points.top_left; src[1] = corner_points.top_right;
+      src[2] = corner_points.bottom_left; src[3] = corner_points.bottom_right;
+      break;
+  }
+  if (upsample && !llcv_warp_auto_upsamples())
+    for (int i = 0; i < 4; i++) { src[i].x /= 2.0f; src[i].y /= 2.0f; }
+  const dmz_rect dst = dmz_create_rect(0, 0, kCreditCardTargetWidth - 1, kCreditCardTargetHeight - 1);
+  if (*transformed == NULL)
+    *transformed = dmz_create_image_8u(kCreditCardTargetWidth, kCreditCardTargetHeight, sample->nChannels);
+  llcv_unwarp(dmz, sample, src, dst, *transformed);
+}
+
+// ---- session aggregator (scan/scan.cpp:22-200) ---------------------------------------
+#define kDecayFactor 0.8f
+#define kMinStability 0.7f
+#define EXTRA_TIME_FOR_EXPIRY_IN_MICROSECONDS 1000
+
+void scanner_initialize(ScannerState *state) {
+  state->dmz = NULL;
+  scanner_reset(state);
+}
+
+void scanner_reset(ScannerState *state) {
+  state->count15 = state->count16 = 0;
+  memset(&state->aggregated15, 0, sizeof(NumberScores));
+  memset(&state->aggregated16, 0, sizeof(NumberScores));
+  state->timeOfCardNumberCompletionInMilliseconds = 0;
+  state->scan_expiry = false;
+  state->expiry_month = state->expiry_year = 0;
+}
+
+void scanner_add_frame(ScannerState *state, IplImage *y, FrameScanResult *result) {
+  scanner_add_frame_with_expiry(state, y, false, result);
+}
+
+void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_expiry,
+                                   FrameScanResult *result) {
+  (void)scan_expiry;  // the expiry path is not built yet (DESIGN.md "out of scope")
+  const bool need_number = state->timeOfCardNumberCompletionInMilliseconds == 0;
+  result->usable = false;
+  result->upside_down = false;
+  dmz_hip_context *ctx = hip_of(state->dmz);
+  if (!ctx || !y || y->roi || y->width != kCreditCardTargetWidth || y->height != kCreditCardTargetHeight ||
+      y->nChannels != 1)
+    return;  // frame.cpp:25-29 asserts these
+  // scan_card_image (frame.cpp:24-81) on the device; rows must be 428 bytes apart
+  const uint8_t *cards = (const uint8_t *)y->imageData;
+  uint8_t *packed = NULL;
+  if (y->widthStep != kCreditCardTargetWidth) {
+    packed = (uint8_t *)malloc((size_t)kCreditCardTargetWidth * kCreditCardTargetHeight);
+    for (int r = 0; r < kCreditCardTargetHeight; r++)
+      memcpy(packed + (size_t)r * kCreditCardTargetWidth, y->imageData + (size_t)r * y->widthStep, kCreditCardTargetWidth);
+    cards = packed;
+  }
+  dmz_hip_frame_result r;
+  memset(&r, 0, sizeof(r));
+  const int rc = dmz_hip_scan_cards_batch(ctx, cards, (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight, 1, 0, &r);
+  free(packed);
+  if (rc != DMZ_HIP_OK) {
+    fprintf(stderr, "dmz (HIP): scan failed: %s\n", dmz_hip_last_error(ctx));
+    return;
+  }
+  fill_frame_result(r, result);
+  if (result->upside_down || !result->usable) return;  // scan.cpp:51-60
+  if (need_number) {                                   // scan.cpp:69-85
+    state->mostRecentUsableHSeg = result->hseg;
+    state->mostRecentUsableVSeg = result->vseg;
+    NumberScores *agg = result->hseg.n_offsets == 15 ? &state->aggregated15
+                      : result->hseg.n_offsets == 16 ? &state->aggregated16 : NULL;
+    if (agg) {
+      for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 10; k++) {
+          agg->v[i][k] = agg->v[i][k] * kDecayFactor;
+          agg->v[i][k] = agg->v[i][k] + result->scores.v[i][k] * (1 - kDecayFactor);
+        }
+      if (result->hseg.n_offsets == 15) state->count15++;
+      else state->count16++;
+    }
+  }
+}
+
+void scanner_result(ScannerState *state, ScannerResult *result) {
+  result->complete = false;
+  if (state->timeOfCardNumberCompletionInMilliseconds > 0) {
+    *result = state->successfulCardNumberResult;
+  } else {
+    const uint16_t max_count = state->count15 > state->count16 ? state->count15 : state->count16;
+    const uint16_t min_count = state->count15 > state->count16 ? state->count16 : state->count15;
+    if (max_count - min_count < 3) return;   // at least a three frame lead (scan.cpp:103-105)
+    if (min_count * 2 > max_count) return;   // a significant 15-vs-16 opinion (scan.cpp:108-110)
+    result->hseg = state->mostRecentUsableHSeg;
+    result->vseg = state->mostRecentUsableVSeg;
+    const NumberScores *agg;
+    if (state->count15 > state->count16) { result->n_numbers = 15; agg = &state->aggregated15; }
+    else { result->n_numbers = 16; agg = &state->aggregated16; }
+    uint8_t digits[16];
+    for (int i = 0; i < result->n_numbers; i++) {
+      int best = 0;  // Eigen maxCoeff: first maximum
+      for (int k = 1; k < 10; k++)
+        if (agg->v[i][k] > agg->v[i][best]) best = k;
+      // Eigen 10-element redux tree
+      const float *p = agg->v[i];
+      const float sum = ((p[0] + p[1]) + (p[2] + (p[3] + p[4]))) + ((p[5] + p[6]) + (p[7] + (p[8] + p[9])));
+      result->predictions.v[i] = best;
+      digits[i] = (uint8_t)best;
+      if (agg->v[i][best] / sum < kMinStability) return;  // scan.cpp:143-146
+    }
+    const CardType type = dmz_card_info_for_prefix_and_length(digits, result->n_numbers, false).card_type;
+    if (type != CardTypeAmbiguous && type != CardTypeUnrecognized &&
+        dmz_passes_luhn_checksum(digits, result->n_numbers)) {
+      struct timeval tv;
+      gettimeofday(&tv, NULL);
+      state->timeOfCardNumberCompletionInMilliseconds = (long)((tv.tv_sec * 1000) + (tv.tv_usec / 1000));
+      state->successfulCardNumberResult = *result;
+    }
+  }
+  if (state->timeOfCardNumberCompletionInMilliseconds > 0) {
+    if (state->scan_expiry) {  // only set once the expiry path exists (scan.cpp:61-67)
+      struct timeval tv;
+      gettimeofday(&tv, NULL);
+      const long now = (long)((tv.tv_sec * 1000) + (tv.tv_usec / 1000));
+      if ((state->expiry_month > 0 && state->expiry_year > 0) ||
+          now - (long)state->timeOfCardNumberCompletionInMilliseconds > EXTRA_TIME_FOR_EXPIRY_IN_MICROSECONDS) {
+        result->expiry_month = state->expiry_month;
+        result->expiry_year = state->expiry_year;
+        result->complete = true;
+      }
+    } else {
+      result->expiry_month = 0;
+      result->expiry_year = 0;
+      result->complete = true;
+    }
+  }
+}
+
+void scanner_destroy(ScannerState *state) { (void)state; }

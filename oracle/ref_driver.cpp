@@ -131,3 +131,9 @@ REF_API void ref_best_n_hseg_constrained(float *grad_sums, int pattern_type, flo
 REF_API int ref_passes_luhn(uint8_t *digits, int n) {
   return dmz_passes_luhn_checksum(digits, (uint8_t)n) ? 1 : 0;
 }
+
+REF_API int ref_card_type(uint8_t *digits, int n, int allow_incomplete, int *number_length) {
+  dmz_card_info info = dmz_card_info_for_prefix_and_length(digits, (uint8_t)n, allow_incomplete != 0);
+  *number_length = info.number_length;
+  return info.card_type;
+}

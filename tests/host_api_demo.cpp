@@ -1,0 +1,67 @@
+// Drives the reference-style C++ entry points (card.io-dmz_amd/host/dmz.h) the way an SDK
+// call site would: detect -> transform -> scanner_add_frame x N -> scanner_result.
+// usage: host_api_demo <frames.raw (n x 640x480 u8)> <n>   -> one line of text per frame + a summary
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dmz.h"
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  const int n = atoi(argv[2]);
+  std::vector<unsigned char> buf((size_t)n * 640 * 480);
+  FILE *f = fopen(argv[1], "rb");
+  if (!f || fread(buf.data(), 1, buf.size(), f) != buf.size()) return 3;
+  fclose(f);
+  if (!dmz_has_hip_runtime()) { printf("NOGPU\n"); return 4; }
+  dmz_context *dmz = dmz_context_create();
+  if (!dmz) return 5;
+  ScannerState state;
+  scanner_initialize(&state);
+  state.dmz = dmz;
+  for (int i = 0; i < n; i++) {
+    IplImage y;
+    memset(&y, 0, sizeof(y));
+    y.nSize = sizeof(y); y.nChannels = 1; y.depth = IPL_DEPTH_8U; y.width = 640; y.height = 480;
+    y.widthStep = 640; y.imageData = (char *)buf.data() + (size_t)i * 640 * 480; y.imageSize = 640 * 480;
+    dmz_edges edges;
+    dmz_corner_points corners;
+    memset(&corners, 0, sizeof(corners));
+    const bool found = dmz_detect_edges(&y, NULL, NULL, FrameOrientationLandscapeRight, &edges, &corners);
+    printf("frame %d found %d edges %d%d%d%d tl %.9g %.9g br %.9g %.9g", i, found, edges.top.found,
+           edges.left.found, edges.bottom.found, edges.right.found, corners.top_left.x, corners.top_left.y,
+           corners.bottom_right.x, corners.bottom_right.y);
+    if (found) {
+      IplImage *card = NULL;
+      dmz_transform_card(dmz, &y, corners, FrameOrientationLandscapeRight, false, &card);
+      unsigned long sum = 0;
+      for (int k = 0; k < 428 * 270; k++) sum += (unsigned char)card->imageData[k] * (unsigned long)(k % 251 + 1);
+      FrameScanResult fr;
+      memset(&fr, 0, sizeof(fr));
+      scanner_add_frame_with_expiry(&state, card, false, &fr);
+      printf(" cardsum %lu usable %d upside %d y_offset %d vscore %.6f digits ", sum, fr.usable, fr.upside_down,
+             fr.vseg.y_offset, fr.vseg.score);
+      for (int d = 0; d < fr.hseg.n_offsets; d++) {
+        int best = 0;
+        for (int k = 1; k < 10; k++) if (fr.scores.v[d][k] > fr.scores.v[d][best]) best = k;
+        printf("%d", best);
+      }
+      dmz_release_image(&card);
+    }
+    printf("\n");
+  }
+  ScannerResult res;
+  scanner_result(&state, &res);
+  printf("session count15 %d count16 %d complete %d\n", state.count15, state.count16, res.complete);
+  float m[9];
+  dmz_point s[4] = {{106, 105}, {533, 105}, {106, 374}, {533, 374}}, d[4];
+  dmz_rect_get_points(dmz_create_rect(0, 0, 427, 269), d);
+  llcv_calc_persp_transform(m, 9, true, s, d);
+  printf("persp %.9g %.9g %.9g\n", m[0], m[2], m[5]);
+  scanner_destroy(&state);
+  dmz_context_destroy(dmz);
+  return 0;
+}

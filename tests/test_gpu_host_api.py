@@ -1,0 +1,57 @@
+"""The C++ host mirror of the reference API (card.io-dmz_amd/host/dmz.h): an SDK-style
+call sequence compiled with g++ and run on the GPU, checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "card.io-dmz_amd")
+
+
+@pytest.mark.gpu
+def test_sdk_style_call_sequence(tmp_path, oracle, ctx):
+    exe = str(tmp_path / "host_api_demo")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(PKG, "host"),
+                           os.path.join(ROOT, "tests", "host_api_demo.cpp"), "-o", exe,
+                           "-L", PKG, "-ldmz_host", "-ldmz_hip", "-Wl,-rpath," + PKG])
+    n = 5
+    frames = np.stack([oracle.synth_frame(99, 0)[0]] * n)  # the same card five times: a session
+    raw = tmp_path / "frames.raw"
+    frames.tofile(raw)
+    out = subprocess.check_output([exe, str(raw), str(n)], text=True).strip().splitlines()
+    want, wcard = oracle.scan_frame(frames[0])
+    weights = (np.arange(428 * 270) % 251 + 1).astype(np.uint64)
+    cardsum = int((wcard.reshape(-1).astype(np.uint64) * weights).sum())
+    for i in range(n):
+        t = out[i].split()
+        assert t[3] == str(int(want["found_all"]))
+        assert float(t[7]) == float(want["corners"][0]) and float(t[8]) == float(want["corners"][1])
+        assert float(t[10]) == float(want["corners"][6]) and float(t[11]) == float(want["corners"][7])
+        assert int(t[13]) == cardsum
+        assert int(t[15]) == int(bool(want["flags"] & 1))
+        assert int(t[19]) == int(want["vseg_y_offset"])
+        assert abs(float(t[21]) - float(want["vseg_score"])) < 1e-4
+        assert t[23] == "".join(str(int(d)) for d in want["digits"][: int(want["n_offsets"])])
+    sess = out[n].split()
+    usable = int(bool(want["flags"] & 1))
+    assert int(sess[4]) == usable * n  # count16
+    m = oracle.calc_persp_transform([106, 105, 533, 105, 106, 374, 533, 374], [0, 0, 427, 0, 0, 269, 427, 269])
+    p = out[n + 1].split()
+    assert np.float32(p[1]) == m[0] and np.float32(p[2]) == m[2] and np.float32(p[3]) == m[5]
+
+
+def test_host_library_exports_reference_names(pkg):
+    """CPU: the mirror exports the reference's entry point names (C++ linkage, like the reference)."""
+    pkg.build()
+    so = os.path.join(PKG, "libdmz_host.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", PKG, "libdmz_host.so"], stdout=subprocess.DEVNULL)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", so], text=True)
+    for name in ("dmz_context_create()", "dmz_context_destroy(dmz_context*)", "dmz_detect_edges(",
+                 "dmz_transform_card(", "dmz_found_all_edges(", "llcv_unwarp(", "llcv_calc_persp_transform(",
+                 "scanner_initialize(", "scanner_reset(", "scanner_add_frame(", "scanner_add_frame_with_expiry(",
+                 "scanner_result(", "scanner_destroy(", "mz_create()", "mz_destroy(", "mz_prepare_for_backgrounding(",
+                 "dmz_passes_luhn_checksum(", "dmz_card_info_for_prefix_and_length(", "dmz_prepare_for_backgrounding("):
+        assert name in syms, name
