@@ -28,7 +28,7 @@ struct dmz_hip_context {
   std::string err;
 
   float *d_weights = nullptr;  // blob
-  float *d_hidwt = nullptr;    // digit hidden W transposed 3 x [320][32]
+  float *d_hidwt = nullptr;    // 16-byte aligned copy of the digit hidden matrices, 3 x [32][320]
 
   // detection tables for the current (width, height, orientation)
   int cfg_w = 0, cfg_h = 0, cfg_orientation = 0;
@@ -411,7 +411,7 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
   for (int m = 0; m < 3; m++)
     for (int j = 0; j < 32; j++)
       for (int i = 0; i < 320; i++)
-        hidwt[(size_t)m * 320 * 32 + i * 32 + j] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
+        hidwt[(size_t)m * 320 * 32 + j * 320 + i] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
   bool ok = hipMalloc((void **)&ctx->d_weights, sizeof(float) * dmzw::TOTAL) == hipSuccess &&
             hipMalloc((void **)&ctx->d_hidwt, sizeof(float) * hidwt.size()) == hipSuccess &&
             hipMemcpy(ctx->d_weights, w, sizeof(float) * dmzw::TOTAL, hipMemcpyHostToDevice) == hipSuccess &&

@@ -102,7 +102,7 @@ void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, 
                      int n, int only_warped, dmz_hip_frame_result *results);
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results);
-void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidwt /* 3 x [320][32] */,
+void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw /* 3 x [32][320] */,
                        const uint8_t *cards, size_t card_stride, int n,
                        dmz_hip_frame_result *results);
 void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *x, int n, float *out);

@@ -27,8 +27,8 @@ def test_sdk_style_call_sequence(tmp_path, oracle, ctx):
     for i in range(n):
         t = out[i].split()
         assert t[3] == str(int(want["found_all"]))
-        assert float(t[7]) == float(want["corners"][0]) and float(t[8]) == float(want["corners"][1])
-        assert float(t[10]) == float(want["corners"][6]) and float(t[11]) == float(want["corners"][7])
+        assert np.float32(t[7]) == want["corners"][0] and np.float32(t[8]) == want["corners"][1]
+        assert np.float32(t[10]) == want["corners"][6] and np.float32(t[11]) == want["corners"][7]
         assert int(t[13]) == cardsum
         assert int(t[15]) == int(bool(want["flags"] & 1))
         assert int(t[19]) == int(want["vseg_y_offset"])
