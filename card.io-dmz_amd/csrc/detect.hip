@@ -125,10 +125,11 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   }
   int flags = 0;
   if (m > low) {
-    const int ax = iabs(dxc), ay = iabs(dyc);
-    const long long tg22x = (long long)ax * TG22;
-    const long long tg67x = tg22x + ((long long)(ax + ax) << 15);
-    const long long yy = (long long)ay << 15;
+    // canny.cpp:224-236 in 32 bits: |dx|, |dy| <= 32768, so x*TG22 < 2^29, tg67x < 2^32, y<<15 <= 2^30
+    const unsigned ax = (unsigned)iabs(dxc), ay = (unsigned)iabs(dyc);
+    const unsigned tg22x = ax * (unsigned)TG22;
+    const unsigned tg67x = tg22x + ((ax + ax) << 15);
+    const unsigned yy = ay << 15;
     bool is_max;
     if (yy < tg22x) {
       is_max = m > mW && m >= mE;
@@ -138,17 +139,21 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
       const bool neg = (dxc ^ dyc) < 0;  // s = -1
       is_max = neg ? (m > mNE && m > mSW) : (m > mNW && m > mSE);
     }
-    if (is_max) flags = MAP_CAND | (m > high ? MAP_EDGE : 0);
+    if (is_max) {
+      flags = MAP_CAND | (m > high ? MAP_EDGE : 0);
+      // Hough slope gate (hough.cpp:133-150); only edge pixels ever vote, so it is evaluated
+      // for NMS survivors only
+      bool use;
+      if (dxc != 0) {
+        const float slope = (float)dyc / (float)dxc;
+        use = VERT ? (slope >= bp.slope_a && slope <= bp.slope_b)
+                   : (slope >= bp.slope_a || slope <= bp.slope_b);
+      } else {
+        use = !VERT;
+      }
+      if (use) flags |= MAP_GATE;
+    }
   }
-  bool use;
-  if (dxc != 0) {
-    const float slope = (float)dyc / (float)dxc;
-    use = VERT ? (slope >= bp.slope_a && slope <= bp.slope_b)
-               : (slope >= bp.slope_a || slope <= bp.slope_b);
-  } else {
-    use = !VERT;
-  }
-  if (use) flags |= MAP_GATE;
   const int q = s * c.L + c.l;  // walk-space index
   map[q] = (unsigned char)flags;
   if ((flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND) {  // seeds need no propagation
@@ -356,18 +361,26 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   __syncthreads();
   {
     const int half = (numrho - 1) / 2;
-    for (int q = tid; q < N; q += NT) {
-      const int f = map[q];
-      if ((f & (MAP_EDGE | MAP_GATE)) != (MAP_EDGE | MAP_GATE)) continue;
-      int a = __umulhi((uint32_t)q, inv_L);
-      int l = q - a * L;
-      if (l >= L) { l -= L; a++; }
-      const int r = VERT ? l : a, col = VERT ? a : l;  // image coordinates inside the ROI
+    const uint32_t *map32 = (const uint32_t *)map;  // lds_map is 16-byte aligned
+    for (int q4 = tid; q4 < (N + 3) >> 2; q4 += NT) {
+      const uint32_t w4 = map32[q4];
+      // bytes with MAP_EDGE and MAP_GATE both set
+      uint32_t hits4 = (w4 >> 1) & (w4 >> 2) & 0x01010101u;
+      while (hits4) {
+        const int b = (__builtin_ctz(hits4)) >> 3;
+        hits4 &= hits4 - 1;
+        const int q = 4 * q4 + b;
+        if (q >= N) break;
+        int a = __umulhi((uint32_t)q, inv_L);
+        int l = q - a * L;
+        if (l >= L) { l -= L; a++; }
+        const int r = VERT ? l : a, col = VERT ? a : l;  // image coordinates inside the ROI
 #pragma unroll
-      for (int n = 0; n < kNumAngle; n++) {
-        const int rr = ((col * bp.tab_cos[n] + r * bp.tab_sin[n]) >> 10) + half;
-        const int cell = n * numrho + rr;
-        atomicAdd(&acc32[cell >> 1], 1u << ((cell & 1) * 16));  // counts < 65536: no carry
+        for (int n = 0; n < kNumAngle; n++) {
+          const int rr = ((col * bp.tab_cos[n] + r * bp.tab_sin[n]) >> 10) + half;
+          const int cell = n * numrho + rr;
+          atomicAdd(&acc32[cell >> 1], 1u << ((cell & 1) * 16));  // counts < 65536: no carry
+        }
       }
     }
   }
@@ -376,12 +389,15 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 
   // ---- F. arg-max with the reference's scan order (hough.cpp:163-176) ----
   unsigned long long best = 0;
-  for (int i = tid; i < ncell; i += NT) {
-    const int n = i / numrho, rr = i - n * numrho;
-    const unsigned int val = (acc32[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-    const unsigned int order = (unsigned int)(rr * kNumAngle + n);  // scan position
-    const unsigned long long key = ((unsigned long long)val << 32) | (0xffffffffu - order);
-    best = key > best ? key : best;
+  {
+    const unsigned short *acc16 = (const unsigned short *)acc32;
+    for (int n = 0; n < kNumAngle; n++)
+      for (int rr = tid; rr < numrho; rr += NT) {
+        const unsigned int val = acc16[n * numrho + rr];
+        const unsigned int order = (unsigned int)(rr * kNumAngle + n);  // scan position
+        const unsigned long long key = ((unsigned long long)val << 32) | (0xffffffffu - order);
+        best = key > best ? key : best;
+      }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long other = __shfl_down(best, o, 64);
