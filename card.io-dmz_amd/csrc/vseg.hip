@@ -39,6 +39,21 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return imax(a, imax(b, c)); }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return imin(a, imin(b, c)); }
 
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32: |error| ~ 2e-7 absolute
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // 2 * log2(e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+  return x;
+}
+
 constexpr int VS_THREADS = 256;
 constexpr int VS_WAVES = 4;
 constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
@@ -166,16 +181,11 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
       const f32x4 acc = t ? acc1 : acc0;
 #pragma unroll
       for (int v = 0; v < 4; v++) {
-        const float hv = tanhf(acc[v] + b1);  // units >= 50 have zero logistic weights
-        float o0 = w20 * hv, o1 = w21 * hv, o2 = w22 * hv;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {  // sum over the 16 hidden units of this wave
-          o0 += __shfl_xor(o0, o, 64);
-          o1 += __shfl_xor(o1, o, 64);
-          o2 += __shfl_xor(o2, o, 64);
-        }
+        const float hv = fast_tanh(acc[v] + b1);  // units >= 50 have zero logistic weights
+        // sum over the 16 hidden units of this wave (one DPP row)
+        const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
         const int row = (mt + t) * 16 + 4 * kk + v;
-        if (ii == 0 && row < nrows) {
+        if (ii == 15 && row < nrows) {
           float *p = part + (wave * 80 + row) * 4;
           p[0] = o0; p[1] = o1; p[2] = o2;
         }
@@ -265,7 +275,7 @@ __device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts,
   w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
 }
 
-__global__ __launch_bounds__(VS_THREADS) void k_vseg(const float *__restrict__ wts,
+__global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict__ wts,
                                                       const uint8_t *__restrict__ cards,
                                                       size_t card_stride, int n, int only_warped,
                                                       dmz_hip_frame_result *__restrict__ results) {
@@ -381,16 +391,10 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
     }
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-      const float hv = tanhf(acc[v] + w.b1);
-      float o0 = w.w20 * hv, o1 = w.w21 * hv, o2 = w.w22 * hv;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        o0 += __shfl_xor(o0, o, 64);
-        o1 += __shfl_xor(o1, o, 64);
-        o2 += __shfl_xor(o2, o, 64);
-      }
+      const float hv = fast_tanh(acc[v] + w.b1);
+      const float o0 = row16_sum(w.w20 * hv), o1 = row16_sum(w.w21 * hv), o2 = row16_sum(w.w22 * hv);
       const int row = 4 * kk + v;
-      if (ii == 0 && row < rows) {
+      if (ii == 15 && row < rows) {
         float *p = part + (wave * 80 + row) * 4;
         p[0] = o0; p[1] = o1; p[2] = o2;
       }
