@@ -42,6 +42,19 @@ ALGO = {
     "digits":   (16 * 27 * 19 + 744,        16 * 3 * 2 * (8 * 360 * 9 + 320 * 32 + 320)),
 }
 PIPELINE_BYTES = 307200 + 115560 + 1024
+# HBM traffic per frame (bytes) from the committed PMC passes profiles/r1_pmc_{FETCH,WRITE}_SIZE_*.txt
+# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, KB per dispatch / 4096 frames).
+# FETCH_SIZE is NOT doubled: the guide's x2 gfx950 correction is calibrated for 16 B/lane
+# streams, these kernels load 4 B/lane ("uncalibrated" there); WRITE_SIZE matched known byte
+# counts exactly (k_synth_frames: 307,200 B/frame; k_warp: 112.9 KB vs 115,560 B written).
+PMC_TRAFFIC = {
+    "detect": (71912.8 + 123573.8 + 256 + 256) * 1024 / 4096,
+    "geometry": (166.5 + 847.2 + 384 + 1472) * 1024 / 4096,
+    "warp": (352640.2 + 462271.1) * 1024 / 4096,
+    "vseg": (100604.2 + 3146.3) * 1024 / 4096,
+    "hseg": (32576.1 + 256.0) * 1024 / 4096,
+    "digits": (24546.8 + 2902.4) * 1024 / 4096,
+}
 
 
 def cpu_baseline(orc_mod, frames, budget_s=12.0):
@@ -166,6 +179,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(fl_frac, 5), "traffic": None}
         roof["kernel"] = dom
         roof["launch_ms"] = per_stage[dom]["ms_per_step"]
+        roof["traffic"] = round(PMC_TRAFFIC[dom] * B)  # bytes per launch, from profiles/ (see PMC_TRAFFIC)
         value = world * B * args.steps / elapsed
         roof["pipeline_GBps"] = round(value / world * PIPELINE_BYTES / 1e9, 2)
         roof["pipeline_frac_of_hbm"] = round(value / world * PIPELINE_BYTES / 1e9 / HBM_PEAK_GBPS, 5)
