@@ -34,6 +34,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
+// developer ablation (tools/ablate.sh): return after phase k
+#ifndef DMZ_DIGITS_STOP
+#define DMZ_DIGITS_STOP 99
+#endif
+#define DG_STOP(k, expr) if (DMZ_DIGITS_STOP == (k)) { if (tid == 0) res->number_score = (float)(expr); return; }
+
 constexpr int DG_THREADS = 256;
 constexpr int DG_ESTRIDE = 528;  // bytes per equalised digit patch (513 used)
 constexpr int DG_PSTRIDE = 324;  // floats per pooled row (320 used)
@@ -73,18 +79,31 @@ __device__ __forceinline__ void digit_conv_pool(const float (&in)[5][5], const f
   }
 }
 
-// FC 320 -> 32 for 16 rows of `pooled` on the matrix core; part[khalf][row][32]
-__device__ __forceinline__ void digit_fc1(const float *__restrict__ hw /* [32][320], 16-B aligned */,
-                                          const float *__restrict__ pooled, float *__restrict__ part,
-                                          int wave, int lane) {
+// FC 320 -> 32 for 16 rows of `pooled` on the matrix core; part[khalf][row][32].
+// The B operands (this wave's 16 hidden units x its K half) are fetched early by the caller
+// so that the L2 latency hides behind the convolution.
+struct Fc1B {
+  f32x4 b[10];
+};
+
+__device__ __forceinline__ void digit_fc1_load(const float *__restrict__ hw /* [32][320], 16-B aligned */,
+                                               int wave, int lane, Fc1B &w) {
   const int nt = wave & 1, kh = wave >> 1;
   const int ii = lane & 15, kk = lane >> 4;
   const float *bp = hw + (nt * 16 + ii) * 320 + kh * 160 + 4 * kk;
+#pragma unroll
+  for (int u = 0; u < 10; u++) w.b[u] = *(const f32x4 *)(bp + 16 * u);
+}
+
+__device__ __forceinline__ void digit_fc1(const Fc1B &w, const float *__restrict__ pooled,
+                                          float *__restrict__ part, int wave, int lane) {
+  const int nt = wave & 1, kh = wave >> 1;
+  const int ii = lane & 15, kk = lane >> 4;
   const float *ap = pooled + ii * DG_PSTRIDE + kh * 160 + 4 * kk;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < 10; u += 2) {
-    const f32x4 b0 = *(const f32x4 *)(bp + 16 * u), b1 = *(const f32x4 *)(bp + 16 * u + 16);
+    const f32x4 b0 = w.b[u], b1 = w.b[u + 1];
     const f32x4 a0 = *(const f32x4 *)(ap + 16 * u), a1 = *(const f32x4 *)(ap + 16 * u + 16);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
@@ -127,7 +146,7 @@ __device__ __forceinline__ void digit_head(const float *__restrict__ mw, const f
   __syncthreads();
 }
 
-__global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__ wts,
+__global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restrict__ wts,
                                                         const float *__restrict__ hidw /* 3 x [32][320] */,
                                                         const uint8_t *__restrict__ cards,
                                                         size_t card_stride, int n,
@@ -137,7 +156,11 @@ __global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__
   __shared__ float part[2 * 16 * 32];
   __shared__ float hid[16 * 32];
   __shared__ float prob[3 * 16 * 10];
-  int *hist = (int *)pooled;  // 16 x 256 ints, dead before pooled is written
+  // pooled is dead until the first conv: it first holds the 16 histograms (u16 counters,
+  // 8 KB) and the 27 x 428 number strip (11.6 KB)
+  unsigned int *hist32 = (unsigned int *)pooled;                       // 16 x 128 words
+  unsigned short *hist16 = (unsigned short *)pooled;                   // 16 x 256 counters
+  unsigned char *strip_l = (unsigned char *)pooled + 16 * 256 * 2;     // 27 x 428 bytes
 
   const int f = blockIdx.x;
   if (f >= n) return;
@@ -146,15 +169,17 @@ __global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nd = res->n_offsets;
   const int y_off = res->vseg_y_offset;
-  const uint8_t *strip = cards + (size_t)f * card_stride + (size_t)y_off * DMZ_CARD_WIDTH;
+  const uint32_t *strip = (const uint32_t *)(cards + (size_t)f * card_stride + (size_t)y_off * DMZ_CARD_WIDTH);
 
-  // ---- per digit: cross gradient clamped at the 19x27 ROI edge, histogram ----
-  for (int i = tid; i < 16 * 256; i += DG_THREADS) hist[i] = 0;
+  // ---- number strip -> LDS (2889 aligned dwords), histograms cleared ----
+  for (int i = tid; i < 27 * 107; i += DG_THREADS) ((uint32_t *)strip_l)[i] = strip[i];
+  for (int i = tid; i < 16 * 128; i += DG_THREADS) hist32[i] = 0u;
   __syncthreads();
+  // ---- per digit: cross gradient clamped at the 19x27 ROI edge, histogram ----
   for (int i = tid; i < nd * 513; i += DG_THREADS) {
     const int d = i / 513, p = i - d * 513;
     const int r = p / 19, c = p - r * 19;
-    const uint8_t *roi = strip + res->offsets[d];
+    const unsigned char *roi = strip_l + res->offsets[d];
     const int ru = r > 0 ? r - 1 : r, rd = r < 26 ? r + 1 : r;
     const int cl = c > 0 ? c - 1 : c, cr = c < 18 ? c + 1 : c;
     const int nn = roi[ru * DMZ_CARD_WIDTH + c], ww = roi[r * DMZ_CARD_WIDTH + cl],
@@ -162,12 +187,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__
               ss = roi[rd * DMZ_CARD_WIDTH + c];
     const int gv = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
     eq[d * DG_ESTRIDE + p] = (unsigned char)gv;
-    atomicAdd(&hist[d * 256 + gv], 1);
+    atomicAdd(&hist32[d * 128 + (gv >> 1)], 1u << ((gv & 1) * 16));  // counts <= 513: no carry
   }
   __syncthreads();
+  DG_STOP(1, eq[0] + hist32[3])
   // ---- equalisation LUT (stats.cpp:135-151): one wave per digit, 4 bins per lane ----
   for (int d = wave; d < nd; d += DG_THREADS / 64) {
-    int *h = hist + d * 256;
+    unsigned short *h = hist16 + d * 256;
     const int h0 = h[lane * 4 + 0], h1 = h[lane * 4 + 1], h2 = h[lane * 4 + 2], h3 = h[lane * 4 + 3];
     const int tot = h0 + h1 + h2 + h3;
     int incl = tot;
@@ -183,14 +209,16 @@ __global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__
     l0 = imin(255, imax(0, l0)); l1 = imin(255, imax(0, l1));
     l2 = imin(255, imax(0, l2)); l3 = imin(255, imax(0, l3));
     if (lane == 0) l0 = 0;  // lut[0] = 0 (stats.cpp:151)
-    h[lane * 4 + 0] = l0; h[lane * 4 + 1] = l1; h[lane * 4 + 2] = l2; h[lane * 4 + 3] = l3;
+    h[lane * 4 + 0] = (unsigned short)l0; h[lane * 4 + 1] = (unsigned short)l1;
+    h[lane * 4 + 2] = (unsigned short)l2; h[lane * 4 + 3] = (unsigned short)l3;
   }
   __syncthreads();
   for (int i = tid; i < nd * 513; i += DG_THREADS) {
     const int d = i / 513, p = i - d * 513;
-    eq[d * DG_ESTRIDE + p] = (unsigned char)hist[d * 256 + eq[d * DG_ESTRIDE + p]];
+    eq[d * DG_ESTRIDE + p] = (unsigned char)hist16[d * 256 + eq[d * DG_ESTRIDE + p]];
   }
   __syncthreads();
+  DG_STOP(2, eq[0] + eq[512])
   // rows of unused digits (nd = 15) must be finite for the matrix core
   for (int i = tid; i < 16 * DG_PSTRIDE; i += DG_THREADS) pooled[i] = 0.0f;
   __syncthreads();
@@ -199,6 +227,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__
   const float s255 = 1.0f / 255.0f;
   for (int m = 0; m < 3; m++) {
     const float *mw = wts + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
+    Fc1B fcb;
+    digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);
     for (int i = tid; i < nd * 40; i += DG_THREADS) {
       const int d = i / 40, pos = i - d * 40;
       const int pr = pos / 5, pc = pos - pr * 5;
@@ -211,8 +241,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_digits(const float *__restrict__
       digit_conv_pool(in, mw, pos, pooled + d * DG_PSTRIDE);
     }
     __syncthreads();
-    digit_fc1(hidw + m * 32 * 320, pooled, part, wave, lane);
+    DG_STOP(3, pooled[0] + pooled[300])
+    digit_fc1(fcb, pooled, part, wave, lane);
     __syncthreads();
+    DG_STOP(4, part[0] + part[600])
     digit_head(mw, part, hid, prob + m * 160, nd, tid);
   }
   // ---- vote (n_categorize.cpp:69-70), arg-max, usable gate (frame.cpp:63-64) ----
@@ -280,7 +312,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restr
     digit_conv_pool(in, mw, pos, pooled + d * DG_PSTRIDE);
   }
   __syncthreads();
-  digit_fc1(hidw + model * 32 * 320, pooled, part, wave, lane);
+  Fc1B fcb;
+  digit_fc1_load(hidw + model * 32 * 320, wave, lane, fcb);
+  digit_fc1(fcb, pooled, part, wave, lane);
   __syncthreads();
   digit_head(mw, part, hid, prob, rows, tid);
   if (tid < rows * 10) out[(size_t)base * 10 + tid] = prob[tid];
