@@ -54,6 +54,12 @@ __device__ __forceinline__ float row16_sum(float x) {
   return x;
 }
 
+// developer ablation (tools/ablate.sh): return after phase k
+#ifndef DMZ_VSEG_STOP
+#define DMZ_VSEG_STOP 99
+#endif
+#define VS_STOP(k, expr) if (DMZ_VSEG_STOP == (k)) { if (tid == 0) res->vseg_score = (float)(expr); return; }
+
 constexpr int VS_THREADS = 256;
 constexpr int VS_WAVES = 4;
 constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
@@ -309,8 +315,10 @@ __global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict_
   VsegWeights w;
   vseg_load_weights(wts, wave, lane, w);
   __syncthreads();
+  VS_STOP(1, grad[0] + norm[5])
   vseg_mlp_rows(w.bw, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
   __syncthreads();
+  VS_STOP(2, part[0] + part[100])
   vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
   __syncthreads();
   if (tid == 0) {
@@ -327,6 +335,7 @@ __global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict_
     s_int[0] = cnt;
   }
   __syncthreads();
+  VS_STOP(3, s_int[0] + vis[100])
   const int nfine = s_int[0];
   if (nfine > 0) {
     vseg_prepare_rows(card, row_y, nfine, grad, norm, wave, lane);
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict_
     vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
     __syncthreads();
   }
+  VS_STOP(4, vis[150] + amx[3])
   if (tid == 0) {
     float score;
     int y_off, pattern;
