@@ -30,7 +30,7 @@ ORIENTATION_LANDSCAPE_LEFT = 4
 
 FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
 OPT_TRUNCATE_CORNERS = 1
-STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits")
+STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
 
 # mirror of struct dmz_hip_frame_result (include/dmz_hip.h), 1024 bytes
 RESULT_DTYPE = np.dtype([
@@ -44,6 +44,22 @@ RESULT_DTYPE = np.dtype([
 ])
 assert RESULT_DTYPE.itemsize == 1024
 
+# mirror of struct dmz_hip_expiry_group / dmz_hip_expiry_result (include/dmz_hip.h)
+EXPIRY_MAX_GROUPS = 8
+EXPIRY_GROUP_DTYPE = np.dtype([
+    ("top", "<i2"), ("left", "<i2"), ("width", "<i2"), ("height", "<i2"),
+    ("char_top", "<i2", (5,)), ("char_left", "<i2", (5,)),
+    ("stripe_base_row", "<i2"), ("reserved", "<i2"), ("scores", "<f4", (4, 10)),
+])
+assert EXPIRY_GROUP_DTYPE.itemsize == 192
+EXPIRY_DTYPE = np.dtype([
+    ("n_groups", "<i4"), ("n_found", "<i4"), ("n_stripes", "<i4"),
+    ("stripe_base_row", "<i4", (3,)), ("stripe_sum", "<i8", (3,)),
+    ("categorised", "<i4"), ("reserved", "<i4"),
+    ("groups", EXPIRY_GROUP_DTYPE, (EXPIRY_MAX_GROUPS,)),
+])
+assert EXPIRY_DTYPE.itemsize == 1592
+
 # every symbol include/dmz_hip.h declares
 EXPORTS = (
     "dmz_hip_device_count", "dmz_hip_context_create", "dmz_hip_context_destroy",
@@ -53,6 +69,8 @@ EXPORTS = (
     "dmz_hip_apply_vseg_model", "dmz_hip_apply_digit_model", "dmz_hip_synth_frames",
     "dmz_hip_synth_cards", "dmz_hip_set_profiling", "dmz_hip_get_stage_times",
     "dmz_hip_malloc", "dmz_hip_free", "dmz_hip_memcpy_h2d", "dmz_hip_memcpy_d2h",
+    "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
+    "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model",
 )
 
 
@@ -92,6 +110,10 @@ def load_library():
     lib.dmz_hip_transform_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, vp, sz]
     lib.dmz_hip_scan_cards_batch.argtypes = [vp, vp, sz, i, i, vp]
     lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
+    lib.dmz_hip_scan_expiry_batch.argtypes = [vp, vp, sz, i, vp, vp]
+    lib.dmz_hip_pipeline_expiry_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp, vp]
+    lib.dmz_hip_apply_slash_model.argtypes = [vp, vp, i, vp]
+    lib.dmz_hip_apply_expiry_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_calc_persp_transform.argtypes = [vp, vp, vp, vp]
     lib.dmz_hip_warp_perspective_batch.argtypes = [vp, vp, sz, i, i, i, i, vp, vp, sz]
     lib.dmz_hip_apply_vseg_model.argtypes = [vp, vp, i, vp]
@@ -218,6 +240,16 @@ class Context:
             self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
             _ptr(cards), CARD_BYTES, _ptr(results)))
 
+    def scan_expiry(self, cards, n, results, expiry):
+        self._check(self.lib.dmz_hip_scan_expiry_batch(self.h, _ptr(cards), CARD_BYTES, n, _ptr(results),
+                                                       _ptr(expiry)))
+
+    def pipeline_expiry(self, y, n, results, expiry, cards=None, width=FRAME_W, height=FRAME_H,
+                        orientation=ORIENTATION_LANDSCAPE_RIGHT, options=0):
+        self._check(self.lib.dmz_hip_pipeline_expiry_batch(
+            self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
+            _ptr(cards), CARD_BYTES, _ptr(results), _ptr(expiry)))
+
     def calc_persp_transform(self, src_pts, dst_pts):
         s = np.ascontiguousarray(src_pts, np.float32).reshape(8)
         d = np.ascontiguousarray(dst_pts, np.float32).reshape(8)
@@ -239,6 +271,18 @@ class Context:
         x = np.ascontiguousarray(x, np.float32).reshape(-1, 27 * 19)
         out = np.empty((x.shape[0], 10), np.float32)
         self._check(self.lib.dmz_hip_apply_digit_model(self.h, model, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def apply_slash_model(self, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, 176)
+        out = np.empty((x.shape[0], 2), np.float32)
+        self._check(self.lib.dmz_hip_apply_slash_model(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def apply_expiry_model(self, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, 176)
+        out = np.empty((x.shape[0], 10), np.float32)
+        self._check(self.lib.dmz_hip_apply_expiry_model(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
         return out
 
     def synth_frames(self, seed, first, n, y_dev):

@@ -29,6 +29,8 @@ struct dmz_hip_context {
 
   float *d_weights = nullptr;  // blob
   float *d_hidwt = nullptr;    // 16-byte aligned copy of the digit hidden matrices, 3 x [32][320]
+  float *d_xw = nullptr;       // expiry models re-laid-out for coalesced reads (dmzx:: offsets)
+  DmzExpiryTables *d_xtab = nullptr;  // bilateral filter weights
 
   // detection tables for the current (width, height, orientation)
   int cfg_w = 0, cfg_h = 0, cfg_orientation = 0;
@@ -40,13 +42,14 @@ struct dmz_hip_context {
     void *p = nullptr;
     size_t cap = 0;
   };
-  Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc;
+  Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc, xstage, stage_exp;
 
   // profiling
   bool profiling = false;
   struct Span {
     int stage;
     hipEvent_t a, b;
+    bool b_shared = false;  // b is also the start event of a later span: recycled there
   };
   std::vector<Span> spans;
   std::vector<hipEvent_t> free_events;
@@ -234,6 +237,7 @@ int configure_detection(dmz_hip_context *ctx, int width, int height, int orienta
 struct StageTimer {
   dmz_hip_context *ctx;
   hipEvent_t a = nullptr, b = nullptr;
+  hipEvent_t b_override = nullptr;  // already-recorded end event (shared with the next span)
   int stage;
   StageTimer(dmz_hip_context *c, int s) : ctx(c), stage(s) {
     if (!ctx->profiling) return;
@@ -243,6 +247,11 @@ struct StageTimer {
   }
   ~StageTimer() {
     if (!ctx->profiling) return;
+    if (b_override) {
+      ctx->free_events.push_back(b);
+      ctx->spans.push_back({stage, a, b_override, true});
+      return;
+    }
     (void)hipEventRecord(b, ctx->stream);
     ctx->spans.push_back({stage, a, b});
   }
@@ -267,7 +276,7 @@ void resolve_spans(dmz_hip_context *ctx) {
       ctx->stage_launches[s.stage] += 1;
     }
     ctx->free_events.push_back(s.a);
-    ctx->free_events.push_back(s.b);
+    if (!s.b_shared) ctx->free_events.push_back(s.b);
   }
   ctx->spans.clear();
 }
@@ -364,6 +373,28 @@ int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int
   return DMZ_HIP_OK;
 }
 
+// best_expiry_seg + categorize_expiry_digits on device-resident cards / results / output
+int run_expiry(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+               const dmz_hip_frame_result *results, dmz_hip_expiry_result *out) {
+  int rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * 3 * (size_t)n);
+  if (rc) return rc;
+  if (!ctx->profiling) {
+    dmz_launch_expiry(ctx->stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, cards, card_stride, n, results,
+                      (DmzExpiryStage *)ctx->xstage.p, out, nullptr);
+  } else {
+    // two spans (segmentation kernels | categorisation kernel) sharing the middle event
+    StageTimer a(ctx, DMZ_HIP_STAGE_EXPIRY_SEG);
+    hipEvent_t mid = a.take(), mid2 = a.take();
+    dmz_launch_expiry(ctx->stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, cards, card_stride, n, results,
+                      (DmzExpiryStage *)ctx->xstage.p, out, mid);
+    (void)hipEventRecord(mid2, ctx->stream);
+    ctx->spans.push_back({DMZ_HIP_STAGE_EXPIRY_CAT, mid, mid2});
+    a.b_override = mid;
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return DMZ_HIP_OK;
+}
+
 int check_frames(dmz_hip_context *ctx, const void *y, size_t frame_stride, int row_stride, int width,
                  int height, int n) {
   if (!ctx) return DMZ_HIP_EINVAL;
@@ -412,7 +443,42 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     for (int j = 0; j < 32; j++)
       for (int i = 0; i < 320; i++)
         hidwt[(size_t)m * 320 * 32 + j * 320 + i] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
-  bool ok = hipMalloc((void **)&ctx->d_weights, sizeof(float) * dmzw::TOTAL) == hipSuccess &&
+  // expiry models: slash W1 input-major, conv2 tap-major, FC1 input-major (coalesced across lanes)
+  std::vector<float> xw(dmzx::TOTAL);
+  {
+    const float *sw = w + dmzw::SLASH + dmzw::S_W1;
+    for (int j = 0; j < 80; j++)
+      for (int i = 0; i < 176; i++) xw[dmzx::SLASH_W1T + i * 80 + j] = sw[j * 176 + i];
+    const float *c2 = w + dmzw::EXPIRY + dmzw::X_C2W;
+    for (int k = 0; k < 40; k++)
+      for (int t = 0; t < 1250; t++) xw[dmzx::CONV2_T + t * 40 + k] = c2[k * 1250 + t];
+    const float *hw = w + dmzw::EXPIRY + dmzw::X_HW;
+    for (int j = 0; j < 176; j++)
+      for (int i = 0; i < 120; i++) xw[dmzx::FC1_T + i * 176 + j] = hw[j * 120 + i];
+  }
+  // cv::bilateralFilter(d = 3, sigmaColor = 0.95, sigmaSpace = 2/3) tables, expiry_categorize.cpp:52-57
+  // (cvSmooth hands param3 to sigmaColor and param4 to sigmaSpace)
+  DmzExpiryTables xtab;
+  {
+    const int aperture = 3;
+    const double space_sigma = (aperture / 2.0 - 1) * 0.3 + 0.8, color_sigma = (aperture - 1) / 3.0;
+    const double sigma_color = space_sigma, sigma_space = color_sigma;
+    const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
+    const double gauss_space_coeff = -0.5 / (sigma_space * sigma_space);
+    for (int i = 0; i < 256; i++) xtab.color_weight[i] = (float)exp(i * i * gauss_color_coeff);
+    static const int di[5] = {-1, 0, 0, 0, 1}, dj[5] = {0, -1, 0, 1, 0};
+    for (int k = 0; k < 8; k++) xtab.space_weight[k] = 0.0f;
+    for (int k = 0; k < 5; k++) {
+      const double r = sqrt((double)di[k] * di[k] + (double)dj[k] * dj[k]);
+      xtab.space_weight[k] = (float)exp(r * r * gauss_space_coeff);
+    }
+  }
+  bool ok = hipMalloc((void **)&ctx->d_xw, sizeof(float) * xw.size()) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_xtab, sizeof(DmzExpiryTables)) == hipSuccess &&
+            hipMemcpy(ctx->d_xw, xw.data(), sizeof(float) * xw.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(ctx->d_xtab, &xtab, sizeof(xtab), hipMemcpyHostToDevice) == hipSuccess &&
+            dmz_configure_expiry() == 0 &&
+            hipMalloc((void **)&ctx->d_weights, sizeof(float) * dmzw::TOTAL) == hipSuccess &&
             hipMalloc((void **)&ctx->d_hidwt, sizeof(float) * hidwt.size()) == hipSuccess &&
             hipMemcpy(ctx->d_weights, w, sizeof(float) * dmzw::TOTAL, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(ctx->d_hidwt, hidwt.data(), sizeof(float) * hidwt.size(), hipMemcpyHostToDevice) == hipSuccess &&
@@ -433,12 +499,14 @@ void dmz_hip_context_destroy(dmz_hip_context *ctx) {
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   dmz_hip_context::Buf *bufs[] = {&ctx->hits, &ctx->mats, &ctx->skip, &ctx->synth, &ctx->stage_in,
                                   &ctx->stage_cb, &ctx->stage_cr, &ctx->stage_cards, &ctx->stage_res,
-                                  &ctx->cards, &ctx->misc};
+                                  &ctx->cards, &ctx->misc, &ctx->xstage, &ctx->stage_exp};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   if (ctx->d_weights) (void)hipFree(ctx->d_weights);
   if (ctx->d_hidwt) (void)hipFree(ctx->d_hidwt);
+  if (ctx->d_xw) (void)hipFree(ctx->d_xw);
+  if (ctx->d_xtab) (void)hipFree(ctx->d_xtab);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -555,12 +623,14 @@ int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t 
   return DMZ_HIP_OK;
 }
 
-int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
-                           int width, int height, int n, int orientation, int options, uint8_t *cards,
-                           size_t card_stride, dmz_hip_frame_result *results) {
+static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+                         int width, int height, int n, int orientation, int options, uint8_t *cards,
+                         size_t card_stride, dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry,
+                         bool with_expiry) {
   int rc = check_frames(ctx, y, frame_stride, row_stride, width, height, n);
   if (rc) return rc;
   if (!results) return fail(ctx, DMZ_HIP_EINVAL, "null results");
+  if (with_expiry && !expiry) return fail(ctx, DMZ_HIP_EINVAL, "null expiry results");
   if (!cards) card_stride = (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT;
   if (card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
     return fail(ctx, DMZ_HIP_EINVAL, "bad card stride");
@@ -587,13 +657,70 @@ int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_
                           orientation, options, dres, dcards, card_stride)))
     return rc;
   if ((rc = run_scan(ctx, dcards, card_stride, n, 1, dres))) return rc;
+  bool exp_dev = true;
+  if (with_expiry) {
+    exp_dev = is_device_ptr(expiry);
+    dmz_hip_expiry_result *dexp = expiry;
+    if (!exp_dev) {
+      if ((rc = ensure(ctx, ctx->stage_exp, sizeof(dmz_hip_expiry_result) * (size_t)n))) return rc;
+      dexp = (dmz_hip_expiry_result *)ctx->stage_exp.p;
+    }
+    if ((rc = run_expiry(ctx, dcards, card_stride, n, dres, dexp))) return rc;
+    if (!exp_dev)
+      HIP_TRY(ctx, hipMemcpyAsync(expiry, dexp, sizeof(dmz_hip_expiry_result) * (size_t)n, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+  }
   if (!res_dev)
     HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
                                 hipMemcpyDeviceToHost, ctx->stream));
   if (cards && !cards_dev)
     HIP_TRY(ctx, hipMemcpyAsync(cards, dcards, card_stride * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (!res_dev || (cards && !cards_dev)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!res_dev || !exp_dev || (cards && !cards_dev)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DMZ_HIP_OK;
+}
+
+int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+                           int width, int height, int n, int orientation, int options, uint8_t *cards,
+                           size_t card_stride, dmz_hip_frame_result *results) {
+  return pipeline_impl(ctx, y, frame_stride, row_stride, width, height, n, orientation, options, cards,
+                       card_stride, results, nullptr, false);
+}
+
+int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                              const dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!cards || !results || !expiry || n <= 0 || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT ||
+      (card_stride & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad card buffer (stride must be >= 115560 and a multiple of 4)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dc = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_cards, cards, card_stride * (size_t)n, &dc))) return rc;
+  if (((uintptr_t)dc) & 3) return fail(ctx, DMZ_HIP_EINVAL, "card buffer must be 4-byte aligned");
+  const void *dres = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_res, results, sizeof(dmz_hip_frame_result) * (size_t)n, &dres))) return rc;
+  const bool out_dev = is_device_ptr(expiry);
+  dmz_hip_expiry_result *dout = expiry;
+  if (!out_dev) {
+    if ((rc = ensure(ctx, ctx->stage_exp, sizeof(dmz_hip_expiry_result) * (size_t)n))) return rc;
+    dout = (dmz_hip_expiry_result *)ctx->stage_exp.p;
+  }
+  if ((rc = run_expiry(ctx, (const uint8_t *)dc, card_stride, n, (const dmz_hip_frame_result *)dres, dout)))
+    return rc;
+  if (!out_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(expiry, dout, sizeof(dmz_hip_expiry_result) * (size_t)n, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+                                  int width, int height, int n, int orientation, int options, uint8_t *cards,
+                                  size_t card_stride, dmz_hip_frame_result *results,
+                                  dmz_hip_expiry_result *expiry) {
+  return pipeline_impl(ctx, y, frame_stride, row_stride, width, height, n, orientation, options, cards,
+                       card_stride, results, expiry, true);
 }
 
 int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts, const float *dst_pts, float *m) {
@@ -657,6 +784,10 @@ static int run_model(dmz_hip_context *ctx, int which, int model, const float *x,
   }
   if (which == 0)
     dmz_launch_vseg_model(ctx->stream, ctx->d_weights, (const float *)dx, n, dout);
+  else if (which == 2)
+    dmz_launch_slash_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout);
+  else if (which == 3)
+    dmz_launch_expiry_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout);
   else
     dmz_launch_digit_model(ctx->stream, ctx->d_weights, ctx->d_hidwt, model, (const float *)dx, n, dout);
   HIP_TRY(ctx, hipGetLastError());
@@ -674,6 +805,14 @@ int dmz_hip_apply_vseg_model(dmz_hip_context *ctx, const float *x, int n, float 
 int dmz_hip_apply_digit_model(dmz_hip_context *ctx, int model, const float *x, int n, float *out) {
   if (model < 0 || model > 2) return fail(ctx, DMZ_HIP_EINVAL, "model must be 0..2");
   return run_model(ctx, 1, model, x, n, out, 27 * 19, 10);
+}
+
+int dmz_hip_apply_slash_model(dmz_hip_context *ctx, const float *x, int n, float *out) {
+  return run_model(ctx, 2, 0, x, n, out, 176, 2);
+}
+
+int dmz_hip_apply_expiry_model(dmz_hip_context *ctx, const float *x, int n, float *out) {
+  return run_model(ctx, 3, 0, x, n, out, 176, 10);
 }
 
 static int run_synth(dmz_hip_context *ctx, int cards, uint64_t seed, uint64_t first, int n, uint8_t *out) {

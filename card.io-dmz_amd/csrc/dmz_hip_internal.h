@@ -80,6 +80,32 @@ struct DmzWarpMat {
   int pad_;
 };
 
+// Expiry path.  Per (frame, stripe) staging written by k_expiry_seg and merged, in stripe order,
+// by k_expiry_cat; group headers only (the first 32 bytes of dmz_hip_expiry_group).
+struct DmzExpiryStage {
+  int n;  // groups this stripe produced (may exceed the 8 kept)
+  int pad_[3];
+  short hdr[DMZ_HIP_EXPIRY_MAX_GROUPS][16];
+};
+// cv::bilateralFilter tables (expiry_categorize.cpp:52-57): evaluated with glibc on the host.
+struct DmzExpiryTables {
+  float color_weight[256];
+  float space_weight[8];  // 5 used: (-1,0) (0,-1) (0,0) (0,1) (1,0)
+};
+// Re-laid-out copies of the expiry models (float offsets into one device buffer)
+namespace dmzx {
+constexpr int SLASH_W1T = 0;                      // [176][80]  (input-major)
+constexpr int CONV2_T = SLASH_W1T + 176 * 80;     // [50*25][40]
+constexpr int FC1_T = CONV2_T + 1250 * 40;        // [120][176]
+constexpr int TOTAL = FC1_T + 120 * 176;
+}  // namespace dmzx
+// offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)
+namespace dmzw {
+constexpr int X_C1W = 0, X_C1B = 1250, X_C2W = 1300, X_C2B = 51300, X_HW = 51340, X_HB = 72460,
+              X_LW = 72636, X_LB = 74396;
+constexpr int S_W1 = 0, S_B1 = 80 * 176, S_W2 = S_B1 + 80, S_B2 = S_W2 + 160;
+}  // namespace dmzw
+
 // Limits of the detect kernel (one (frame, box) per workgroup, box resident in LDS).
 constexpr int kDetectMaxLds = 160 * 1024;
 constexpr int kDetectMaxThreads = 1024;
@@ -112,6 +138,13 @@ size_t dmz_synth_params_bytes(int n);
 int dmz_synth_upload_params(hipStream_t s, uint64_t seed, uint64_t first, int n, void *scratch);
 void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *y);
 void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards);
+void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* dmzx layout */,
+                       const DmzExpiryTables *tables, const uint8_t *cards, size_t card_stride, int n,
+                       const dmz_hip_frame_result *results, DmzExpiryStage *stage /* n x 3 */,
+                       dmz_hip_expiry_result *out, hipEvent_t mid /* recorded between seg and cat, or null */);
+void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
+void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
+int dmz_configure_expiry(void);
 int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
 int dmz_configure_scan(void);
 int dmz_configure_vseg(void);

@@ -1,0 +1,852 @@
+// expiry.hip -- the expiry path of the scan, batched over frames:
+//   best_expiry_seg          scan/expiry_seg.cpp:707-902  (k_expiry_stripes)
+//   find_character_groups_for_stripe  :437-704, gather_into_groups :131-167,
+//   strip_group_white_space :101-129, regrid_group :169-229, optimize_character_rects :231-339,
+//   is_slash :52-58 with applym_730c4cbd                     (k_expiry_seg)
+//   prepare_image_for_cat    scan/expiry_categorize.cpp:35-70, categorize_expiry_digits :138-160
+//   with applyc_bf4dd6c8 (models/expiry/modelc_bf4dd6c8.cpp:12500-13505)   (k_expiry_cat)
+//
+// Exactness: everything up to and including the character rectangles is integer or
+// order-preserving IEEE float/double arithmetic (no contraction: the file is compiled with
+// -ffp-contract=off and uses explicit fmaf only inside the CNN), so stripes, groups and rects
+// are bit-exact.  The slash decision P > 0.7 and the digit scores go through tanhf/expf and, in
+// the CNN, fused multiply-adds: scores agree to 1e-4 (the reference's own KAT tolerance is 1e-5,
+// which the device models meet -- tests/test_gpu_expiry.py).
+//
+// std::sort in the reference is unstable; ties are resolved in ascending original index here
+// and in the oracle (see oracle/orc_expiry.c).
+//
+// Mapping: the list logic is short, serial and data-dependent, so one 64-lane wave owns one
+// (frame, stripe): lanes are columns, candidate rects, groups, grid hypotheses or character
+// rects as the step requires, with ballot/popcount compaction between steps.  The CNN stage is
+// one 256-thread workgroup per frame with the four digits of a group resident in LDS.
+#include <float.h>
+#include <math.h>
+
+#include "dmz_hip_internal.h"
+
+namespace {
+
+constexpr int CW = DMZ_CARD_WIDTH, CH = DMZ_CARD_HEIGHT;
+constexpr int kNumberHeight = 27;  // dmz_constants.h kNumberHeight
+constexpr int SCW = 9, SCH = 15;   // kSmallCharacterWidth / Height, expiry_types.h:16-17
+constexpr int TW = 11, TH = 16;    // kTrimmedCharacterImageWidth / Height, expiry_types.h:18-19
+constexpr int SOB_ROWS = 21;       // rows base-3 .. base+17 of the Scharr image
+constexpr int SOB_STRIDE = 432;    // shorts per row in LDS
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
+    v = v > w ? v : w;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w < v ? w : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// ---------------------------------------------------------------------------------------------
+// k_expiry_stripes: line sums of the |Scharr dx| image and the <= 3 probable stripes.
+// The 3/10/3 vertical pass commutes with the row sum, so line_sum[r] = 3 (I[r-1] + I[r+1]) +
+// 10 I[r] with I[r] = sum over columns 27..284 of |p[c+1] - p[c-1]| (one v_sad_u8 per dword) and
+// the row index clamped to the ROI [y0, 269] (sobel.cpp:765-766).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict__ cards, size_t card_stride,
+                                                       int n, const dmz_hip_frame_result *__restrict__ results,
+                                                       dmz_hip_expiry_result *__restrict__ out,
+                                                       DmzExpiryStage *__restrict__ stage) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n) return;
+  __shared__ int I[128];
+  __shared__ int line[128 + 16];
+  {
+    uint32_t *o32 = (uint32_t *)(out + f);
+    for (int i = lane; i < (int)(sizeof(dmz_hip_expiry_result) / 4); i += 64) o32[i] = 0u;
+    if (lane < 3) stage[(size_t)f * 3 + lane].n = 0;
+  }
+  const int flags = results[f].flags, yoff = results[f].vseg_y_offset;
+  // frame.cpp:72 -- and the vseg gates of frame.cpp:38-47 that precede it
+  if (!(flags & DMZ_HIP_FLAG_VSEG_OK) || !(yoff < CH - 2 * SCH) || yoff < 0) return;
+  const int y0 = yoff + kNumberHeight;
+  const int nrows = CH - y0;
+  if (nrows > 128 || nrows < 18) return;  // y_offset >= 121 for a card that is not upside down
+  const uint8_t *card = cards + (size_t)f * card_stride;
+
+  for (int r = 0; r < nrows; r++) {
+    const uint32_t *row = (const uint32_t *)(card + (size_t)(y0 + r) * CW);
+    const uint32_t a = row[6 + lane], b = row[7 + lane];
+    const uint32_t left = __builtin_amdgcn_alignbyte(b, a, 2);  // p[26 + 4 lane ..]
+    unsigned s = __builtin_amdgcn_sad_u8(b, left, 0u);          // p[28 + 4 lane ..] vs left
+    if (lane == 0) {
+      const uint8_t *p = (const uint8_t *)row;
+      s += (unsigned)iabs((int)p[284] - (int)p[282]) + (unsigned)iabs((int)p[285] - (int)p[283]);
+    }
+    s = (unsigned)wave_sum_i32((int)s);
+    if (lane == 0) I[r] = (int)s;
+  }
+  __syncthreads();
+  for (int r = lane; r < nrows; r += 64)
+    line[r] = 3 * (I[imax(r - 1, 0)] + I[imin(r + 1, nrows - 1)]) + 10 * I[r];
+  __syncthreads();
+
+  // expiry_seg.cpp:790-836: stripes of 15 rows, base_row in [y0 + 1, 254)
+  const int ncand = (CH - (SCH + 1)) - (y0 + 1);
+  unsigned key[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int idx = lane + 64 * j;
+    key[j] = 0u;
+    if (idx < ncand) {
+      const int b = 1 + idx;  // row index relative to y0
+      int sum = 0, mx = 0;
+      for (int k = 0; k < SCH; k++) {
+        const int v = line[b + k];
+        sum += v;
+        mx = imax(mx, v);
+      }
+      const int thr = mx / 2;
+      bool good = !(line[b] + line[b + 1] < thr) && !(line[b + SCH - 2] + line[b + SCH - 1] < thr);
+      for (int k = 0; k < SCH - 3; k++)
+        if (line[b + k + 1] < thr && line[b + k + 2] < thr) good = false;
+      if (good) key[j] = ((unsigned)sum << 7) | (unsigned)(127 - idx);
+    }
+  }
+  // descending by sum (ties: ascending base row), up to three that do not overlap (838-858)
+  int np = 0;
+  for (int round = 0; round < 3; round++) {
+    const unsigned m = wave_max_u32(key[0] > key[1] ? key[0] : key[1]);
+    if (m == 0u) break;
+    const int idx = 127 - (int)(m & 127u);
+    if (lane == 0) {
+      out[f].stripe_base_row[np] = y0 + 1 + idx;
+      out[f].stripe_sum[np] = (int64_t)(m >> 7);
+    }
+    np++;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      if (iabs(lane + 64 * j - idx) < SCH) key[j] = 0u;
+  }
+  if (lane == 0) out[f].n_stripes = np;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_expiry_seg: one wave per (frame, stripe)
+// ---------------------------------------------------------------------------------------------
+struct SegLds {
+  short sob[SOB_ROWS * SOB_STRIDE];  // |Scharr dx| rows base-3 .. base+17
+  int colA[432];                     // column sums over rows base .. base+16 (rect sums), later the pick map
+  int colB[432];                     // column sums over rows base-1 .. base+15 (regrid_group)
+  int rsum[432];                     // 9-wide sliding rect sums
+  int itemL[64], itemS[64];          // non-overlapping rects sorted by left
+  int gstart[66];
+  int gL[64], gW[64];                // surviving local groups
+  int rL[64], rS[64];                // regridded rects of the current group
+  int cLeft[64], cTop[64];           // optimised character rects of the current group
+  int scratch[64 * 21];              // per-lane column / row sums of optimize_character_rects
+  float xs[176];
+  float hid[80];
+};
+
+// |p[c+1] - p[c-1]| of the four pixels of dword d of a row, column index clamped (sobel.cpp:729-734)
+__device__ __forceinline__ void scharr_inter4(const uint32_t *__restrict__ row, int d, int v[4]) {
+  const uint32_t cur = row[d];
+  const uint32_t prev = d > 0 ? row[d - 1] : 0u;
+  const uint32_t next = d < 106 ? row[d + 1] : 0u;
+  const uint32_t left = d > 0 ? __builtin_amdgcn_alignbyte(cur, prev, 3) : ((cur << 8) | (cur & 0xFFu));
+  const uint32_t right = d < 106 ? __builtin_amdgcn_alignbyte(next, cur, 1) : ((cur >> 8) | (cur & 0xFF000000u));
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = iabs((int)((right >> (8 * k)) & 255u) - (int)((left >> (8 * k)) & 255u));
+}
+
+// strip_group_white_space (expiry_seg.cpp:101-129) on the index range [s, e) of a sum array
+__device__ __forceinline__ void strip_white_space(const int *__restrict__ sums, int &s, int &e) {
+  while (e - s > 5) {
+    const int idx = s + (e - s - 4) / 2;
+    const long long q = ((long long)sums[idx] + sums[idx + 1] + sums[idx + 2] + sums[idx + 3]) / 4;
+    const long long thr = (long long)((double)q * 0.8);
+    if ((long long)sums[s] < thr) s++;
+    else if ((long long)sums[e - 1] < thr) e--;
+    else break;
+  }
+}
+
+// the value cvNormalize(255, CV_C) + cvThreshold(100, TOZERO) leave for a Scharr sample
+__device__ __forceinline__ int norm_thresh(int v, float scale) {
+  const int iv = __float2int_rn((float)v * scale);
+  return iv > 100 ? iv : 0;
+}
+
+__global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                   const uint8_t *__restrict__ cards, size_t card_stride, int n,
+                                                   const dmz_hip_frame_result *__restrict__ results,
+                                                   const dmz_hip_expiry_result *__restrict__ er,
+                                                   DmzExpiryStage *__restrict__ stage) {
+  const int f = blockIdx.x / 3, st = blockIdx.x - f * 3, lane = threadIdx.x;
+  if (f >= n) return;
+  if (st >= er[f].n_stripes) return;
+  __shared__ SegLds L;
+  const int base = er[f].stripe_base_row[st];
+  const long long stripe_sum = er[f].stripe_sum[st];
+  const int y0 = results[f].vseg_y_offset + kNumberHeight;
+  const uint8_t *card = cards + (size_t)f * card_stride;
+  DmzExpiryStage *sg = stage + (size_t)f * 3 + st;
+  int n_emitted = 0;
+
+  // ---- |Scharr dx| of rows base-3 .. base+17 (zero outside the ROI [y0, 269]) ----
+  {
+    const int d0 = lane, d1 = lane + 64;
+    const bool has1 = d1 < 107;
+    int ia[2][4], ib[2][4], ic[2][4];
+#pragma unroll
+    for (int t = 0; t < SOB_ROWS + 2; t++) {
+      const int rowc = imin(imax(base - 4 + t, y0), CH - 1);
+      const uint32_t *row = (const uint32_t *)(card + (size_t)rowc * CW);
+      scharr_inter4(row, d0, ic[0]);
+      if (has1) scharr_inter4(row, d1, ic[1]);
+      if (t >= 2) {
+        const int k = t - 2, R = base - 3 + k;
+        const bool valid = R >= y0 && R <= CH - 1;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          if (h == 1 && !has1) break;
+          int v[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) v[q] = valid ? 3 * (ia[h][q] + ic[h][q]) + 10 * ib[h][q] : 0;
+          uint32_t *dst = (uint32_t *)(L.sob + k * SOB_STRIDE + 4 * (h ? d1 : d0));
+          dst[0] = (uint32_t)(v[0] & 0xFFFF) | ((uint32_t)v[1] << 16);
+          dst[1] = (uint32_t)(v[2] & 0xFFFF) | ((uint32_t)v[3] << 16);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          ia[h][q] = ib[h][q];
+          ib[h][q] = ic[h][q];
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- column sums, sliding 9-wide rect sums (expiry_seg.cpp:456-486) ----
+  for (int c = lane; c < CW; c += 64) {
+    int a = 0;
+    for (int k = 3; k <= 19; k++) a += L.sob[k * SOB_STRIDE + c];
+    L.colA[c] = a;
+    L.colB[c] = a + L.sob[2 * SOB_STRIDE + c] - L.sob[19 * SOB_STRIDE + c];
+  }
+  __syncthreads();
+  for (int c = lane; c < CW - SCW + 1; c += 64) {
+    int s = 0;
+    for (int k = 0; k < SCW; k++) s += L.colA[c + k];
+    L.rsum[c] = s;
+  }
+  __syncthreads();
+
+  // thresholds (expiry_seg.cpp:447-449, 488-494): the float total is accumulated in column order
+  const float thr1 = (float)(((stripe_sum * SCW) / CW) / 5);
+  float total = 0.0f;
+  int cnt = 0;
+  for (int c = 0; c < CW - SCW + 1; c++) {
+    const float s = (float)L.rsum[c];
+    if (s > thr1) {
+      total += s;
+      cnt++;
+    }
+  }
+  if (cnt == 0) return;
+  const float avg = total / (float)cnt;
+  const float thr2 = (float)(0.8 * (double)avg);
+
+  // ---- greedy non-overlapping pick in descending sum order (expiry_seg.cpp:496-529) ----
+  unsigned key[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const int c = lane + 64 * j;
+    key[j] = 0u;
+    if (c < CW - SCW + 1) {
+      const int s = L.rsum[c];
+      if ((float)s > thr1 && (float)s > thr2) key[j] = ((unsigned)s << 9) | (unsigned)(511 - c);
+    }
+  }
+  for (int c = lane; c < 432; c += 64) L.colA[c] = 0;  // pick map: sum of the rect picked at column c
+  __syncthreads();
+  for (;;) {
+    unsigned m = key[0];
+#pragma unroll
+    for (int j = 1; j < 7; j++) m = key[j] > m ? key[j] : m;
+    m = wave_max_u32(m);
+    if (m == 0u) break;
+    const int pl = 511 - (int)(m & 511u);
+    if (lane == 0) L.colA[pl] = (int)(m >> 9);
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+      if (iabs(lane + 64 * j - pl) < SCW) key[j] = 0u;  // either end would hit the mask
+  }
+  __syncthreads();
+  // sorted by left = column order
+  int n_items = 0;
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const int c = lane + 64 * j;
+    const int s = c < CW ? L.colA[c] : 0;
+    const unsigned long long bal = __ballot(s != 0);
+    if (s != 0) {
+      const int pos = n_items + __popcll(bal & lanemask_lt(lane));
+      L.itemL[pos] = c;
+      L.itemS[pos] = s;
+    }
+    n_items += __popcll(bal);
+  }
+  __syncthreads();
+  if (n_items == 0) return;
+
+  // ---- gather_into_groups (131-167): chain while the gap is < 9; then strip white space ----
+  int n_groups;
+  {
+    const int myL = lane < n_items ? L.itemL[lane] : 0;
+    const int prevL = __shfl_up(myL, 1, 64);
+    const bool boundary = lane < n_items && (lane == 0 || myL - (prevL + SCW) >= SCW);
+    const unsigned long long bal = __ballot(boundary);
+    n_groups = __popcll(bal);
+    if (boundary) L.gstart[__popcll(bal & lanemask_lt(lane))] = lane;
+    if (lane == 0) L.gstart[n_groups] = n_items;
+  }
+  __syncthreads();
+  int G;
+  {
+    int s = 0, e = 0;
+    bool keep = false;
+    if (lane < n_groups) {
+      s = L.gstart[lane];
+      e = L.gstart[lane + 1];
+      strip_white_space(L.itemS, s, e);
+      keep = e - s >= 4;  // kMinimumExpiryStripCharacters - 1 (expiry_seg.cpp:566-571)
+    }
+    const unsigned long long bal = __ballot(keep);
+    G = __popcll(bal);
+    if (keep) {
+      const int pos = __popcll(bal & lanemask_lt(lane));
+      L.gL[pos] = L.itemL[s];
+      L.gW[pos] = L.itemL[e - 1] + SCW - L.itemL[s];
+    }
+  }
+  __syncthreads();
+
+  const int g_top = base - 1;  // expanded stripe top; group height 17
+  for (int g = 0; g < G; g++) {
+    // ---- regrid_group (169-229) ----
+    const int left = L.gL[g], width = L.gW[g];
+    const int bl = imax(left - 2 * SCW, 0), br = imin(left + width + 2 * SCW, CW);
+    const int bw = br - bl;
+    const int min_lines = (int)floorf((float)bw / 11.0f);
+    int gs = 0;
+    for (int c = bl + lane; c < br; c += 64) gs += L.colB[c];
+    const float group_sum = (float)wave_sum_i32(gs);
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int q = lane + 64 * pass;
+      if (q <= 64) {
+        int sp, so;
+        if (q < 11) sp = 11, so = q;
+        else if (q < 23) sp = 12, so = q - 11;
+        else if (q < 36) sp = 13, so = q - 23;
+        else if (q < 50) sp = 14, so = q - 36;
+        else sp = 15, so = q - 50;
+        float gls = 0.0f;
+        int nl = 0;
+        for (int off = so; off < bw; off += sp) {
+          nl++;
+          gls += (float)L.colB[bl + off];
+        }
+        const float average = gls / (float)nl;
+        gls = average * (float)min_lines;
+        const float ratio = gls / (group_sum - gls);
+        if (ratio < FLT_MAX) {  // false for NaN / inf: such a candidate never replaces the best
+          unsigned u = __float_as_uint(ratio);
+          u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+          const unsigned long long k = ((unsigned long long)u << 32) | (unsigned)q;
+          best = k < best ? k : best;
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    int sp = 11, so = 0;
+    if (best != ~0ull) {
+      const int q = (int)(best & 0xFFFFFFFFull);
+      if (q < 11) sp = 11, so = q;
+      else if (q < 23) sp = 12, so = q - 11;
+      else if (q < 36) sp = 13, so = q - 23;
+      else if (q < 50) sp = 14, so = q - 36;
+      else sp = 15, so = q - 50;
+    }
+    int nR;
+    {
+      const int off = so + lane * sp;
+      const bool ok = off + 1 < bw;
+      if (ok) {
+        int s = 0;
+        const int cend = imin(off + sp, bw);
+        for (int c = off + 1; c < cend; c++) s += L.colB[bl + c];
+        L.rL[lane] = bl + off + 1;
+        L.rS[lane] = s;
+      }
+      nR = __popcll(__ballot(ok));
+    }
+    __syncthreads();
+    const int cw = sp - 1;
+    int rs = 0, re = nR;
+    strip_white_space(L.rS, rs, re);
+
+    // ---- optimize_character_rects (231-339): lane = character rect ----
+    const int ciw = cw + 4, cih = 17 + 4;
+    bool keep = false;
+    int c_left = 0, c_top = 0;
+    if (lane >= rs && lane < re) {
+      const int rect_left = L.rL[lane] - 2, rect_top = g_top - 2;  // rect_top == base - 3 == sob row 0
+      if (!(rect_left < 0 || rect_left + ciw > CW || rect_top + cih > CH)) {
+        keep = true;
+        int mx = 0;
+        for (int r = 0; r < cih; r++)
+          for (int c = 0; c < ciw; c++) mx = imax(mx, (int)L.sob[r * SOB_STRIDE + rect_left + c]);
+        const float scale = mx > 0 ? (float)(255.0 / (double)mx) : 0.0f;
+        int *my = L.scratch + lane * 21;
+        for (int c = 0; c < ciw; c++) {
+          int s = 0;
+          for (int r = 0; r < cih; r++) s += norm_thresh(L.sob[r * SOB_STRIDE + rect_left + c], scale);
+          my[c] = s;
+        }
+        int lc = 0, rc = ciw - 1;
+        for (int wv = ciw; wv > TW; wv--) {
+          if (my[lc] <= my[rc]) lc++;
+          else rc--;
+        }
+        for (int r = 0; r < cih; r++) {
+          int s = 0;
+          for (int c = lc; c <= rc; c++) s += norm_thresh(L.sob[r * SOB_STRIDE + rect_left + c], scale);
+          my[r] = s;
+        }
+        int tr = 0, brw = cih - 1;
+        for (int hv = cih; hv > TH; hv--) {
+          if (my[tr] <= my[brw]) tr++;
+          else brw--;
+        }
+        c_left = rect_left + lc;
+        c_top = rect_top + tr;
+      }
+    }
+    const unsigned long long kbal = __ballot(keep);
+    const int n2 = __popcll(kbal);
+    if (keep) {
+      const int pos = __popcll(kbal & lanemask_lt(lane));
+      L.cLeft[pos] = c_left;
+      L.cTop[pos] = c_top;
+    }
+    __syncthreads();
+    if (n2 < 5) continue;  // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623)
+
+    // ---- slash search (643-674): character first+2 of every window of five ----
+    for (int p = 2; p + 2 < n2; p++) {
+      const int pl = L.cLeft[p], pt = L.cTop[p] - (base - 3);
+      for (int i = lane; i < TW * TH; i += 64) {
+        const int r = i / TW, c = i - r * TW;
+        L.xs[i] = (float)L.sob[(pt + r) * SOB_STRIDE + pl + c] * (1.0f / 255.0f);
+      }
+      __syncthreads();
+      // applym_730c4cbd: 176 -> 80 tanh -> 2 softmax; sequential dot products
+      {
+        const float *w1t = xw + dmzx::SLASH_W1T;
+        const int j1 = imin(64 + lane, 79);
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int i = 0; i < 176; i++) {
+          const float xi = L.xs[i];
+          s0 += w1t[i * 80 + lane] * xi;
+          s1 += w1t[i * 80 + j1] * xi;
+        }
+        const float *sw = wts + dmzw::SLASH;
+        L.hid[lane] = tanhf(s0 + sw[dmzw::S_B1 + lane]);
+        if (lane < 16) L.hid[64 + lane] = tanhf(s1 + sw[dmzw::S_B1 + 64 + lane]);
+      }
+      __syncthreads();
+      float e = 0.0f;
+      if (lane < 2) {
+        const float *sw = wts + dmzw::SLASH;
+        float s = 0.0f;
+        for (int j = 0; j < 80; j++) s += sw[dmzw::S_W2 + lane * 80 + j] * L.hid[j];
+        e = expf(s + sw[dmzw::S_B2 + lane]);
+      }
+      const float e0 = __shfl(e, 0, 64), e1 = __shfl(e, 1, 64);
+      const float p0 = e0 / (e0 + e1);
+      if (p0 > 0.7f) {
+        if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
+          const int first = p - 2;
+          int top = L.cTop[first], gleft = L.cLeft[first], gwidth = SCW, gheight = SCH;
+          for (int i = 0; i < 5; i++) {
+            const int ct = L.cTop[first + i], cl = L.cLeft[first + i];
+            const int former_bottom = top + gheight;
+            top = imin(ct, top);
+            gwidth = (cl + SCW) - gleft;
+            gheight = imax(ct + SCH, former_bottom) - top;
+          }
+          short *h = sg->hdr[n_emitted];
+          h[0] = (short)top, h[1] = (short)gleft, h[2] = (short)gwidth, h[3] = (short)gheight;
+          for (int i = 0; i < 5; i++) {
+            h[4 + i] = (short)L.cTop[first + i];
+            h[9 + i] = (short)L.cLeft[first + i];
+          }
+          h[14] = (short)base;
+          h[15] = 0;
+        }
+        n_emitted++;
+      }
+      __syncthreads();
+    }
+  }
+  if (lane == 0) sg->n = n_emitted;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Expiry digit CNN (applyc_bf4dd6c8) for up to four 16x11 inputs resident in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int XC_THREADS = 256;
+constexpr int XIN_W = 19, XIN_H = 24;  // zero-padded input: 4 rows/cols of padding before, 4/4 after
+struct CatLds {
+  float l1[4 * 50 * 70];        // 56,000 B; prep-time scratch overlays it
+  float xin[4 * XIN_H * XIN_W]; // 7,296 B
+  float xf[4 * 176];
+  float l2[4 * 120];
+  float l3[4 * 176];
+  float es[4 * 16];
+  float mean[4];
+  short hdr[DMZ_HIP_EXPIRY_MAX_GROUPS][16];
+  int n_groups;
+};
+
+__device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar redux order (Redux.h:77-90)
+  const float a = (v[0] + v[1]) + (v[2] + (v[3] + v[4]));
+  const float b = (v[5] + v[6]) + (v[7] + (v[8] + v[9]));
+  return a + b;
+}
+
+// xf[nd][176] raw inputs -> scores (global, nd x 10 floats at `out`, row stride 10)
+__device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__restrict__ xw, CatLds &S, int nd,
+                                 float *__restrict__ out, int tid) {
+  const float *xm = wts + dmzw::EXPIRY;
+  // modelc_bf4dd6c8.cpp:13459: subtract the mean (sequential 176-term sum)
+  if (tid < nd) {
+    const float *x = S.xf + tid * 176;
+    float m = x[0];
+    for (int i = 1; i < 176; i++) m = m + x[i];
+    S.mean[tid] = m / 176.0f;
+  }
+  __syncthreads();
+  for (int i = tid; i < nd * 176; i += XC_THREADS) {
+    const int d = i / 176, p = i - d * 176, r = p / 11, c = p - r * 11;
+    S.xin[d * XIN_H * XIN_W + (r + 4) * XIN_W + (c + 4)] = S.xf[i] - S.mean[d];
+  }
+  __syncthreads();
+  // layer 1: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU
+  if (tid < 50 * nd) {
+    const int d = tid / 50, k = tid - d * 50;
+    float w[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) w[i] = xm[dmzw::X_C1W + k * 25 + i];
+    const float bias = xm[dmzw::X_C1B + k];
+    const float *xi = S.xin + d * XIN_H * XIN_W;
+    float *o = S.l1 + (d * 50 + k) * 70;
+    for (int pr = 0; pr < 10; pr++)
+      for (int pc = 0; pc < 7; pc++) {
+        float patch[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b < 6; b++) patch[a][b] = xi[(2 * pr + a) * XIN_W + 2 * pc + b];
+        float m = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+              for (int j = 0; j < 5; j++) s = fmaf(w[i * 5 + j], patch[a + i][b + j], s);
+            m = (a == 0 && b == 0) ? s : fmaxf(m, s);
+          }
+        const float v = m + bias;
+        o[pr * 7 + pc] = v > 0.0f ? v : 0.0f;
+      }
+  }
+  __syncthreads();
+  // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU
+  if (tid < 40 * nd) {
+    const int d = tid / 40, k = tid - d * 40;
+    const float *c2t = xw + dmzx::CONV2_T;
+    float acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) acc[i] = 0.0f;
+    for (int m = 0; m < 50; m++) {
+      float in[70];
+      const float2 *src = (const float2 *)(S.l1 + (d * 50 + m) * 70);
+#pragma unroll
+      for (int i = 0; i < 35; i++) {
+        const float2 t = src[i];
+        in[2 * i] = t.x;
+        in[2 * i + 1] = t.y;
+      }
+      float w[25];
+#pragma unroll
+      for (int i = 0; i < 25; i++) w[i] = c2t[(m * 25 + i) * 40 + k];
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[r * 3 + c] = fmaf(w[i * 5 + j], in[(r + i) * 7 + c + j], acc[r * 3 + c]);
+    }
+    const float bias = xm[dmzw::X_C2B + k];
+#pragma unroll
+    for (int pr = 0; pr < 3; pr++) {
+      float m = acc[(2 * pr) * 3];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) m = fmaxf(m, acc[(2 * pr + a) * 3 + b]);
+      const float v = m + bias;
+      S.l2[d * 120 + k * 3 + pr] = v > 0.0f ? v : 0.0f;
+    }
+  }
+  __syncthreads();
+  // FC 120 -> 176, ReLU
+  {
+    const float *fc1t = xw + dmzx::FC1_T;
+    for (int idx = tid; idx < nd * 176; idx += XC_THREADS) {
+      const int d = idx / 176, j = idx - d * 176;
+      const float *l2 = S.l2 + d * 120;
+      float s = 0.0f;
+      for (int i = 0; i < 120; i++) s = fmaf(fc1t[i * 176 + j], l2[i], s);
+      const float v = s + xm[dmzw::X_HB + j];
+      S.l3[idx] = v > 0.0f ? v : 0.0f;
+    }
+  }
+  __syncthreads();
+  // FC 176 -> 10, softmax
+  if (tid < nd * 10) {
+    const int d = tid / 10, k = tid - d * 10;
+    const float *lw = xm + dmzw::X_LW + k * 176;
+    const float *l3 = S.l3 + d * 176;
+    float s = 0.0f;
+    for (int i = 0; i < 176; i++) s = fmaf(lw[i], l3[i], s);
+    S.es[d * 16 + k] = expf(s + xm[dmzw::X_LB + k]);
+  }
+  __syncthreads();
+  if (tid < nd * 10) {
+    const int d = tid / 10, k = tid - d * 10;
+    out[d * 10 + k] = S.es[d * 16 + k] / tree_sum10(S.es + d * 16);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(XC_THREADS) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                           const DmzExpiryTables *__restrict__ tab,
+                                                           const uint8_t *__restrict__ cards, size_t card_stride,
+                                                           int n, const dmz_hip_frame_result *__restrict__ results,
+                                                           const DmzExpiryStage *__restrict__ stage,
+                                                           dmz_hip_expiry_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  CatLds &S = *(CatLds *)smem_raw;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (f >= n) return;
+  dmz_hip_expiry_result *er = out + f;
+  const int n_stripes = er->n_stripes;
+  if (n_stripes == 0) return;
+  // ---- merge the per-stripe staging in stripe order (FrameScanResult.expiry_groups order) ----
+  {
+    int cnt[3], tot = 0;
+    for (int s = 0; s < 3; s++) {
+      cnt[s] = s < n_stripes ? stage[(size_t)f * 3 + s].n : 0;
+      tot += cnt[s];
+    }
+    if (tid < 24) {
+      const int s = tid >> 3, i = tid & 7;
+      int pos = i;
+      for (int q = 0; q < s; q++) pos += imin(cnt[q], DMZ_HIP_EXPIRY_MAX_GROUPS);
+      if (i < imin(cnt[s], DMZ_HIP_EXPIRY_MAX_GROUPS) && pos < DMZ_HIP_EXPIRY_MAX_GROUPS) {
+        const short *h = stage[(size_t)f * 3 + s].hdr[i];
+        short *dst = (short *)&er->groups[pos];
+        for (int q = 0; q < 16; q++) {
+          dst[q] = h[q];
+          S.hdr[pos][q] = h[q];
+        }
+      }
+    }
+    if (tid == 0) {
+      er->n_found = tot;
+      er->n_groups = imin(tot, DMZ_HIP_EXPIRY_MAX_GROUPS);
+      S.n_groups = imin(tot, DMZ_HIP_EXPIRY_MAX_GROUPS);
+    }
+  }
+  if (!(results[f].flags & DMZ_HIP_FLAG_USABLE)) return;  // scan.cpp:57-59
+  if (tid == 0) er->categorised = 1;
+  for (int i = tid; i < 4 * XIN_H * XIN_W; i += XC_THREADS) S.xin[i] = 0.0f;
+  __syncthreads();
+  const int n_groups = S.n_groups;
+  const uint8_t *card = cards + (size_t)f * card_stride;
+  // prep scratch over l1 (dead until the first convolution)
+  unsigned char *gp = (unsigned char *)S.l1;               // 4 x 176 gradient / equalised patch
+  unsigned char *sm = gp + 4 * 176;                        // 4 x 176 smoothed
+  unsigned int *hist = (unsigned int *)(gp + 2 * 4 * 176); // 4 x 256
+  for (int g = 0; g < n_groups; g++) {
+    // ---- prepare_image_for_cat (expiry_categorize.cpp:35-70): wave d = character d ----
+    const int d = wave, ci = d < 2 ? d : d + 1;
+    const int left = S.hdr[g][9 + ci], top = S.hdr[g][4 + ci];
+    const uint8_t *roi = card + (size_t)top * CW + left;
+    for (int i = lane; i < 256; i += 64) hist[d * 256 + i] = 0u;
+    __syncthreads();
+    for (int p = lane; p < 176; p += 64) {
+      const int r = p / TW, c = p - r * TW;
+      const int ru = r > 0 ? r - 1 : r, rd = r < TH - 1 ? r + 1 : r;
+      const int cl = c > 0 ? c - 1 : c, cr = c < TW - 1 ? c + 1 : c;
+      const int nn = roi[ru * CW + c], ww = roi[r * CW + cl], cc = roi[r * CW + c], ee = roi[r * CW + cr],
+                ss = roi[rd * CW + c];
+      const int gv = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
+      gp[d * 176 + p] = (unsigned char)gv;
+      atomicAdd(&hist[d * 256 + gv], 1u);
+    }
+    __syncthreads();
+    {  // llcv_equalize_hist LUT (stats.cpp:135-151): 4 bins per lane
+      unsigned int *h = hist + d * 256;
+      const int h0 = (int)h[lane * 4 + 0], h1 = (int)h[lane * 4 + 1], h2 = (int)h[lane * 4 + 2], h3 = (int)h[lane * 4 + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int incl = tot;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      const int excl = incl - tot;
+      const float scale = 255.f / (TW * TH);
+      const int c0 = excl + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
+      int l0 = __float2int_rn((float)c0 * scale), l1 = __float2int_rn((float)c1 * scale),
+          l2 = __float2int_rn((float)c2 * scale), l3 = __float2int_rn((float)c3 * scale);
+      l0 = imin(255, imax(0, l0)), l1 = imin(255, imax(0, l1)), l2 = imin(255, imax(0, l2)), l3 = imin(255, imax(0, l3));
+      if (lane == 0) l0 = 0;
+      __syncthreads();
+      h[lane * 4 + 0] = (unsigned)l0, h[lane * 4 + 1] = (unsigned)l1, h[lane * 4 + 2] = (unsigned)l2, h[lane * 4 + 3] = (unsigned)l3;
+    }
+    __syncthreads();
+    for (int p = lane; p < 176; p += 64) gp[d * 176 + p] = (unsigned char)hist[d * 256 + gp[d * 176 + p]];
+    __syncthreads();
+    // cv::bilateralFilter(d = 3, BORDER_REPLICATE), generic accumulation order
+    for (int p = lane; p < 176; p += 64) {
+      const int r = p / TW, c = p - r * TW;
+      const unsigned char *e = gp + d * 176;
+      const int val0 = e[p];
+      const int rr[5] = {imax(r - 1, 0), r, r, r, imin(r + 1, TH - 1)};
+      const int cq[5] = {c, imax(c - 1, 0), c, imin(c + 1, TW - 1), c};
+      float sum = 0.0f, wsum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int val = e[rr[k] * TW + cq[k]];
+        const float w = tab->space_weight[k] * tab->color_weight[iabs(val - val0)];
+        sum += (float)val * w;
+        wsum += w;
+      }
+      sm[d * 176 + p] = (unsigned char)__float2int_rn(sum / wsum);
+    }
+    __syncthreads();
+    for (int p = lane; p < 176; p += 64) S.xf[d * 176 + p] = (float)sm[d * 176 + p] * (1.0f / 255.0f);
+    __syncthreads();
+    expiry_cnn_block(wts, xw, S, 4, &er->groups[g].scores[0][0], tid);
+  }
+}
+
+// applym_730c4cbd on n inputs (known-answer tests): one wave per input
+__global__ __launch_bounds__(64) void k_slash_model(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                    const float *__restrict__ x, int n, float *__restrict__ out) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n) return;
+  __shared__ float xs[176], hid[80];
+  for (int k = lane; k < 176; k += 64) xs[k] = x[(size_t)i * 176 + k];
+  __syncthreads();
+  const float *w1t = xw + dmzx::SLASH_W1T;
+  const float *sw = wts + dmzw::SLASH;
+  const int j1 = imin(64 + lane, 79);
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int k = 0; k < 176; k++) {
+    s0 += w1t[k * 80 + lane] * xs[k];
+    s1 += w1t[k * 80 + j1] * xs[k];
+  }
+  hid[lane] = tanhf(s0 + sw[dmzw::S_B1 + lane]);
+  if (lane < 16) hid[64 + lane] = tanhf(s1 + sw[dmzw::S_B1 + 64 + lane]);
+  __syncthreads();
+  float e = 0.0f;
+  if (lane < 2) {
+    float s = 0.0f;
+    for (int j = 0; j < 80; j++) s += sw[dmzw::S_W2 + lane * 80 + j] * hid[j];
+    e = expf(s + sw[dmzw::S_B2 + lane]);
+  }
+  const float e0 = __shfl(e, 0, 64), e1 = __shfl(e, 1, 64);
+  if (lane < 2) out[(size_t)i * 2 + lane] = e / (e0 + e1);
+}
+
+// applyc_bf4dd6c8 on n inputs, four per workgroup
+__global__ __launch_bounds__(XC_THREADS) void k_expiry_model(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                             const float *__restrict__ x, int n, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  CatLds &S = *(CatLds *)smem_raw;
+  const int tid = threadIdx.x, first = blockIdx.x * 4;
+  const int nd = imin(4, n - first);
+  if (nd <= 0) return;
+  for (int i = tid; i < 4 * XIN_H * XIN_W; i += XC_THREADS) S.xin[i] = 0.0f;
+  for (int i = tid; i < nd * 176; i += XC_THREADS) S.xf[i] = x[(size_t)first * 176 + i];
+  __syncthreads();
+  expiry_cnn_block(wts, xw, S, nd, out + (size_t)first * 10, tid);
+}
+
+}  // namespace
+
+int dmz_configure_expiry(void) {
+  hipError_t e = hipFuncSetAttribute((const void *)k_expiry_cat, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(CatLds));
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void *)k_expiry_model, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CatLds));
+  return (int)e;
+}
+
+void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, const DmzExpiryTables *tables,
+                       const uint8_t *cards, size_t card_stride, int n, const dmz_hip_frame_result *results,
+                       DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid) {
+  hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
+  hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), 0, s, weights, xw, cards, card_stride, n, results,
+                     out, stage);
+  if (mid) (void)hipEventRecord(mid, s);
+  hipLaunchKernelGGL(k_expiry_cat, dim3((unsigned)n), dim3(XC_THREADS), sizeof(CatLds), s, weights, xw, tables, cards,
+                     card_stride, n, results, stage, out);
+}
+
+void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out) {
+  hipLaunchKernelGGL(k_slash_model, dim3((unsigned)n), dim3(64), 0, s, weights, xw, x, n, out);
+}
+
+void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out) {
+  hipLaunchKernelGGL(k_expiry_model, dim3((unsigned)((n + 3) / 4)), dim3(XC_THREADS), sizeof(CatLds), s, weights, xw, x,
+                     n, out);
+}

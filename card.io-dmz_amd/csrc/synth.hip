@@ -19,7 +19,8 @@ struct SynthParams {
   int bg, card, ink, rim, noise_bg, noise_card, x0, y0, pitch;
   uint32_t key_frame, key_card;
   uint8_t digits[16];
-  int pad_;
+  int ex0, ey0, epitch;
+  uint8_t exp_digits[4];
 };
 
 uint64_t splitmix64(uint64_t *s) {
@@ -89,7 +90,15 @@ void make_params(uint64_t seed, uint64_t frame, SynthParams *p) {
   p->digits[15] = (uint8_t)((10 - sum % 10) % 10);
   p->key_frame = hash32((uint32_t)(seed * 0x9E3779B1u) ^ hash32((uint32_t)frame) ^ (uint32_t)(frame >> 32));
   p->key_card = p->key_frame ^ 0x5bd1e995u;
-  p->pad_ = 0;
+  // expiry line "MM/YY" (orc_synth.c make_params: same draws in the same order)
+  p->ex0 = 190 * 16 + (int)(splitmix64(&s) % 257) - 128;
+  p->ey0 = 206 * 16 + (int)(splitmix64(&s) % 129) - 64;
+  p->epitch = 13 * 16 + (int)(splitmix64(&s) % 17) - 8;
+  const int month = 1 + (int)(splitmix64(&s) % 12), year = 27 + (int)(splitmix64(&s) % 4);
+  p->exp_digits[0] = (uint8_t)(month / 10);
+  p->exp_digits[1] = (uint8_t)(month % 10);
+  p->exp_digits[2] = (uint8_t)(year / 10);
+  p->exp_digits[3] = (uint8_t)(year % 10);
 }
 
 __constant__ short c_seg[7][4] = {
@@ -97,6 +106,11 @@ __constant__ short c_seg[7][4] = {
     {14 * 16, 12 * 16, 17 * 16, 24 * 16}, {2 * 16, 22 * 16, 15 * 16, 25 * 16},
     {0 * 16, 12 * 16, 3 * 16, 24 * 16},  {0 * 16, 1 * 16, 3 * 16, 13 * 16},
     {2 * 16, 11 * 16, 15 * 16, 14 * 16},
+};
+__constant__ short c_seg_small[7][4] = {
+    {1 * 16, 0 * 16, 8 * 16, 2 * 16},   {7 * 16, 1 * 16, 9 * 16, 8 * 16},  {7 * 16, 7 * 16, 9 * 16, 14 * 16},
+    {1 * 16, 13 * 16, 8 * 16, 15 * 16}, {0 * 16, 7 * 16, 2 * 16, 14 * 16}, {0 * 16, 1 * 16, 2 * 16, 8 * 16},
+    {1 * 16, 104, 8 * 16, 136},
 };
 __constant__ unsigned char c_digit_segs[10] = {0x3F, 0x06, 0x5B, 0x4F, 0x66, 0x6D, 0x7D, 0x07, 0x7F, 0x6F};
 
@@ -107,18 +121,29 @@ __device__ __forceinline__ int noise_at(uint32_t key, int x, int y) {
   return (int)(h & 255) + (int)((h >> 8) & 255) + (int)((h >> 16) & 255) + (int)(h >> 24) - 510;
 }
 
-__device__ int stroke_cov(int segs, int px, int py) {
+template <bool SMALL>
+__device__ int stroke_cov_tab(int segs, int px, int py) {
   int best = 0;
   for (int s = 0; s < 7; s++) {
     if (!(segs & (1 << s))) continue;
-    const int ax = px - c_seg[s][0], bx = c_seg[s][2] - px;
-    const int ay = py - c_seg[s][1], by = c_seg[s][3] - py;
+    const short *sg = SMALL ? c_seg_small[s] : c_seg[s];
+    const int ax = px - sg[0], bx = sg[2] - px;
+    const int ay = py - sg[1], by = sg[3] - py;
     const int cx = clampi((ax < bx ? ax : bx) + 8, 0, 16);
     const int cy = clampi((ay < by ? ay : by) + 8, 0, 16);
     const int c = cx * cy;
     if (c > best) best = c;
   }
   return best;
+}
+__device__ int stroke_cov(int segs, int px, int py) { return stroke_cov_tab<false>(segs, px, py); }
+
+__device__ int slash_cov(int px, int py) {
+  const int xl = 24 + ((240 - py) * 96) / 240;
+  const int dx = px - xl < 0 ? xl - px : px - xl;
+  const int cx = clampi(16 - dx + 8, 0, 16);
+  const int cy = clampi((py < 240 - py ? py : 240 - py) + 8, 0, 16);
+  return cx * cy;
 }
 
 __device__ int card_delta(const SynthParams &p, int U, int V) {
@@ -137,6 +162,30 @@ __device__ int card_delta(const SynthParams &p, int U, int V) {
         const int c0 = stroke_cov(segs, lx, ry);
         const int c1 = stroke_cov(segs, lx + 16, ry + 16);
         const int c2 = stroke_cov(segs, lx - 16, ry - 16);
+        d += (p.ink * c0) >> 8;
+        d += (p.rim * (c1 - c0 > 0 ? c1 - c0 : 0)) >> 8;
+        d -= (p.rim * (c2 - c0 > 0 ? c2 - c0 : 0)) >> 8;
+      }
+    }
+  }
+  const int ey = V - p.ey0;
+  if (ey >= -32 && ey < 15 * 16 + 32) {
+    const int ex = U - p.ex0;
+    if (ex >= -32) {
+      const int slot = (ex + 32) / p.epitch;
+      if (slot < 5) {
+        const int lx = ex - slot * p.epitch;
+        int c0, c1, c2;
+        if (slot == 2) {
+          c0 = slash_cov(lx, ey);
+          c1 = slash_cov(lx + 16, ey + 16);
+          c2 = slash_cov(lx - 16, ey - 16);
+        } else {
+          const int segs = c_digit_segs[p.exp_digits[slot > 2 ? slot - 1 : slot]];
+          c0 = stroke_cov_tab<true>(segs, lx, ey);
+          c1 = stroke_cov_tab<true>(segs, lx + 16, ey + 16);
+          c2 = stroke_cov_tab<true>(segs, lx - 16, ey - 16);
+        }
         d += (p.ink * c0) >> 8;
         d += (p.rim * (c1 - c0 > 0 ? c1 - c0 : 0)) >> 8;
         d -= (p.rim * (c2 - c0 > 0 ? c2 - c0 : 0)) >> 8;

@@ -80,6 +80,29 @@ typedef struct dmz_hip_frame_result {
 #define DMZ_HIP_FLAG_VSEG_OK 4     /* passed the vseg gates (frame.cpp:38-47) */
 #define DMZ_HIP_FLAG_WARPED 8      /* card image was rectified */
 
+/* ---- expiry path: scan/expiry_seg.h best_expiry_seg + the per-frame half of
+ * scan/expiry_categorize.cpp (categorize_expiry_digits, :138-160).  One record per frame; the
+ * groups are GroupedRects of pattern ExpiryPatternMMsYY (expiry_types.h:37-45,65-79) in the
+ * order the reference appends them to FrameScanResult.expiry_groups (frame.h:19). --------- */
+#define DMZ_HIP_EXPIRY_MAX_GROUPS 8
+typedef struct dmz_hip_expiry_group {
+  int16_t top, left, width, height;  /* GroupedRects.top/left/width/height (expiry_seg.cpp:651-668) */
+  int16_t char_top[5], char_left[5]; /* CharacterRect.top/left of the 5 characters (11 x 16 px each) */
+  int16_t stripe_base_row;           /* the stripe the group was found in */
+  int16_t reserved;
+  float scores[4][10];               /* ExpiryGroupScores rows 0,1,3,4 (M M / Y Y); 0 unless categorised */
+} dmz_hip_expiry_group;              /* 192 bytes */
+typedef struct dmz_hip_expiry_result {
+  int32_t n_groups;                  /* min(n_found, DMZ_HIP_EXPIRY_MAX_GROUPS) */
+  int32_t n_found;                   /* groups best_expiry_seg produced for this frame */
+  int32_t n_stripes;                 /* probable stripes tried (<= 3), expiry_seg.cpp:838-858 */
+  int32_t stripe_base_row[3];
+  int64_t stripe_sum[3];
+  int32_t categorised;               /* 1: frame was usable, scores are filled (scan.cpp:57-64) */
+  int32_t reserved;
+  dmz_hip_expiry_group groups[DMZ_HIP_EXPIRY_MAX_GROUPS];
+} dmz_hip_expiry_result;             /* 1592 bytes */
+
 /* dmz_hip_transform_batch / pipeline option bits */
 #define DMZ_HIP_OPT_TRUNCATE_CORNERS 1 /* cast corner points to int like cython_dmz/dmz.pyx:267-270 */
 
@@ -131,6 +154,21 @@ int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_
                            int options, uint8_t *cards, size_t card_stride,
                            dmz_hip_frame_result *results);
 
+/* Batched expiry scan of n 428x270 cards whose number path has already run (results[i] holds
+ * flags and vseg_y_offset): best_expiry_seg (expiry_seg.h:14, expiry_seg.cpp:707-902) for every
+ * frame that passed the vseg gates with y_offset < 240 (frame.cpp:71-73), then
+ * categorize_expiry_digits (expiry_categorize.cpp:138-160) for the usable ones (scan.cpp:57-64).
+ * cards and card_stride must be 4-byte aligned. */
+int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                              const dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry);
+
+/* dmz_hip_pipeline_batch followed by dmz_hip_scan_expiry_batch (scanner_add_frame_with_expiry
+ * with scan_expiry = true, scan.cpp:41-86 / BASELINE config 4). */
+int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride,
+                                  int row_stride, int width, int height, int n, int orientation,
+                                  int options, uint8_t *cards, size_t card_stride,
+                                  dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry);
+
 /* Single homography, llcv_calc_persp_transform (cv/warp.h:25, warp.cpp:34-125),
  * computed on the device with the same kernel code the batch path uses.
  * src_pts/dst_pts: 4 (x,y) pairs; m: 9 floats row-major (host pointers). */
@@ -150,6 +188,12 @@ int dmz_hip_apply_vseg_model(dmz_hip_context *ctx, const float *x /* n x 204 */,
                              float *out /* n x 3 */);
 int dmz_hip_apply_digit_model(dmz_hip_context *ctx, int model /* 0..2 */,
                               const float *x /* n x 27 x 19 */, int n, float *out /* n x 10 */);
+/* applym_730c4cbd (models/expiry/modelm_730c4cbd.hpp) and applyc_bf4dd6c8
+ * (models/expiry/modelc_bf4dd6c8.hpp): the slash MLP and the expiry digit CNN. */
+int dmz_hip_apply_slash_model(dmz_hip_context *ctx, const float *x /* n x 176 */, int n,
+                              float *out /* n x 2 */);
+int dmz_hip_apply_expiry_model(dmz_hip_context *ctx, const float *x /* n x 16 x 11 */, int n,
+                               float *out /* n x 10 */);
 
 /* Synthetic inputs resident in HBM (bench/test generator; byte-identical to
  * oracle/orc_synth.c).  Frames are 640x480, cards 428x270, tightly packed. */
@@ -165,7 +209,9 @@ int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_inde
 #define DMZ_HIP_STAGE_VSEG 3
 #define DMZ_HIP_STAGE_HSEG 4
 #define DMZ_HIP_STAGE_DIGITS 5
-#define DMZ_HIP_STAGE_COUNT 6
+#define DMZ_HIP_STAGE_EXPIRY_SEG 6
+#define DMZ_HIP_STAGE_EXPIRY_CAT 7
+#define DMZ_HIP_STAGE_COUNT 8
 int dmz_hip_set_profiling(dmz_hip_context *ctx, int enabled);
 /* ms[i] = accumulated milliseconds, launches[i] = launch count since the last reset. */
 int dmz_hip_get_stage_times(dmz_hip_context *ctx, float ms[DMZ_HIP_STAGE_COUNT],

@@ -153,6 +153,47 @@ void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets
                        float scores[160]);                                  /* n_categorize.cpp:75-107 */
 void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res); /* frame.cpp:24-81 (number path) */
 
+/* ---- expiry path: scan/expiry_seg.cpp, scan/expiry_categorize.cpp.
+ * Per-frame part only: segmentation into MM/YY groups and the four digit score rows of each
+ * group; the cross-frame aggregation (expiry_categorize.cpp:251-330) is session logic.
+ * Layout == dmz_hip_expiry_group / dmz_hip_expiry_result (include/dmz_hip.h). ------------- */
+#define ORC_EXPIRY_MAX_GROUPS 8
+typedef struct {
+  int16_t top, left, width, height;  /* GroupedRects of the 5 characters (expiry_seg.cpp:651-668) */
+  int16_t char_top[5], char_left[5]; /* the 11x16 trimmed character rects */
+  int16_t stripe_base_row;
+  int16_t reserved;
+  float scores[4][10];               /* characters 0,1,3,4 (M M / Y Y); zero when not categorised */
+} orc_expiry_group;                  /* 192 bytes */
+typedef struct {
+  int32_t n_groups;                  /* min(n_found, ORC_EXPIRY_MAX_GROUPS) */
+  int32_t n_found;                   /* groups the segmentation produced */
+  int32_t n_stripes;
+  int32_t stripe_base_row[3];
+  int64_t stripe_sum[3];
+  int32_t categorised;               /* 1 when scores were filled (frame usable) */
+  int32_t reserved;
+  orc_expiry_group groups[ORC_EXPIRY_MAX_GROUPS];
+} orc_expiry_result;                 /* 56 + 8*192 = 1592 bytes */
+
+/* sobel.cpp:706-804 (x86 scalar branch) on rows [y0, y0+h) of an 8U image, dst int16 same geometry */
+void orc_scharr3_dx_abs(const uint8_t *src, int stride, int w, int h, int16_t *dst, int dstride);
+/* expiry_seg.cpp:707-902 + 437-704: fills everything but the scores */
+void orc_best_expiry_seg(const uint8_t *card, int stride, int starting_y_offset, orc_expiry_result *out);
+/* expiry_categorize.cpp:35-70: 11x16 ROI -> gradient, equalise, bilateral, /255 */
+void orc_prepare_image_for_cat(const uint8_t *card, int stride, int left, int top, float x[176]);
+/* expiry_categorize.cpp:138-160 for every group of `out` (fills scores, sets categorised) */
+void orc_categorize_expiry_groups(const uint8_t *card, int stride, orc_expiry_result *out);
+/* frame.cpp:71-73 gate + scan.cpp:62-64 gate, given the number-path result of the same card */
+void orc_scan_card_expiry(const uint8_t *card, int stride, const orc_frame_result *res,
+                          orc_expiry_result *out);
+/* flat-array hooks onto gather_into_groups (expiry_seg.cpp:131-167) and regrid_group (169-229) */
+int orc_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *sums, int top, int height,
+                                  int *group_n, int *group_left, int *group_width, int *rect_left,
+                                  int64_t *rect_sum);
+void orc_expiry_regrid_group(const int16_t *sobel, int top, int height, int *left, int *width,
+                             int *character_width, int *n, int *rect_left, int64_t *rect_sum);
+
 /* ---- full per-frame pipeline: detect -> transform(Y) -> scan ---------------- */
 void orc_scan_frame(const uint8_t *y, int stride, int w, int h, int orientation,
                     int truncate_corners, uint8_t *card_out /* 428*270 or NULL */,

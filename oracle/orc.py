@@ -28,6 +28,22 @@ assert RESULT_DTYPE.itemsize == 1024
 
 FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
 
+# mirror of orc_expiry_group / orc_expiry_result == dmz_hip_expiry_group / dmz_hip_expiry_result
+EXPIRY_MAX_GROUPS = 8
+EXPIRY_GROUP_DTYPE = np.dtype([
+    ("top", "<i2"), ("left", "<i2"), ("width", "<i2"), ("height", "<i2"),
+    ("char_top", "<i2", (5,)), ("char_left", "<i2", (5,)),
+    ("stripe_base_row", "<i2"), ("reserved", "<i2"), ("scores", "<f4", (4, 10)),
+])
+assert EXPIRY_GROUP_DTYPE.itemsize == 192
+EXPIRY_DTYPE = np.dtype([
+    ("n_groups", "<i4"), ("n_found", "<i4"), ("n_stripes", "<i4"),
+    ("stripe_base_row", "<i4", (3,)), ("stripe_sum", "<i8", (3,)),
+    ("categorised", "<i4"), ("reserved", "<i4"),
+    ("groups", EXPIRY_GROUP_DTYPE, (EXPIRY_MAX_GROUPS,)),
+])
+assert EXPIRY_DTYPE.itemsize == 56 + 8 * 192
+
 _u8p = C.POINTER(C.c_uint8)
 _f32p = C.POINTER(C.c_float)
 _i16p = C.POINTER(C.c_int16)
@@ -240,6 +256,35 @@ class Oracle:
         d = np.ascontiguousarray(digits, np.uint8)
         return bool(self.lib.orc_passes_luhn(_p(d, _u8p), len(d)))
 
+    # ---- expiry path ----
+    def scharr3_dx_abs(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(img.shape, np.int16)
+        self.lib.orc_scharr3_dx_abs(_p(img, _u8p), img.shape[1], img.shape[1], img.shape[0],
+                                    _p(out, _i16p), img.shape[1])
+        return out
+
+    def best_expiry_seg(self, card, y_offset):
+        card = np.ascontiguousarray(card, np.uint8)
+        out = np.zeros(1, EXPIRY_DTYPE)
+        self.lib.orc_best_expiry_seg(_p(card, _u8p), card.shape[1], int(y_offset), out.ctypes.data_as(C.c_void_p))
+        return out[0]
+
+    def prepare_image_for_cat(self, card, left, top):
+        card = np.ascontiguousarray(card, np.uint8)
+        x = np.empty(176, np.float32)
+        self.lib.orc_prepare_image_for_cat(_p(card, _u8p), card.shape[1], int(left), int(top), _p(x, _f32p))
+        return x
+
+    def scan_card_expiry(self, card, res):
+        card = np.ascontiguousarray(card, np.uint8)
+        r = np.zeros(1, RESULT_DTYPE)
+        r[0] = res
+        out = np.zeros(1, EXPIRY_DTYPE)
+        self.lib.orc_scan_card_expiry(_p(card, _u8p), card.shape[1], r.ctypes.data_as(C.c_void_p),
+                                      out.ctypes.data_as(C.c_void_p))
+        return out[0]
+
 
 class Reference:
     """Partial build of the reference's own code (oracle/_ref/libdmzref.so); None if absent."""
@@ -319,3 +364,38 @@ class Reference:
     def passes_luhn(self, digits):
         d = np.ascontiguousarray(digits, np.uint8).copy()
         return bool(self.lib.ref_passes_luhn(_p(d, _u8p), len(d)))
+
+
+def _gather_into_groups(lib, prefix, lefts, sums, top, height):
+    lefts = np.ascontiguousarray(lefts, np.int32)
+    sums = np.ascontiguousarray(sums, np.int64)
+    n = len(lefts)
+    gn, gl, gw = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+    rl = np.zeros(max(n, 1), np.int32)
+    rs = np.zeros(max(n, 1), np.int64)
+    i64p = C.POINTER(C.c_int64)
+    fn = getattr(lib, prefix + "expiry_gather_into_groups")
+    fn.restype = C.c_int
+    ng = fn(C.c_int(n), _p(lefts, _i32p), _p(sums, i64p), C.c_int(top), C.c_int(height), _p(gn, _i32p),
+            _p(gl, _i32p), _p(gw, _i32p), _p(rl, _i32p), _p(rs, i64p))
+    k = int(gn[:ng].sum())
+    return gn[:ng].copy(), gl[:ng].copy(), gw[:ng].copy(), rl[:k].copy(), rs[:k].copy()
+
+
+def _regrid_group(lib, prefix, sobel, top, height, left, width, character_width=9):
+    sobel = np.ascontiguousarray(sobel, np.int16)
+    assert sobel.shape == (270, 428)
+    l, w, cw, n = C.c_int(left), C.c_int(width), C.c_int(character_width), C.c_int(0)
+    rl = np.zeros(128, np.int32)
+    rs = np.zeros(128, np.int64)
+    fn = getattr(lib, prefix + "expiry_regrid_group")
+    fn.restype = None
+    fn(_p(sobel, _i16p), C.c_int(top), C.c_int(height), C.byref(l), C.byref(w), C.byref(cw), C.byref(n),
+       _p(rl, _i32p), _p(rs, C.POINTER(C.c_int64)))
+    return l.value, w.value, cw.value, rl[:n.value].copy(), rs[:n.value].copy()
+
+
+Oracle.expiry_gather_into_groups = lambda self, *a: _gather_into_groups(self.lib, "orc_", *a)
+Oracle.expiry_regrid_group = lambda self, *a: _regrid_group(self.lib, "orc_", *a)
+Reference.expiry_gather_into_groups = lambda self, *a: _gather_into_groups(self.lib, "ref_", *a)
+Reference.expiry_regrid_group = lambda self, *a: _regrid_group(self.lib, "ref_", *a)

@@ -27,6 +27,9 @@ typedef struct {
   int x0, y0;        /* card-space origin of the first digit box, 1/16 px */
   int pitch;         /* digit pitch in 1/16 px */
   uint8_t digits[16];
+  int ex0, ey0;      /* card-space origin of the MM/YY line, 1/16 px */
+  int epitch;        /* its character pitch, 1/16 px */
+  uint8_t exp_digits[4]; /* M M Y Y */
 } synth_params;
 
 static uint64_t splitmix64(uint64_t *s) {
@@ -104,6 +107,15 @@ static void make_params(uint64_t seed, uint64_t frame, synth_params *p) {
     sum += d;
   }
   p->digits[15] = (uint8_t)((10 - sum % 10) % 10);
+  /* expiry line "MM/YY": small characters (9 x 15 px boxes) below the number */
+  p->ex0 = 190 * 16 + (int)(splitmix64(&s) % 257) - 128;
+  p->ey0 = 206 * 16 + (int)(splitmix64(&s) % 129) - 64;
+  p->epitch = 13 * 16 + (int)(splitmix64(&s) % 17) - 8;
+  const int month = 1 + (int)(splitmix64(&s) % 12), year = 27 + (int)(splitmix64(&s) % 4);
+  p->exp_digits[0] = (uint8_t)(month / 10);
+  p->exp_digits[1] = (uint8_t)(month % 10);
+  p->exp_digits[2] = (uint8_t)(year / 10);
+  p->exp_digits[3] = (uint8_t)(year % 10);
 }
 
 /* 7 segments in a 17 x 25 px digit box, 1/16 px units: x0,y0,x1,y1 */
@@ -116,6 +128,16 @@ static const int16_t k_seg[7][4] = {
     {0 * 16, 1 * 16, 3 * 16, 13 * 16},    /* f top left */
     {2 * 16, 11 * 16, 15 * 16, 14 * 16},  /* g middle */
 };
+/* the same seven segments in a 9 x 15 px box (expiry characters), stroke 2 px */
+static const int16_t k_seg_small[7][4] = {
+    {1 * 16, 0 * 16, 8 * 16, 2 * 16},    /* a */
+    {7 * 16, 1 * 16, 9 * 16, 8 * 16},    /* b */
+    {7 * 16, 7 * 16, 9 * 16, 14 * 16},   /* c */
+    {1 * 16, 13 * 16, 8 * 16, 15 * 16},  /* d */
+    {0 * 16, 7 * 16, 2 * 16, 14 * 16},   /* e */
+    {0 * 16, 1 * 16, 2 * 16, 8 * 16},    /* f */
+    {1 * 16, 104, 8 * 16, 136},          /* g (6.5 .. 8.5 px) */
+};
 static const uint8_t k_digit_segs[10] = {
     0x3F, 0x06, 0x5B, 0x4F, 0x66, 0x6D, 0x7D, 0x07, 0x7F, 0x6F};
 
@@ -123,16 +145,26 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 
 /* soft coverage (0..256) of point (px,py) [1/16 px, box-local] by the digit's strokes,
  * evaluated for a box offset (ox,oy) so that the emboss rim can reuse it */
-static int stroke_cov(int segs, int px, int py) {
+static int stroke_cov_tab(const int16_t seg[7][4], int segs, int px, int py) {
   int best = 0;
   for (int s = 0; s < 7; s++) {
     if (!(segs & (1 << s))) continue;
-    int cx = clampi((px - k_seg[s][0] < k_seg[s][2] - px ? px - k_seg[s][0] : k_seg[s][2] - px) + 8, 0, 16);
-    int cy = clampi((py - k_seg[s][1] < k_seg[s][3] - py ? py - k_seg[s][1] : k_seg[s][3] - py) + 8, 0, 16);
+    int cx = clampi((px - seg[s][0] < seg[s][2] - px ? px - seg[s][0] : seg[s][2] - px) + 8, 0, 16);
+    int cy = clampi((py - seg[s][1] < seg[s][3] - py ? py - seg[s][1] : seg[s][3] - py) + 8, 0, 16);
     int c = cx * cy;
     if (c > best) best = c;
   }
   return best; /* 0..256 */
+}
+static int stroke_cov(int segs, int px, int py) { return stroke_cov_tab(k_seg, segs, px, py); }
+
+/* '/' in the 9 x 15 box: a 2 px wide stroke from (1.5, 15) to (7.5, 0) */
+static int slash_cov(int px, int py) {
+  const int xl = 24 + ((240 - py) * 96) / 240;
+  const int dx = px - xl < 0 ? xl - px : px - xl;
+  const int cx = clampi(16 - dx + 8, 0, 16);
+  const int cy = clampi((py < 240 - py ? py : 240 - py) + 8, 0, 16);
+  return cx * cy;
 }
 
 /* card texture at card-space point (U,V) in 1/16 px; returns grey delta vs card mean */
@@ -154,6 +186,30 @@ static int card_delta(const synth_params *p, int U, int V) {
         int c0 = stroke_cov(segs, lx, ry);
         int c1 = stroke_cov(segs, lx + 16, ry + 16); /* highlight up-left of the stroke */
         int c2 = stroke_cov(segs, lx - 16, ry - 16); /* shadow down-right of the stroke */
+        d += (p->ink * c0) >> 8;
+        d += (p->rim * (c1 - c0 > 0 ? c1 - c0 : 0)) >> 8;
+        d -= (p->rim * (c2 - c0 > 0 ? c2 - c0 : 0)) >> 8;
+      }
+    }
+  }
+  int ey = V - p->ey0;
+  if (ey >= -32 && ey < 15 * 16 + 32) {
+    int ex = U - p->ex0;
+    if (ex >= -32) {
+      int slot = (ex + 32) / p->epitch;
+      if (slot < 5) {
+        int lx = ex - slot * p->epitch;
+        int c0, c1, c2;
+        if (slot == 2) {
+          c0 = slash_cov(lx, ey);
+          c1 = slash_cov(lx + 16, ey + 16);
+          c2 = slash_cov(lx - 16, ey - 16);
+        } else {
+          int segs = k_digit_segs[p->exp_digits[slot > 2 ? slot - 1 : slot]];
+          c0 = stroke_cov_tab(k_seg_small, segs, lx, ey);
+          c1 = stroke_cov_tab(k_seg_small, segs, lx + 16, ey + 16);
+          c2 = stroke_cov_tab(k_seg_small, segs, lx - 16, ey - 16);
+        }
         d += (p->ink * c0) >> 8;
         d += (p->rim * (c1 - c0 > 0 ? c1 - c0 : 0)) >> 8;
         d -= (p->rim * (c2 - c0 > 0 ? c2 - c0 : 0)) >> 8;

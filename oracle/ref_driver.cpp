@@ -137,3 +137,64 @@ REF_API int ref_card_type(uint8_t *digits, int n, int allow_incomplete, int *num
   *number_length = info.number_length;
   return info.card_type;
 }
+
+// ---- expiry segmentation list logic (scan/expiry_seg.cpp): the two functions below touch the
+// Scharr image only through the CV_IMAGE_ELEM header macro, so they link without OpenCV ----
+REF_API int ref_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *sums, int top,
+                                          int height, int *group_n, int *group_left, int *group_width,
+                                          int *rect_left, int64_t *rect_sum) {
+  GroupedRectsList items, groups;
+  for (int i = 0; i < n_items; i++) {
+    GroupedRects g;
+    g.top = top;
+    g.left = lefts[i];
+    g.width = kSmallCharacterWidth;
+    g.height = height;
+    g.grouped_yet = false;
+    g.sum = (long)sums[i];
+    g.character_width = kSmallCharacterWidth;
+    items.push_back(g);
+  }
+  gather_into_groups(groups, items, kSmallCharacterWidth);
+  int k = 0;
+  for (size_t i = 0; i < groups.size(); i++) {
+    group_n[i] = (int)groups[i].character_rects.size();
+    group_left[i] = groups[i].left;
+    group_width[i] = groups[i].width;
+    for (size_t j = 0; j < groups[i].character_rects.size(); j++, k++) {
+      rect_left[k] = groups[i].character_rects[j].left;
+      rect_sum[k] = groups[i].character_rects[j].sum;
+    }
+  }
+  return (int)groups.size();
+}
+
+REF_API void ref_expiry_regrid_group(const int16_t *sobel, int top, int height, int *left, int *width,
+                                     int *character_width, int *n, int *rect_left, int64_t *rect_sum) {
+  IplImage img;
+  memset(&img, 0, sizeof(img));
+  img.nSize = sizeof(IplImage);
+  img.nChannels = 1;
+  img.depth = IPL_DEPTH_16S;
+  img.width = kCreditCardTargetWidth;
+  img.height = kCreditCardTargetHeight;
+  img.widthStep = kCreditCardTargetWidth * 2;
+  img.imageData = (char *)sobel;
+  GroupedRects g;
+  g.top = top;
+  g.height = height;
+  g.left = *left;
+  g.width = *width;
+  g.character_width = *character_width;
+  g.grouped_yet = false;
+  g.sum = 0;
+  regrid_group(&img, g);
+  *left = g.left;
+  *width = g.width;
+  *character_width = g.character_width;
+  *n = (int)g.character_rects.size();
+  for (size_t i = 0; i < g.character_rects.size(); i++) {
+    rect_left[i] = g.character_rects[i].left;
+    rect_sum[i] = g.character_rects[i].sum;
+  }
+}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes tests/golden/pipeline_golden.npz: the ORACLE's outputs for eight seeded synthetic
-frames (result records, SHA-256 of each rectified card, one full card).  A regression
+frames (result records, expiry records, SHA-256 of each rectified card, one full card).  A regression
 guard for the oracle and a committed target for the GPU parity test; regenerate only when
 the oracle changes on purpose:  python tests/golden/make_pipeline_golden.py"""
 import hashlib
@@ -19,17 +19,19 @@ SEED, N = 20261001, 8
 def main():
     o = orc.Oracle()
     recs = np.zeros(N, orc.RESULT_DTYPE)
+    exps = np.zeros(N, orc.EXPIRY_DTYPE)
     hashes, digits = [], []
     card0 = None
     for i in range(N):
         y, d = o.synth_frame(SEED, i)
         recs[i], card = o.scan_frame(y)
+        exps[i] = o.scan_card_expiry(card, recs[i])
         hashes.append(hashlib.sha256(card.tobytes()).hexdigest())
         digits.append(d)
         if i == 0:
             card0 = card
     np.savez_compressed(os.path.join(HERE, "pipeline_golden.npz"), seed=SEED, records=recs.view(np.uint8),
-                        card_sha256=np.array(hashes), true_digits=np.array(digits), card0=card0)
+                        expiry=exps.view(np.uint8), card_sha256=np.array(hashes), true_digits=np.array(digits), card0=card0)
     print("wrote", N, "records")
 
 

@@ -22,6 +22,7 @@ def test_oracle_reproduces_golden(oracle, orc):
         assert np.array_equal(d, G["true_digits"][i])
         got, card = oracle.scan_frame(y)
         assert got.tobytes() == want[i].tobytes(), i
+        assert oracle.scan_card_expiry(card, got).tobytes() == G["expiry"].view(orc.EXPIRY_DTYPE).reshape(-1)[i].tobytes(), i
         assert hashlib.sha256(card.tobytes()).hexdigest() == str(G["card_sha256"][i])
     assert np.array_equal(oracle.scan_frame(oracle.synth_frame(SEED, 0)[0])[1], G["card0"])
 
@@ -33,10 +34,13 @@ def test_hip_pipeline_reproduces_golden(ctx, pkg):
     y = ctx.alloc(n * pkg.FRAME_BYTES)
     res = ctx.alloc(n * 1024)
     cards = ctx.alloc(n * pkg.CARD_BYTES)
+    exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
     ctx.synth_frames(SEED, 0, n, y.ptr)
-    ctx.pipeline(y.ptr, n, res.ptr, cards.ptr)
+    ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
     ctx.synchronize()
     got = res.download(pkg.RESULT_DTYPE, n)
+    gexp = exp.download(pkg.EXPIRY_DTYPE, n)
+    wexp = G["expiry"].view(pkg.EXPIRY_DTYPE).reshape(-1)
     gcards = cards.download(np.uint8).reshape(n, 270, 428)
     for i in range(n):
         assert hashlib.sha256(gcards[i].tobytes()).hexdigest() == str(G["card_sha256"][i]), i
@@ -47,5 +51,11 @@ def test_hip_pipeline_reproduces_golden(ctx, pkg):
             assert np.array_equal(np.asarray(got[i][f]).view(np.uint32), np.asarray(want[i][f]).view(np.uint32)), (i, f)
         assert abs(float(got[i]["vseg_score"]) - float(want[i]["vseg_score"])) <= 1e-4
         assert np.abs(got[i]["scores"] - want[i]["scores"]).max() <= 1e-4
-    for b in (y, res, cards):
+        # expiry: everything but the float scores is bit-exact
+        a, b = gexp[i:i + 1].copy(), wexp[i:i + 1].copy()
+        assert np.abs(a["groups"]["scores"] - b["groups"]["scores"]).max() <= 1e-4, i
+        a["groups"]["scores"] = 0
+        b["groups"]["scores"] = 0
+        assert a.tobytes() == b.tobytes(), i
+    for b in (y, res, cards, exp):
         b.free()

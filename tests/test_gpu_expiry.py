@@ -1,0 +1,153 @@
+"""GPU parity of the expiry path through the C-ABI against the CPU oracle:
+stripes, groups and character rects bit-exact; the 4 x 10 digit scores within 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KATS = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_kats.npz"))
+SEED = 0xE791
+
+
+def _compare(pkg, got, want, tag):
+    """one frame: dmz_hip_expiry_result vs orc_expiry_result"""
+    assert got["n_stripes"] == want["n_stripes"], tag
+    ns = int(want["n_stripes"])
+    assert np.array_equal(got["stripe_base_row"][:ns], want["stripe_base_row"][:ns]), tag
+    assert np.array_equal(got["stripe_sum"][:ns], want["stripe_sum"][:ns]), tag
+    assert got["n_found"] == want["n_found"], (tag, got["n_found"], want["n_found"])
+    assert got["n_groups"] == want["n_groups"], tag
+    assert got["categorised"] == want["categorised"], tag
+    err = 0.0
+    for k in range(int(want["n_groups"])):
+        g, w = got["groups"][k], want["groups"][k]
+        for name in ("top", "left", "width", "height", "stripe_base_row"):
+            assert g[name] == w[name], (tag, k, name)
+        assert np.array_equal(g["char_top"], w["char_top"]), (tag, k)
+        assert np.array_equal(g["char_left"], w["char_left"]), (tag, k)
+        err = max(err, float(np.abs(g["scores"] - w["scores"]).max()))
+    assert err <= 1e-4, (tag, err)
+    return err
+
+
+def test_expiry_model_kats_on_device(ctx):
+    out = ctx.apply_slash_model(KATS["slash_in"])[0]
+    assert np.abs(out - KATS["slash_out"]).max() <= 1e-5
+    out = ctx.apply_expiry_model(KATS["expiry_in"])[0]
+    assert np.abs(out - KATS["expiry_out"]).max() <= 1e-5
+
+
+def test_expiry_models_match_oracle_on_random_batches(ctx, oracle):
+    rng = np.random.default_rng(11)
+    x = rng.random((37, 176), dtype=np.float32)
+    got = ctx.apply_slash_model(x)
+    want = np.stack([oracle.applym_slash(v) for v in x])
+    assert np.abs(got - want).max() <= 2e-6
+    # CNN inputs: images in [0, 1] like prepare_image_for_cat produces; a batch that is not a multiple of 4
+    x = (rng.integers(0, 256, (23, 176)) / np.float32(255)).astype(np.float32)
+    got = ctx.apply_expiry_model(x)
+    want = np.stack([oracle.applyc_expiry(v)[0] for v in x])
+    assert np.abs(got - want).max() <= 1e-5
+
+
+def test_scan_expiry_on_synthetic_cards(ctx, pkg, oracle):
+    """pre-warped cards (BASELINE config 3 shape): number path, then the expiry path"""
+    n = 96
+    cards = ctx.alloc(n * pkg.CARD_BYTES)
+    res = ctx.alloc(n * 1024)
+    exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
+    res.upload(np.zeros(n * 1024, np.uint8))
+    ctx.synth_cards(SEED, 0, n, cards.ptr)
+    ctx.scan_cards(cards.ptr, n, res.ptr)
+    ctx.scan_expiry(cards.ptr, n, res.ptr, exp.ptr)
+    ctx.synchronize()
+    got_res = res.download(pkg.RESULT_DTYPE, n)
+    got = exp.download(pkg.EXPIRY_DTYPE, n)
+    host_cards = cards.download(np.uint8).reshape(n, 270, 428)
+    with_groups = categorised = 0
+    worst = 0.0
+    for i in range(n):
+        want_res = oracle.scan_card_image(host_cards[i], warped=False)
+        assert (got_res[i]["flags"] & 7) == (want_res["flags"] & 7), i
+        assert got_res[i]["vseg_y_offset"] == want_res["vseg_y_offset"], i
+        want = oracle.scan_card_expiry(host_cards[i], want_res)
+        worst = max(worst, _compare(pkg, got[i], want, i))
+        with_groups += int(want["n_found"] > 0)
+        categorised += int(want["categorised"] and want["n_groups"] > 0)
+    # the corpus must exercise both halves of the path
+    assert with_groups >= n // 4 and categorised >= n // 8, (with_groups, categorised)
+    for b in (cards, res, exp):
+        b.free()
+
+
+def test_pipeline_expiry_matches_oracle(ctx, pkg, oracle):
+    """frames -> detect -> warp -> scan -> expiry in one call (BASELINE config 4 shape); host result buffers"""
+    n = 40
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 100, n, y.ptr)
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.pipeline_expiry(y.ptr, n, res, exp)
+    frames = y.download(np.uint8).reshape(n, 480, 640)
+    hits = 0
+    for i in range(n):
+        want_res, card = oracle.scan_frame(frames[i])
+        assert res[i]["flags"] == want_res["flags"], i
+        want = oracle.scan_card_expiry(card, want_res)
+        _compare(pkg, exp[i], want, i)
+        hits += int(want["n_found"] > 0)
+    assert hits >= n // 4
+    # the number-path record is the one dmz_hip_pipeline_batch writes
+    res2 = np.zeros(n, pkg.RESULT_DTYPE)
+    ctx.pipeline(y.ptr, n, res2)
+    assert res.tobytes() == res2.tobytes()
+    y.free()
+
+
+def test_expiry_gates_and_edge_cards(ctx, pkg, oracle):
+    """blank / noise / saturated cards, an upside-down card, a number row too low for any stripe"""
+    rng = np.random.default_rng(5)
+    base, _ = oracle.synth_card(SEED, 3)
+    cards = [np.zeros((270, 428), np.uint8), np.full((270, 428), 255, np.uint8),
+             rng.integers(0, 256, (270, 428)).astype(np.uint8), base[::-1, ::-1].copy(), base.copy()]
+    low = base.copy()
+    low[80:] = base[:190]  # push the number row (and everything else) 80 px down: no room for stripes
+    low[:80] = base[0:1]
+    cards.append(low)
+    # vertical bars everywhere below the number: many strong stripes and long rect chains
+    bars = base.copy()
+    bars[185:, ::6] = 20
+    cards.append(bars)
+    arr = np.ascontiguousarray(np.stack(cards))
+    n = len(cards)
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_cards(arr, n, res)
+    ctx.scan_expiry(arr, n, res, exp)
+    for i in range(n):
+        want_res = oracle.scan_card_image(arr[i], warped=False)
+        assert (res[i]["flags"] & 7) == (want_res["flags"] & 7), i
+        want = oracle.scan_card_expiry(arr[i], want_res)
+        _compare(pkg, exp[i], want, i)
+    # forcing the gates open on every card still agrees (segmentation of arbitrary content)
+    forced = res.copy()
+    forced["flags"] = pkg.FLAG_VSEG_OK | pkg.FLAG_USABLE
+    forced["vseg_y_offset"] = [130, 150, 160, 125, 152, 200, 150]
+    ctx.scan_expiry(arr, n, forced, exp)
+    for i in range(n):
+        want = oracle.scan_card_expiry(arr[i], forced[i])
+        _compare(pkg, exp[i], want, "forced %d" % i)
+
+
+def test_expiry_bad_arguments(ctx, pkg):
+    res = np.zeros(1, pkg.RESULT_DTYPE)
+    exp = np.zeros(1, pkg.EXPIRY_DTYPE)
+    card = np.zeros((270, 428), np.uint8)
+    with pytest.raises(pkg.DmzHipError):
+        ctx.scan_expiry(None, 1, res, exp)
+    with pytest.raises(pkg.DmzHipError):
+        ctx.scan_expiry(card, 0, res, exp)
+    with pytest.raises(pkg.DmzHipError):
+        ctx.scan_expiry(card, 1, res, None)

@@ -104,3 +104,41 @@ def test_luhn_matches_reference(oracle, reference):
         n = 15 + int(rng.integers(0, 2))
         d = rng.integers(0, 10, n).astype(np.uint8)
         assert oracle.passes_luhn(d) == reference.passes_luhn(d)
+
+
+def test_expiry_gather_into_groups_bit_exact(oracle, reference):
+    """expiry_seg.cpp:131-167 incl. strip_group_white_space (101-129): non-overlapping 9-px rects."""
+    rng = np.random.default_rng(31)
+    for _ in range(400):
+        n = int(rng.integers(1, 40))
+        # distinct, non-overlapping lefts with random gaps (some >= 9 to split groups)
+        gaps = rng.choice([9, 9, 10, 11, 12, 14, 17, 18, 19, 25, 40], n)
+        lefts = np.cumsum(gaps) - 9
+        lefts = lefts[lefts < 420]
+        sums = rng.integers(1000, 200000, len(lefts))
+        sums[rng.random(len(lefts)) < 0.3] //= 4  # dim rects at random places -> white-space stripping
+        order = rng.permutation(len(lefts))  # the reference receives them in selection order
+        a = oracle.expiry_gather_into_groups(lefts[order], sums[order], 100, 17)
+        b = reference.expiry_gather_into_groups(lefts[order], sums[order], 100, 17)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_expiry_regrid_group_bit_exact(oracle, reference):
+    """expiry_seg.cpp:169-229 on Scharr images of synthetic cards and on random images."""
+    rng = np.random.default_rng(32)
+    for i in range(60):
+        if i < 30:
+            card, _ = oracle.synth_card(5, i)
+            sob = np.zeros((270, 428), np.int16)
+            sob[178:] = oracle.scharr3_dx_abs(card[178:])
+        else:
+            sob = rng.integers(0, 4081, (270, 428)).astype(np.int16)
+        for _ in range(6):
+            top = int(rng.integers(180, 250))
+            left = int(rng.integers(0, 380))
+            width = int(rng.integers(36, min(200, 428 - left)))
+            a = oracle.expiry_regrid_group(sob, top, 17, left, width)
+            b = reference.expiry_regrid_group(sob, top, 17, left, width)
+            assert a[:3] == b[:3]
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
