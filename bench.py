@@ -2,9 +2,9 @@
 """Benchmark of the card.io-dmz scan hot path on MI355X.
 
 A "step" = one pass of the full per-frame pipeline (detect edges -> rectify card
--> number-row search -> digit segmentation -> digit categorisation) over one
-HBM-resident batch of synthetic 640x480 luma frames (BASELINE.json configs[3],
-number path).  `value` = frames/s of the whole job (all ranks), inputs resident
+-> number-row search -> digit segmentation -> digit categorisation -> expiry
+segmentation + categorisation) over one HBM-resident batch of synthetic 640x480
+luma frames (BASELINE.json configs[3]).  `value` = frames/s of the whole job (all ranks), inputs resident
 in HBM when the timed region starts.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
@@ -12,7 +12,7 @@ in HBM when the timed region starts.
 N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 one rank per GPU; frames are sharded (weak scaling: B frames per GPU) and each
-step ends with an RCCL all-gather of the fixed-size result records.
+step ends with an RCCL all-gather of the fixed-size result and expiry records.
 """
 import argparse
 import json
@@ -40,8 +40,12 @@ ALGO = {
     "vseg":     (103 * 408 + 24,            2 * 103 * (204 * 50 + 150)),
     "hseg":     (27 * 428 + 48,             2.0e5),
     "digits":   (16 * 27 * 19 + 744,        16 * 3 * 2 * (8 * 360 * 9 + 320 * 32 + 320)),
+    # expiry: rows below the number (~92 x 428 B) once for the line sums + 3 stripes x 23 rows;
+    # the CNN is 4 digits x 1.27 M MAC per group, ~0.6 groups per frame on this corpus
+    "expiry_seg": (92 * 428 + 3 * 23 * 428 + 1592, 1.5e5),
+    "expiry_cat": (4 * 176 + 160,           0.6 * 4 * 2 * 1.27e6),
 }
-PIPELINE_BYTES = 307200 + 115560 + 1024
+PIPELINE_BYTES = 307200 + 115560 + 1024 + 1592
 # HBM traffic per frame (bytes) from the committed PMC passes profiles/r1_pmc_{FETCH,WRITE}_SIZE_*.txt
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, KB per dispatch / 4096 frames).
 # FETCH_SIZE is NOT doubled: the guide's x2 gfx950 correction is calibrated for 16 B/lane
@@ -54,6 +58,8 @@ PMC_TRAFFIC = {
     "vseg": (100604.2 + 3146.3) * 1024 / 4096,
     "hseg": (32576.1 + 256.0) * 1024 / 4096,
     "digits": (24546.8 + 2902.4) * 1024 / 4096,
+    "expiry_seg": None,  # not collected yet
+    "expiry_cat": None,
 }
 
 
@@ -64,13 +70,14 @@ def cpu_baseline(orc_mod, frames, budget_s=12.0):
     t0 = time.perf_counter()
     done = 0
     for f in frames:
-        o.scan_frame(f, want_card=True)
+        res, card = o.scan_frame(f, want_card=True)
+        o.scan_card_expiry(card, res)
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the benchmark's synthetic 640x480 frames, full pipeline, 1 thread, %.1f s"
+            "sample": "%d of the benchmark's synthetic 640x480 frames, full pipeline incl. expiry, 1 thread, %.1f s"
                       % (done, dt)}
 
 
@@ -107,7 +114,10 @@ def main():
     frames = torch.empty((B, pkg.FRAME_H, pkg.FRAME_W), dtype=torch.uint8, device=dev)
     cards = torch.empty((B, pkg.CARD_H, pkg.CARD_W), dtype=torch.uint8, device=dev)
     results = torch.zeros((B, 1024), dtype=torch.uint8, device=dev)
+    XB = pkg.EXPIRY_DTYPE.itemsize
+    expiry = torch.zeros((B, XB), dtype=torch.uint8, device=dev)
     gathered = torch.empty((world * B, 1024), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered_x = torch.empty((world * B, XB), dtype=torch.uint8, device=dev) if world > 1 else None
     # every rank scans its own contiguous slice of the synthetic corpus (weak scaling:
     # the corpus is world*B frames, rank g owns [g*B, (g+1)*B))
     lo, hi = sharding.shard_range(world * B, rank, world)
@@ -116,9 +126,10 @@ def main():
     torch.cuda.synchronize(dev)
 
     def step():
-        ctx.pipeline(frames, B, results, cards)
+        ctx.pipeline_expiry(frames, B, results, expiry, cards)
         if world > 1:
             sharding.gather_results(results, world, out=gathered)
+            sharding.gather_results(expiry, world, out=gathered_x)
 
     for _ in range(args.warmup):
         step()
@@ -146,7 +157,7 @@ def main():
     ctx.stage_times(reset=True)
     prof_steps = 2
     for _ in range(prof_steps):
-        ctx.pipeline(frames, B, results, cards)
+        ctx.pipeline_expiry(frames, B, results, expiry, cards)
     stage = ctx.stage_times(reset=True)
     ctx.set_profiling(False)
 
@@ -157,6 +168,10 @@ def main():
             "vseg_ok": float(((res["flags"] & pkg.FLAG_VSEG_OK) != 0).mean()),
             "usable": float(((res["flags"] & pkg.FLAG_USABLE) != 0).mean()),
         }
+        ex = expiry.cpu().numpy().view(pkg.EXPIRY_DTYPE).reshape(-1)
+        gates["expiry_group_found"] = float((ex["n_found"] > 0).mean())
+        gates["expiry_categorised"] = float(((ex["categorised"] != 0) & (ex["n_groups"] > 0)).mean())
+        gates["expiry_groups_per_frame"] = float(ex["n_groups"].mean())
         per_stage = {}
         for name, (ms, cnt) in stage.items():
             if cnt == 0:
@@ -179,7 +194,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(fl_frac, 5), "traffic": None}
         roof["kernel"] = dom
         roof["launch_ms"] = per_stage[dom]["ms_per_step"]
-        roof["traffic"] = round(PMC_TRAFFIC[dom] * B)  # bytes per launch, from profiles/ (see PMC_TRAFFIC)
+        # bytes per launch, from profiles/ (see PMC_TRAFFIC)
+        roof["traffic"] = round(PMC_TRAFFIC[dom] * B) if PMC_TRAFFIC[dom] is not None else None
         value = world * B * args.steps / elapsed
         roof["pipeline_GBps"] = round(value / world * PIPELINE_BYTES / 1e9, 2)
         roof["pipeline_frac_of_hbm"] = round(value / world * PIPELINE_BYTES / 1e9 / HBM_PEAK_GBPS, 5)
@@ -198,10 +214,10 @@ def main():
             "dtype": "u8 images / int32 votes / f32 scores (f64 warp coordinates)",
             "data": "synthetic",
             "config": {
-                "workload": "full pipeline detect->warp->vseg->hseg->digits (number path, no expiry), "
+                "workload": "full pipeline detect->warp->vseg->hseg->digits->expiry (BASELINE configs[3]), "
                             "%d synthetic 640x480 Y frames per GPU resident in HBM" % B,
                 "frames_per_gpu": B,
-                "parallelism": "frame-sharded x%d, all-gather of 1 KiB result records" % world,
+                "parallelism": "frame-sharded x%d, all-gather of the 1 KiB result + 1.6 KiB expiry records" % world,
                 "gate_pass_rates": gates,
                 "device_ms_per_step": round(dev_ms / args.steps, 3),
             },

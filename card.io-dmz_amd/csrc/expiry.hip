@@ -677,7 +677,12 @@ __global__ __launch_bounds__(XC_THREADS) void k_expiry_cat(const float *__restri
   if (f >= n) return;
   dmz_hip_expiry_result *er = out + f;
   const int n_stripes = er->n_stripes;
-  if (n_stripes == 0) return;
+  const int flags = results[f].flags, yoff = results[f].vseg_y_offset;
+  const bool gate = (flags & DMZ_HIP_FLAG_VSEG_OK) && yoff < CH - 2 * SCH && yoff >= 0;  // frame.cpp:72
+  if (n_stripes == 0) {
+    if (tid == 0 && gate && (flags & DMZ_HIP_FLAG_USABLE)) er->categorised = 1;
+    return;
+  }
   // ---- merge the per-stripe staging in stripe order (FrameScanResult.expiry_groups order) ----
   {
     int cnt[3], tot = 0;
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(XC_THREADS) void k_expiry_cat(const float *__restri
       S.n_groups = imin(tot, DMZ_HIP_EXPIRY_MAX_GROUPS);
     }
   }
-  if (!(results[f].flags & DMZ_HIP_FLAG_USABLE)) return;  // scan.cpp:57-59
+  if (!(flags & DMZ_HIP_FLAG_USABLE)) return;  // scan.cpp:57-59
   if (tid == 0) er->categorised = 1;
   for (int i = tid; i < 4 * XIN_H * XIN_W; i += XC_THREADS) S.xin[i] = 0.0f;
   __syncthreads();

@@ -13,14 +13,17 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
     y = ctx.alloc(n * pkg.FRAME_BYTES)
     res = ctx.alloc(n * 1024)
     cards = ctx.alloc(n * pkg.CARD_BYTES)
+    exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
     ctx.synth_frames(SEED, 1000, n, y.ptr)
-    ctx.pipeline(y.ptr, n, res.ptr, cards.ptr)
+    ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
     ctx.synchronize()
     got = res.download(pkg.RESULT_DTYPE, n)
+    gexp = exp.download(pkg.EXPIRY_DTYPE, n)
     gcards = cards.download(np.uint8).reshape(n, 270, 428)
     frames = y.download(np.uint8).reshape(n, 480, 640)
     stats = dict(card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
-                 label_diff=0, flag_diff=0)
+                 label_diff=0, flag_diff=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
+                 expiry_slash_flips=0, max_expiry_err=0.0)
     for i in range(n):
         w, wcard = oracle.scan_frame(frames[i])
         g = got[i]
@@ -44,11 +47,36 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
             # the usable gate compares number_score with 3: only a float near-tie may flip it
             assert abs(float(w["number_score"]) - 3.0) < 1e-3, i
             stats["flag_diff"] += 1
+            continue
+        # ---- expiry: stripes, groups and rects exact; scores 1e-4 ----
+        we, ge = oracle.scan_card_expiry(wcard, w), gexp[i]
+        ns = int(we["n_stripes"])
+        if not (ge["n_stripes"] == ns and np.array_equal(ge["stripe_base_row"][:ns], we["stripe_base_row"][:ns])
+                and np.array_equal(ge["stripe_sum"][:ns], we["stripe_sum"][:ns])
+                and ge["categorised"] == we["categorised"]):
+            stats["expiry_seg_diff"] += 1
+            continue
+        if ge["n_found"] != we["n_found"]:
+            stats["expiry_slash_flips"] += 1  # only a slash probability within float noise of 0.7 may do this
+            continue
+        k = int(we["n_groups"])
+        stats["expiry_frames"] += int(k > 0)
+        stats["expiry_groups"] += k
+        a, b = ge["groups"][:k], we["groups"][:k]
+        same = all(np.array_equal(a[f], b[f]) for f in ("top", "left", "width", "height", "char_top", "char_left",
+                                                        "stripe_base_row"))
+        if not same:
+            stats["expiry_seg_diff"] += 1
+            continue
+        if k:
+            stats["max_expiry_err"] = max(stats["max_expiry_err"], float(np.abs(a["scores"] - b["scores"]).max()))
     print("parity stats over %d frames: %s" % (n, stats))
     assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
     assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
     assert stats["ties"] <= 2 and stats["flag_diff"] <= 2
     # a label can only flip when two vote scores of a digit are within the float tolerance
     assert stats["label_diff"] <= 2
-    for b in (y, res, cards):
+    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 and stats["max_expiry_err"] <= 1e-4
+    assert stats["expiry_frames"] >= n // 4
+    for b in (y, res, cards, exp):
         b.free()
