@@ -38,16 +38,29 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
 
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
-    v = v > w ? v : w;
-  }
-  return v;
+// Wave-wide reductions: four DPP row_shr steps leave each 16-lane row's result in its lane 15
+// (out-of-row sources read as 0: the identity of + and of unsigned max), the four row results
+// are combined on the scalar unit.  ~8 instructions instead of six ds_bpermute round trips.
+#define DMZ_DPP_SHR(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x110 + (n), 0xf, 0xf, true)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+  int v = (int)x;
+  unsigned o;
+  o = (unsigned)DMZ_DPP_SHR(v, 1), v = (int)((unsigned)v > o ? (unsigned)v : o);
+  o = (unsigned)DMZ_DPP_SHR(v, 2), v = (int)((unsigned)v > o ? (unsigned)v : o);
+  o = (unsigned)DMZ_DPP_SHR(v, 4), v = (int)((unsigned)v > o ? (unsigned)v : o);
+  o = (unsigned)DMZ_DPP_SHR(v, 8), v = (int)((unsigned)v > o ? (unsigned)v : o);
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane(v, 15), b = (unsigned)__builtin_amdgcn_readlane(v, 31);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane(v, 47), d = (unsigned)__builtin_amdgcn_readlane(v, 63);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += DMZ_DPP_SHR(v, 1);
+  v += DMZ_DPP_SHR(v, 2);
+  v += DMZ_DPP_SHR(v, 4);
+  v += DMZ_DPP_SHR(v, 8);
+  return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) +
+         __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
   for (int o = 32; o > 0; o >>= 1) {
@@ -147,6 +160,15 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 // ---------------------------------------------------------------------------------------------
 // k_expiry_seg: one wave per (frame, stripe)
 // ---------------------------------------------------------------------------------------------
+// developer ablation (tools/ablate.sh): -DDMZ_XSEG_STOP=k returns after phase k
+#ifndef DMZ_XSEG_STOP
+#define DMZ_XSEG_STOP 99
+#endif
+#define XSEG_STOP(k, expr)                     \
+  if (DMZ_XSEG_STOP == (k)) {                  \
+    if (lane == 0) sg->n = (int)(expr) & 0;    \
+    return;                                    \
+  }
 struct SegLds {
   short sob[SOB_ROWS * SOB_STRIDE];  // |Scharr dx| rows base-3 .. base+17
   int colA[432];                     // column sums over rows base .. base+16 (rect sums), later the pick map
@@ -157,9 +179,11 @@ struct SegLds {
   int gL[64], gW[64];                // surviving local groups
   int rL[64], rS[64];                // regridded rects of the current group
   int cLeft[64], cTop[64];           // optimised character rects of the current group
-  int scratch[64 * 21];              // per-lane column / row sums of optimize_character_rects
-  float xs[176];
-  float hid[80];
+  int okeep[64], oLeft[64], oTop[64];
+  int cmax[64], csum[64];
+  int scratch[3 * 21 * 19];          // thresholded tiles of optimize_character_rects
+  __attribute__((aligned(16))) float xs[4 * 176];  // [176][4]: four slash candidates interleaved
+  float hid[4 * 80];
 };
 
 // |p[c+1] - p[c-1]| of the four pixels of dword d of a row, column index clamped (sobel.cpp:729-734)
@@ -242,6 +266,7 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     }
   }
   __syncthreads();
+  XSEG_STOP(1, L.sob[lane])
 
   // ---- column sums, sliding 9-wide rect sums (expiry_seg.cpp:456-486) ----
   for (int c = lane; c < CW; c += 64) {
@@ -258,21 +283,42 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
   }
   __syncthreads();
 
+  XSEG_STOP(2, L.rsum[lane])
   // thresholds (expiry_seg.cpp:447-449, 488-494): the float total is accumulated in column order
+  // While the running total stays below 2^24 every float addition of these integers is exact, so
+  // the float total equals the integer total whenever that is < 2^24 (the common case); only
+  // beyond that the additions round and the reference's column order has to be replayed.
   const float thr1 = (float)(((stripe_sum * SCW) / CW) / 5);
-  float total = 0.0f;
-  int cnt = 0;
-  for (int c = 0; c < CW - SCW + 1; c++) {
-    const float s = (float)L.rsum[c];
-    if (s > thr1) {
-      total += s;
-      cnt++;
+  float total;
+  int cnt;
+  {
+    int isum = 0, icnt = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const int c = lane + 64 * j;
+      if (c < CW - SCW + 1) {
+        const int sv = L.rsum[c];
+        if ((float)sv > thr1) isum += sv, icnt++;
+      }
+    }
+    // rect sums are < 2^20 and there are <= 420 of them: the integer total fits 32 bits
+    isum = wave_sum_i32(isum);
+    cnt = wave_sum_i32(icnt);
+    if ((unsigned)isum < (1u << 24)) {
+      total = (float)isum;
+    } else {
+      total = 0.0f;
+      for (int c = 0; c < CW - SCW + 1; c++) {
+        const float sv = (float)L.rsum[c];
+        if (sv > thr1) total += sv;
+      }
     }
   }
   if (cnt == 0) return;
   const float avg = total / (float)cnt;
   const float thr2 = (float)(0.8 * (double)avg);
 
+  XSEG_STOP(3, thr2)
   // ---- greedy non-overlapping pick in descending sum order (expiry_seg.cpp:496-529) ----
   unsigned key[7];
 #pragma unroll
@@ -299,6 +345,7 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
       if (iabs(lane + 64 * j - pl) < SCW) key[j] = 0u;  // either end would hit the mask
   }
   __syncthreads();
+  XSEG_STOP(4, L.colA[lane])
   // sorted by left = column order
   int n_items = 0;
 #pragma unroll
@@ -348,6 +395,7 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
   }
   __syncthreads();
 
+  XSEG_STOP(5, G)
   const int g_top = base - 1;  // expanded stripe top; group height 17
   for (int g = 0; g < G; g++) {
     // ---- regrid_group (169-229) ----
@@ -413,107 +461,155 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     const int cw = sp - 1;
     int rs = 0, re = nR;
     strip_white_space(L.rS, rs, re);
+    if (DMZ_XSEG_STOP == 6) continue;
 
-    // ---- optimize_character_rects (231-339): lane = character rect ----
+    // ---- optimize_character_rects (231-339): three rects per pass, 21 lanes each.  Lane c of a
+    // slot owns column c of the 21-row window: one column of Scharr samples in registers serves
+    // the max, the normalise+threshold and the column sum; the row sums come from a transposed
+    // read of the thresholded tile (lane r = row r). ----
     const int ciw = cw + 4, cih = 17 + 4;
-    bool keep = false;
-    int c_left = 0, c_top = 0;
-    if (lane >= rs && lane < re) {
-      const int rect_left = L.rL[lane] - 2, rect_top = g_top - 2;  // rect_top == base - 3 == sob row 0
-      if (!(rect_left < 0 || rect_left + ciw > CW || rect_top + cih > CH)) {
-        keep = true;
+    {
+      const int sl = lane / 21, c = lane - sl * 21;
+      int *tile = L.scratch;  // [3][21][19]
+      for (int b0 = rs; b0 < re; b0 += 3) {
+        const int k = b0 + sl;
+        const bool have = sl < 3 && k < re;
+        const int rect_left = have ? L.rL[k] - 2 : 0;
+        const bool valid = have && !(rect_left < 0 || rect_left + ciw > CW || (g_top - 2) + cih > CH);
+        const bool col = valid && c < ciw;
+        int v[21];
         int mx = 0;
-        for (int r = 0; r < cih; r++)
-          for (int c = 0; c < ciw; c++) mx = imax(mx, (int)L.sob[r * SOB_STRIDE + rect_left + c]);
+#pragma unroll
+        for (int r = 0; r < 21; r++) {
+          v[r] = col ? (int)L.sob[r * SOB_STRIDE + rect_left + c] : 0;
+          mx = imax(mx, v[r]);
+        }
+        L.cmax[lane] = mx;
+        __syncthreads();
+        if (sl < 3) {
+#pragma unroll
+          for (int j = 0; j < 18; j++) mx = imax(mx, L.cmax[sl * 21 + j]);
+        }
         const float scale = mx > 0 ? (float)(255.0 / (double)mx) : 0.0f;
-        int *my = L.scratch + lane * 21;
-        for (int c = 0; c < ciw; c++) {
-          int s = 0;
-          for (int r = 0; r < cih; r++) s += norm_thresh(L.sob[r * SOB_STRIDE + rect_left + c], scale);
-          my[c] = s;
+        int cs = 0;
+        if (sl < 3) {
+#pragma unroll
+          for (int r = 0; r < 21; r++) {
+            const int t = norm_thresh(v[r], scale);
+            cs += t;
+            if (c < 19) tile[(sl * 21 + r) * 19 + c] = t;
+          }
         }
+        L.csum[lane] = cs;
+        __syncthreads();
+        // column trimming (every lane of the slot replays it: uniform within the slot)
         int lc = 0, rc = ciw - 1;
-        for (int wv = ciw; wv > TW; wv--) {
-          if (my[lc] <= my[rc]) lc++;
-          else rc--;
+        if (sl < 3)
+          for (int wv = ciw; wv > TW; wv--) {
+            if (L.csum[sl * 21 + lc] <= L.csum[sl * 21 + rc]) lc++;
+            else rc--;
+          }
+        int rsm = 0;
+        if (sl < 3)  // lane c is row c here
+          for (int cc = lc; cc <= rc; cc++) rsm += tile[(sl * 21 + c) * 19 + cc];
+        __syncthreads();
+        L.cmax[lane] = rsm;  // row sums
+        __syncthreads();
+        if (sl < 3 && c == 0 && have) {
+          int tr = 0, brw = cih - 1;
+          for (int hv = cih; hv > TH; hv--) {
+            if (L.cmax[sl * 21 + tr] <= L.cmax[sl * 21 + brw]) tr++;
+            else brw--;
+          }
+          L.okeep[k] = valid ? 1 : 0;
+          L.oLeft[k] = rect_left + lc;
+          L.oTop[k] = (g_top - 2) + tr;
         }
-        for (int r = 0; r < cih; r++) {
-          int s = 0;
-          for (int c = lc; c <= rc; c++) s += norm_thresh(L.sob[r * SOB_STRIDE + rect_left + c], scale);
-          my[r] = s;
-        }
-        int tr = 0, brw = cih - 1;
-        for (int hv = cih; hv > TH; hv--) {
-          if (my[tr] <= my[brw]) tr++;
-          else brw--;
-        }
-        c_left = rect_left + lc;
-        c_top = rect_top + tr;
+        __syncthreads();
       }
     }
+    const bool keep = lane >= rs && lane < re && L.okeep[lane] != 0;
     const unsigned long long kbal = __ballot(keep);
     const int n2 = __popcll(kbal);
     if (keep) {
       const int pos = __popcll(kbal & lanemask_lt(lane));
-      L.cLeft[pos] = c_left;
-      L.cTop[pos] = c_top;
+      L.cLeft[pos] = L.oLeft[lane];
+      L.cTop[pos] = L.oTop[lane];
     }
     __syncthreads();
-    if (n2 < 5) continue;  // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623)
+    if (n2 < 5 || DMZ_XSEG_STOP == 7) continue;  // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623)
 
-    // ---- slash search (643-674): character first+2 of every window of five ----
-    for (int p = 2; p + 2 < n2; p++) {
-      const int pl = L.cLeft[p], pt = L.cTop[p] - (base - 3);
-      for (int i = lane; i < TW * TH; i += 64) {
-        const int r = i / TW, c = i - r * TW;
-        L.xs[i] = (float)L.sob[(pt + r) * SOB_STRIDE + pl + c] * (1.0f / 255.0f);
+    // ---- slash search (643-674): character first+2 of every window of five.  Four candidates
+    // share each pass over the 176 x 80 hidden matrix (applym_730c4cbd: 176 -> 80 tanh -> 2
+    // softmax, sequential dot products as the generated code evaluates them). ----
+    for (int p0 = 2; p0 + 2 < n2; p0 += 4) {
+      const int nc = imin(4, n2 - 2 - p0);
+      for (int i = lane; i < 4 * TW * TH; i += 64) {
+        const int q = i & 3, e = i >> 2;
+        float xv = 0.0f;
+        if (q < nc) {
+          const int r = e / TW, c = e - r * TW;
+          const int pl = L.cLeft[p0 + q], pt = L.cTop[p0 + q] - (base - 3);
+          xv = (float)L.sob[(pt + r) * SOB_STRIDE + pl + c] * (1.0f / 255.0f);
+        }
+        L.xs[i] = xv;  // [176][4]
       }
       __syncthreads();
-      // applym_730c4cbd: 176 -> 80 tanh -> 2 softmax; sequential dot products
       {
         const float *w1t = xw + dmzx::SLASH_W1T;
         const int j1 = imin(64 + lane, 79);
-        float s0 = 0.0f, s1 = 0.0f;
+        float s0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
         for (int i = 0; i < 176; i++) {
-          const float xi = L.xs[i];
-          s0 += w1t[i * 80 + lane] * xi;
-          s1 += w1t[i * 80 + j1] * xi;
+          const float4 xi = *(const float4 *)(L.xs + 4 * i);
+          const float wa = w1t[i * 80 + lane], wb = w1t[i * 80 + j1];
+          s0[0] += wa * xi.x, s0[1] += wa * xi.y, s0[2] += wa * xi.z, s0[3] += wa * xi.w;
+          s1[0] += wb * xi.x, s1[1] += wb * xi.y, s1[2] += wb * xi.z, s1[3] += wb * xi.w;
         }
         const float *sw = wts + dmzw::SLASH;
-        L.hid[lane] = tanhf(s0 + sw[dmzw::S_B1 + lane]);
-        if (lane < 16) L.hid[64 + lane] = tanhf(s1 + sw[dmzw::S_B1 + 64 + lane]);
+        const float ba = sw[dmzw::S_B1 + lane], bb = sw[dmzw::S_B1 + j1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          L.hid[q * 80 + lane] = tanhf(s0[q] + ba);
+          if (lane < 16) L.hid[q * 80 + 64 + lane] = tanhf(s1[q] + bb);
+        }
       }
       __syncthreads();
-      float e = 0.0f;
-      if (lane < 2) {
+      // lanes 2q, 2q+1: the two output units of candidate q
+      float e = 1.0f;
+      {
+        const int q = (lane >> 1) & 3, o = lane & 1;
         const float *sw = wts + dmzw::SLASH;
-        float s = 0.0f;
-        for (int j = 0; j < 80; j++) s += sw[dmzw::S_W2 + lane * 80 + j] * L.hid[j];
-        e = expf(s + sw[dmzw::S_B2 + lane]);
+        float sacc = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < 80; j++) sacc += sw[dmzw::S_W2 + o * 80 + j] * L.hid[q * 80 + j];
+        e = expf(sacc + sw[dmzw::S_B2 + o]);
       }
-      const float e0 = __shfl(e, 0, 64), e1 = __shfl(e, 1, 64);
-      const float p0 = e0 / (e0 + e1);
-      if (p0 > 0.7f) {
-        if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
-          const int first = p - 2;
-          int top = L.cTop[first], gleft = L.cLeft[first], gwidth = SCW, gheight = SCH;
-          for (int i = 0; i < 5; i++) {
-            const int ct = L.cTop[first + i], cl = L.cLeft[first + i];
-            const int former_bottom = top + gheight;
-            top = imin(ct, top);
-            gwidth = (cl + SCW) - gleft;
-            gheight = imax(ct + SCH, former_bottom) - top;
+      for (int q = 0; q < nc; q++) {
+        const float e0 = __shfl(e, 2 * q, 64), e1 = __shfl(e, 2 * q + 1, 64);
+        const float prob = e0 / (e0 + e1);
+        if (prob > 0.7f) {
+          if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
+            const int first = p0 + q - 2;
+            int top = L.cTop[first], gleft = L.cLeft[first], gwidth = SCW, gheight = SCH;
+            for (int i = 0; i < 5; i++) {
+              const int ct = L.cTop[first + i], cl = L.cLeft[first + i];
+              const int former_bottom = top + gheight;
+              top = imin(ct, top);
+              gwidth = (cl + SCW) - gleft;
+              gheight = imax(ct + SCH, former_bottom) - top;
+            }
+            short *h = sg->hdr[n_emitted];
+            h[0] = (short)top, h[1] = (short)gleft, h[2] = (short)gwidth, h[3] = (short)gheight;
+            for (int i = 0; i < 5; i++) {
+              h[4 + i] = (short)L.cTop[first + i];
+              h[9 + i] = (short)L.cLeft[first + i];
+            }
+            h[14] = (short)base;
+            h[15] = 0;
           }
-          short *h = sg->hdr[n_emitted];
-          h[0] = (short)top, h[1] = (short)gleft, h[2] = (short)gwidth, h[3] = (short)gheight;
-          for (int i = 0; i < 5; i++) {
-            h[4 + i] = (short)L.cTop[first + i];
-            h[9 + i] = (short)L.cLeft[first + i];
-          }
-          h[14] = (short)base;
-          h[15] = 0;
+          n_emitted++;
         }
-        n_emitted++;
       }
       __syncthreads();
     }
@@ -525,6 +621,7 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
 // Expiry digit CNN (applyc_bf4dd6c8) for up to four 16x11 inputs resident in LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int XC_THREADS = 256;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XIN_W = 19, XIN_H = 24;  // zero-padded input: 4 rows/cols of padding before, 4/4 after
 struct CatLds {
   float l1[4 * 50 * 70];        // 56,000 B; prep-time scratch overlays it
@@ -561,78 +658,88 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
     S.xin[d * XIN_H * XIN_W + (r + 4) * XIN_W + (c + 4)] = S.xf[i] - S.mean[d];
   }
   __syncthreads();
-  // layer 1: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU
-  if (tid < 50 * nd) {
-    const int d = tid / 50, k = tid - d * 50;
-    float w[25];
+  // layer 1: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU.
+  // Work item = (map pair, digit, pooled row): v_pk_fma_f32 carries two maps per instruction;
+  // the 6 x 18 input strip of the pooled row sits in registers for its seven outputs.
+  for (int idx = tid; idx < 25 * nd * 10; idx += XC_THREADS) {
+    const int pr = idx / (25 * nd), rem = idx - pr * (25 * nd);
+    const int d = rem / 25, kp = rem - d * 25;
+    f32x2 w[25];
 #pragma unroll
-    for (int i = 0; i < 25; i++) w[i] = xm[dmzw::X_C1W + k * 25 + i];
-    const float bias = xm[dmzw::X_C1B + k];
-    const float *xi = S.xin + d * XIN_H * XIN_W;
-    float *o = S.l1 + (d * 50 + k) * 70;
-    for (int pr = 0; pr < 10; pr++)
-      for (int pc = 0; pc < 7; pc++) {
-        float patch[6][6];
+    for (int i = 0; i < 25; i++) w[i] = (f32x2){xm[dmzw::X_C1W + (2 * kp) * 25 + i], xm[dmzw::X_C1W + (2 * kp + 1) * 25 + i]};
+    const f32x2 bias = {xm[dmzw::X_C1B + 2 * kp], xm[dmzw::X_C1B + 2 * kp + 1]};
+    const float *xi = S.xin + d * XIN_H * XIN_W + (2 * pr) * XIN_W;
+    float strip[6][18];
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+    for (int a = 0; a < 6; a++)
 #pragma unroll
-          for (int b = 0; b < 6; b++) patch[a][b] = xi[(2 * pr + a) * XIN_W + 2 * pc + b];
-        float m = 0.0f;
+      for (int b = 0; b < 18; b++) strip[a][b] = xi[a * XIN_W + b];
+    float *o0 = S.l1 + (d * 50 + 2 * kp) * 70 + pr * 7, *o1 = o0 + 70;
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+    for (int pc = 0; pc < 7; pc++) {
+      f32x2 m = {0.0f, 0.0f};
 #pragma unroll
-          for (int b = 0; b < 2; b++) {
-            float s = 0.0f;
+      for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int i = 0; i < 5; i++)
+        for (int b = 0; b < 2; b++) {
+          f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
-              for (int j = 0; j < 5; j++) s = fmaf(w[i * 5 + j], patch[a + i][b + j], s);
-            m = (a == 0 && b == 0) ? s : fmaxf(m, s);
-          }
-        const float v = m + bias;
-        o[pr * 7 + pc] = v > 0.0f ? v : 0.0f;
-      }
+          for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+              const float x = strip[a + i][2 * pc + b + j];
+              acc = __builtin_elementwise_fma(w[i * 5 + j], (f32x2){x, x}, acc);
+            }
+          m = (a == 0 && b == 0) ? acc : __builtin_elementwise_max(m, acc);
+        }
+      const f32x2 v = m + bias;
+      o0[pc] = v.x > 0.0f ? v.x : 0.0f;
+      o1[pc] = v.y > 0.0f ? v.y : 0.0f;
+    }
   }
   __syncthreads();
-  // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU
-  if (tid < 40 * nd) {
-    const int d = tid / 40, k = tid - d * 40;
-    const float *c2t = xw + dmzx::CONV2_T;
-    float acc[18];
+  // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU.
+  // Work item = (map pair, digit, pooled row): the six positions under one pooled output.
+  if (tid < 20 * nd * 3) {
+    const int g = tid / (20 * nd), rem = tid - g * (20 * nd);
+    const int d = rem / 20, kp = rem - d * 20;
+    const float *c2t = xw + dmzx::CONV2_T + 2 * kp;
+    f32x2 acc[6];
 #pragma unroll
-    for (int i = 0; i < 18; i++) acc[i] = 0.0f;
+    for (int i = 0; i < 6; i++) acc[i] = (f32x2){0.0f, 0.0f};
     for (int m = 0; m < 50; m++) {
-      float in[70];
-      const float2 *src = (const float2 *)(S.l1 + (d * 50 + m) * 70);
+      float in[42];
+      const float2 *src = (const float2 *)(S.l1 + (d * 50 + m) * 70 + 14 * g);
 #pragma unroll
-      for (int i = 0; i < 35; i++) {
+      for (int i = 0; i < 21; i++) {
         const float2 t = src[i];
         in[2 * i] = t.x;
         in[2 * i + 1] = t.y;
       }
-      float w[25];
+      f32x2 w[25];
 #pragma unroll
-      for (int i = 0; i < 25; i++) w[i] = c2t[(m * 25 + i) * 40 + k];
+      for (int i = 0; i < 25; i++) {
+        const float2 t = *(const float2 *)(c2t + (m * 25 + i) * 40);
+        w[i] = (f32x2){t.x, t.y};
+      }
 #pragma unroll
       for (int i = 0; i < 5; i++)
 #pragma unroll
         for (int j = 0; j < 5; j++)
 #pragma unroll
-          for (int r = 0; r < 6; r++)
+          for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[r * 3 + c] = fmaf(w[i * 5 + j], in[(r + i) * 7 + c + j], acc[r * 3 + c]);
+            for (int c = 0; c < 3; c++) {
+              const float x = in[(a + i) * 7 + c + j];
+              acc[a * 3 + c] = __builtin_elementwise_fma(w[i * 5 + j], (f32x2){x, x}, acc[a * 3 + c]);
+            }
     }
-    const float bias = xm[dmzw::X_C2B + k];
+    f32x2 m = acc[0];
 #pragma unroll
-    for (int pr = 0; pr < 3; pr++) {
-      float m = acc[(2 * pr) * 3];
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) m = fmaxf(m, acc[(2 * pr + a) * 3 + b]);
-      const float v = m + bias;
-      S.l2[d * 120 + k * 3 + pr] = v > 0.0f ? v : 0.0f;
-    }
+    for (int i = 1; i < 6; i++) m = __builtin_elementwise_max(m, acc[i]);
+    const f32x2 v = m + (f32x2){xm[dmzw::X_C2B + 2 * kp], xm[dmzw::X_C2B + 2 * kp + 1]};
+    S.l2[d * 120 + (2 * kp) * 3 + g] = v.x > 0.0f ? v.x : 0.0f;
+    S.l2[d * 120 + (2 * kp + 1) * 3 + g] = v.y > 0.0f ? v.y : 0.0f;
   }
   __syncthreads();
   // FC 120 -> 176, ReLU

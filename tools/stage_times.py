@@ -14,12 +14,13 @@ ctx = pkg.Context(0)
 y = ctx.alloc(B * pkg.FRAME_BYTES)
 res = ctx.alloc(B * 1024)
 cards = ctx.alloc(B * pkg.CARD_BYTES)
+exp = ctx.alloc(B * pkg.EXPIRY_DTYPE.itemsize)
 ctx.synth_frames(0xCA4D10, 0, B, y.ptr)
-ctx.pipeline(y.ptr, B, res.ptr, cards.ptr)
+ctx.pipeline_expiry(y.ptr, B, res.ptr, exp.ptr, cards.ptr)
 ctx.set_profiling(True)
 ctx.stage_times()
 for _ in range(reps):
-    ctx.pipeline(y.ptr, B, res.ptr, cards.ptr)
+    ctx.pipeline_expiry(y.ptr, B, res.ptr, exp.ptr, cards.ptr)
 t = ctx.stage_times()
 tot = 0.0
 out = []
