@@ -31,8 +31,6 @@ constexpr int CW = DMZ_CARD_WIDTH, CH = DMZ_CARD_HEIGHT;
 constexpr int kNumberHeight = 27;  // dmz_constants.h kNumberHeight
 constexpr int SCW = 9, SCH = 15;   // kSmallCharacterWidth / Height, expiry_types.h:16-17
 constexpr int TW = 11, TH = 16;    // kTrimmedCharacterImageWidth / Height, expiry_types.h:18-19
-constexpr int SOB_ROWS = 21;       // rows base-3 .. base+17 of the Scharr image
-constexpr int SOB_STRIDE = 432;    // shorts per row in LDS
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -159,6 +157,11 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 
 // ---------------------------------------------------------------------------------------------
 // k_expiry_seg: one wave per (frame, stripe)
+//
+// LDS (19.4 KB -> 8 workgroups per CU): the horizontal pass of the Scharr operator,
+// inter[t][c] = |p[c+1] - p[c-1]| as bytes for the 23 image rows base-4 .. base+18; a Scharr sample
+// is 3 (inter[k] + inter[k+2]) + 10 inter[k+1], three byte reads -- half the footprint of parking
+// the int16 samples, which is what buys the occupancy for this latency-bound list logic.
 // ---------------------------------------------------------------------------------------------
 // developer ablation (tools/ablate.sh): -DDMZ_XSEG_STOP=k returns after phase k
 #ifndef DMZ_XSEG_STOP
@@ -169,32 +172,47 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
     if (lane == 0) sg->n = (int)(expr) & 0;    \
     return;                                    \
   }
+constexpr int IROWS = 23;    // inter rows: image rows base-4 .. base+18 (clamped to the ROI)
+constexpr int ISTRIDE = 432; // bytes per inter row
 struct SegLds {
-  short sob[SOB_ROWS * SOB_STRIDE];  // |Scharr dx| rows base-3 .. base+17
-  int colA[432];                     // column sums over rows base .. base+16 (rect sums), later the pick map
-  int colB[432];                     // column sums over rows base-1 .. base+15 (regrid_group)
-  int rsum[432];                     // 9-wide sliding rect sums
-  int itemL[64], itemS[64];          // non-overlapping rects sorted by left
-  int gstart[66];
-  int gL[64], gW[64];                // surviving local groups
-  int rL[64], rS[64];                // regridded rects of the current group
-  int cLeft[64], cTop[64];           // optimised character rects of the current group
+  unsigned char inter[IROWS * ISTRIDE];  // 9,936 B
+  int colB[432];                         // column sums over rows base-1 .. base+15 (regrid_group)
+  union {
+    struct {                             // until the local groups are formed
+      int colA[432];                     // column sums over rows base .. base+16, later the pick map
+      int rsum[432];                     // 9-wide sliding rect sums
+      int itemL[64], itemS[64];          // non-overlapping rects sorted by left
+      int gstart[66];
+    } a;
+    struct {                             // per group
+      int tile[3 * 21 * 19];             // thresholded tiles of optimize_character_rects
+    } b;
+  } u;
+  int gL[64], gW[64];                    // surviving local groups
+  int rL[64], rS[64];                    // regridded rects of the current group
+  int cLeft[64], cTop[64];               // optimised character rects of the current group
   int okeep[64], oLeft[64], oTop[64];
   int cmax[64], csum[64];
-  int scratch[3 * 21 * 19];          // thresholded tiles of optimize_character_rects
-  __attribute__((aligned(16))) float xs[4 * 176];  // [176][4]: four slash candidates interleaved
-  float hid[4 * 80];
 };
 
-// |p[c+1] - p[c-1]| of the four pixels of dword d of a row, column index clamped (sobel.cpp:729-734)
-__device__ __forceinline__ void scharr_inter4(const uint32_t *__restrict__ row, int d, int v[4]) {
+// four |p[c+1] - p[c-1]| of dword d of a row, column index clamped (sobel.cpp:729-734), as bytes
+__device__ __forceinline__ uint32_t scharr_inter4(const uint32_t *__restrict__ row, int d) {
   const uint32_t cur = row[d];
   const uint32_t prev = d > 0 ? row[d - 1] : 0u;
   const uint32_t next = d < 106 ? row[d + 1] : 0u;
   const uint32_t left = d > 0 ? __builtin_amdgcn_alignbyte(cur, prev, 3) : ((cur << 8) | (cur & 0xFFu));
   const uint32_t right = d < 106 ? __builtin_amdgcn_alignbyte(next, cur, 1) : ((cur >> 8) | (cur & 0xFF000000u));
+  uint32_t out = 0u;
 #pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = iabs((int)((right >> (8 * k)) & 255u) - (int)((left >> (8 * k)) & 255u));
+  for (int k = 0; k < 4; k++)
+    out |= (uint32_t)iabs((int)((right >> (8 * k)) & 255u) - (int)((left >> (8 * k)) & 255u)) << (8 * k);
+  return out;
+}
+
+// |Scharr dx| at window row k (image row base-3+k, k = 0..20) and column c; vmask = rows inside the ROI
+__device__ __forceinline__ int sob_at(const unsigned char *__restrict__ inter, unsigned vmask, int k, int c) {
+  const int a = inter[k * ISTRIDE + c], b = inter[(k + 1) * ISTRIDE + c], d = inter[(k + 2) * ISTRIDE + c];
+  return ((vmask >> k) & 1u) ? 3 * (a + d) + 10 * b : 0;
 }
 
 // strip_group_white_space (expiry_seg.cpp:101-129) on the index range [s, e) of a sum array
@@ -215,11 +233,21 @@ __device__ __forceinline__ int norm_thresh(int v, float scale) {
   return iv > 100 ? iv : 0;
 }
 
-__global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
-                                                   const uint8_t *__restrict__ cards, size_t card_stride, int n,
-                                                   const dmz_hip_frame_result *__restrict__ results,
-                                                   const dmz_hip_expiry_result *__restrict__ er,
-                                                   DmzExpiryStage *__restrict__ stage) {
+__device__ __forceinline__ float row16_sum(float x) {  // total of a 16-lane DPP row, in its lane 15
+  x += __builtin_bit_cast(float, DMZ_DPP_SHR(__builtin_bit_cast(int, x), 1));
+  x += __builtin_bit_cast(float, DMZ_DPP_SHR(__builtin_bit_cast(int, x), 2));
+  x += __builtin_bit_cast(float, DMZ_DPP_SHR(__builtin_bit_cast(int, x), 4));
+  x += __builtin_bit_cast(float, DMZ_DPP_SHR(__builtin_bit_cast(int, x), 8));
+  return x;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                      const uint8_t *__restrict__ cards, size_t card_stride, int n,
+                                                      const dmz_hip_frame_result *__restrict__ results,
+                                                      const dmz_hip_expiry_result *__restrict__ er,
+                                                      DmzExpiryStage *__restrict__ stage) {
   const int f = blockIdx.x / 3, st = blockIdx.x - f * 3, lane = threadIdx.x;
   if (f >= n) return;
   if (st >= er[f].n_stripes) return;
@@ -230,76 +258,78 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
   const uint8_t *card = cards + (size_t)f * card_stride;
   DmzExpiryStage *sg = stage + (size_t)f * 3 + st;
   int n_emitted = 0;
+  // window rows k = 0..20 <-> image rows base-3+k; the Scharr image is zero outside [y0, 269]
+  unsigned vmask = 0u;
+  for (int k = 0; k < 21; k++) {
+    const int R = base - 3 + k;
+    if (R >= y0 && R <= CH - 1) vmask |= 1u << k;
+  }
 
-  // ---- |Scharr dx| of rows base-3 .. base+17 (zero outside the ROI [y0, 269]) ----
+  // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766) ----
   {
     const int d0 = lane, d1 = lane + 64;
     const bool has1 = d1 < 107;
-    int ia[2][4], ib[2][4], ic[2][4];
 #pragma unroll
-    for (int t = 0; t < SOB_ROWS + 2; t++) {
+    for (int t = 0; t < IROWS; t++) {
       const int rowc = imin(imax(base - 4 + t, y0), CH - 1);
       const uint32_t *row = (const uint32_t *)(card + (size_t)rowc * CW);
-      scharr_inter4(row, d0, ic[0]);
-      if (has1) scharr_inter4(row, d1, ic[1]);
-      if (t >= 2) {
-        const int k = t - 2, R = base - 3 + k;
-        const bool valid = R >= y0 && R <= CH - 1;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          if (h == 1 && !has1) break;
-          int v[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) v[q] = valid ? 3 * (ia[h][q] + ic[h][q]) + 10 * ib[h][q] : 0;
-          uint32_t *dst = (uint32_t *)(L.sob + k * SOB_STRIDE + 4 * (h ? d1 : d0));
-          dst[0] = (uint32_t)(v[0] & 0xFFFF) | ((uint32_t)v[1] << 16);
-          dst[1] = (uint32_t)(v[2] & 0xFFFF) | ((uint32_t)v[3] << 16);
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          ia[h][q] = ib[h][q];
-          ib[h][q] = ic[h][q];
-        }
+      *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d0) = scharr_inter4(row, d0);
+      if (has1) *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d1) = scharr_inter4(row, d1);
     }
   }
   __syncthreads();
-  XSEG_STOP(1, L.sob[lane])
+  XSEG_STOP(1, L.inter[lane])
 
-  // ---- column sums, sliding 9-wide rect sums (expiry_seg.cpp:456-486) ----
-  for (int c = lane; c < CW; c += 64) {
-    int a = 0;
-    for (int k = 3; k <= 19; k++) a += L.sob[k * SOB_STRIDE + c];
-    L.colA[c] = a;
-    L.colB[c] = a + L.sob[2 * SOB_STRIDE + c] - L.sob[19 * SOB_STRIDE + c];
+  // ---- column sums (four columns per lane from dword reads), sliding 9-wide rect sums (456-486) ----
+  for (int d = lane; d < 107; d += 64) {
+    int a[4] = {0, 0, 0, 0}, s2[4], s19[4];
+    uint32_t w0 = *(const uint32_t *)(L.inter + 2 * ISTRIDE + 4 * d);
+    uint32_t w1 = *(const uint32_t *)(L.inter + 3 * ISTRIDE + 4 * d);
+#pragma unroll
+    for (int k = 2; k <= 19; k++) {
+      const uint32_t w2 = *(const uint32_t *)(L.inter + (k + 2) * ISTRIDE + 4 * d);
+      const bool ok = (vmask >> k) & 1u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int v = ok ? 3 * (int)(((w0 >> (8 * q)) & 255u) + ((w2 >> (8 * q)) & 255u)) + 10 * (int)((w1 >> (8 * q)) & 255u) : 0;
+        if (k == 2) s2[q] = v;
+        else a[q] += v;
+        if (k == 19) s19[q] = v;
+      }
+      w0 = w1;
+      w1 = w2;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      L.u.a.colA[4 * d + q] = a[q];
+      L.colB[4 * d + q] = a[q] + s2[q] - s19[q];
+    }
   }
   __syncthreads();
   for (int c = lane; c < CW - SCW + 1; c += 64) {
     int s = 0;
-    for (int k = 0; k < SCW; k++) s += L.colA[c + k];
-    L.rsum[c] = s;
+#pragma unroll
+    for (int k = 0; k < SCW; k++) s += L.u.a.colA[c + k];
+    L.u.a.rsum[c] = s;
   }
   __syncthreads();
 
-  XSEG_STOP(2, L.rsum[lane])
-  // thresholds (expiry_seg.cpp:447-449, 488-494): the float total is accumulated in column order
-  // While the running total stays below 2^24 every float addition of these integers is exact, so
-  // the float total equals the integer total whenever that is < 2^24 (the common case); only
-  // beyond that the additions round and the reference's column order has to be replayed.
+  XSEG_STOP(2, L.u.a.rsum[lane])
+  // thresholds (expiry_seg.cpp:447-449, 488-494).  While the running total stays below 2^24 every
+  // float addition of these integers is exact, so the float total equals the integer total whenever
+  // that is < 2^24 (the common case); only beyond that the additions round and the reference's
+  // column order has to be replayed.
   const float thr1 = (float)(((stripe_sum * SCW) / CW) / 5);
   float total;
   int cnt;
+  int rs7[7];
   {
     int isum = 0, icnt = 0;
 #pragma unroll
     for (int j = 0; j < 7; j++) {
       const int c = lane + 64 * j;
-      if (c < CW - SCW + 1) {
-        const int sv = L.rsum[c];
-        if ((float)sv > thr1) isum += sv, icnt++;
-      }
+      rs7[j] = c < CW - SCW + 1 ? L.u.a.rsum[c] : 0;
+      if (c < CW - SCW + 1 && (float)rs7[j] > thr1) isum += rs7[j], icnt++;
     }
     // rect sums are < 2^20 and there are <= 420 of them: the integer total fits 32 bits
     isum = wave_sum_i32(isum);
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     } else {
       total = 0.0f;
       for (int c = 0; c < CW - SCW + 1; c++) {
-        const float sv = (float)L.rsum[c];
+        const float sv = (float)L.u.a.rsum[c];
         if (sv > thr1) total += sv;
       }
     }
@@ -325,12 +355,10 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
   for (int j = 0; j < 7; j++) {
     const int c = lane + 64 * j;
     key[j] = 0u;
-    if (c < CW - SCW + 1) {
-      const int s = L.rsum[c];
-      if ((float)s > thr1 && (float)s > thr2) key[j] = ((unsigned)s << 9) | (unsigned)(511 - c);
-    }
+    if (c < CW - SCW + 1 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
+      key[j] = ((unsigned)rs7[j] << 9) | (unsigned)(511 - c);
   }
-  for (int c = lane; c < 432; c += 64) L.colA[c] = 0;  // pick map: sum of the rect picked at column c
+  for (int c = lane; c < 432; c += 64) L.u.a.colA[c] = 0;  // pick map: sum of the rect picked at column c
   __syncthreads();
   for (;;) {
     unsigned m = key[0];
@@ -339,24 +367,24 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     m = wave_max_u32(m);
     if (m == 0u) break;
     const int pl = 511 - (int)(m & 511u);
-    if (lane == 0) L.colA[pl] = (int)(m >> 9);
+    if (lane == 0) L.u.a.colA[pl] = (int)(m >> 9);
 #pragma unroll
     for (int j = 0; j < 7; j++)
       if (iabs(lane + 64 * j - pl) < SCW) key[j] = 0u;  // either end would hit the mask
   }
   __syncthreads();
-  XSEG_STOP(4, L.colA[lane])
+  XSEG_STOP(4, L.u.a.colA[lane])
   // sorted by left = column order
   int n_items = 0;
 #pragma unroll
   for (int j = 0; j < 7; j++) {
     const int c = lane + 64 * j;
-    const int s = c < CW ? L.colA[c] : 0;
+    const int s = c < CW ? L.u.a.colA[c] : 0;
     const unsigned long long bal = __ballot(s != 0);
     if (s != 0) {
       const int pos = n_items + __popcll(bal & lanemask_lt(lane));
-      L.itemL[pos] = c;
-      L.itemS[pos] = s;
+      L.u.a.itemL[pos] = c;
+      L.u.a.itemS[pos] = s;
     }
     n_items += __popcll(bal);
   }
@@ -366,13 +394,13 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
   // ---- gather_into_groups (131-167): chain while the gap is < 9; then strip white space ----
   int n_groups;
   {
-    const int myL = lane < n_items ? L.itemL[lane] : 0;
+    const int myL = lane < n_items ? L.u.a.itemL[lane] : 0;
     const int prevL = __shfl_up(myL, 1, 64);
     const bool boundary = lane < n_items && (lane == 0 || myL - (prevL + SCW) >= SCW);
     const unsigned long long bal = __ballot(boundary);
     n_groups = __popcll(bal);
-    if (boundary) L.gstart[__popcll(bal & lanemask_lt(lane))] = lane;
-    if (lane == 0) L.gstart[n_groups] = n_items;
+    if (boundary) L.u.a.gstart[__popcll(bal & lanemask_lt(lane))] = lane;
+    if (lane == 0) L.u.a.gstart[n_groups] = n_items;
   }
   __syncthreads();
   int G;
@@ -380,20 +408,20 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     int s = 0, e = 0;
     bool keep = false;
     if (lane < n_groups) {
-      s = L.gstart[lane];
-      e = L.gstart[lane + 1];
-      strip_white_space(L.itemS, s, e);
+      s = L.u.a.gstart[lane];
+      e = L.u.a.gstart[lane + 1];
+      strip_white_space(L.u.a.itemS, s, e);
       keep = e - s >= 4;  // kMinimumExpiryStripCharacters - 1 (expiry_seg.cpp:566-571)
     }
     const unsigned long long bal = __ballot(keep);
     G = __popcll(bal);
     if (keep) {
       const int pos = __popcll(bal & lanemask_lt(lane));
-      L.gL[pos] = L.itemL[s];
-      L.gW[pos] = L.itemL[e - 1] + SCW - L.itemL[s];
+      L.gL[pos] = L.u.a.itemL[s];
+      L.gW[pos] = L.u.a.itemL[e - 1] + SCW - L.u.a.itemL[s];
     }
   }
-  __syncthreads();
+  __syncthreads();  // u.a is dead from here on; u.b takes its place
 
   XSEG_STOP(5, G)
   const int g_top = base - 1;  // expanded stripe top; group height 17
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     const int ciw = cw + 4, cih = 17 + 4;
     {
       const int sl = lane / 21, c = lane - sl * 21;
-      int *tile = L.scratch;  // [3][21][19]
+      int *tile = L.u.b.tile;  // [3][21][19]
       for (int b0 = rs; b0 < re; b0 += 3) {
         const int k = b0 + sl;
         const bool have = sl < 3 && k < re;
@@ -479,10 +507,15 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
         const bool col = valid && c < ciw;
         int v[21];
         int mx = 0;
+        {
+          int iv[IROWS];
 #pragma unroll
-        for (int r = 0; r < 21; r++) {
-          v[r] = col ? (int)L.sob[r * SOB_STRIDE + rect_left + c] : 0;
-          mx = imax(mx, v[r]);
+          for (int t = 0; t < IROWS; t++) iv[t] = col ? (int)L.inter[t * ISTRIDE + rect_left + c] : 0;
+#pragma unroll
+          for (int r = 0; r < 21; r++) {
+            v[r] = ((vmask >> r) & 1u) ? 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1] : 0;
+            mx = imax(mx, v[r]);
+          }
         }
         L.cmax[lane] = mx;
         __syncthreads();
@@ -539,80 +572,80 @@ __global__ __launch_bounds__(64) void k_expiry_seg(const float *__restrict__ wts
     __syncthreads();
     if (n2 < 5 || DMZ_XSEG_STOP == 7) continue;  // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623)
 
-    // ---- slash search (643-674): character first+2 of every window of five.  Four candidates
-    // share each pass over the 176 x 80 hidden matrix (applym_730c4cbd: 176 -> 80 tanh -> 2
-    // softmax, sequential dot products as the generated code evaluates them). ----
-    for (int p0 = 2; p0 + 2 < n2; p0 += 4) {
-      const int nc = imin(4, n2 - 2 - p0);
-      for (int i = lane; i < 4 * TW * TH; i += 64) {
-        const int q = i & 3, e = i >> 2;
-        float xv = 0.0f;
-        if (q < nc) {
-          const int r = e / TW, c = e - r * TW;
-          const int pl = L.cLeft[p0 + q], pt = L.cTop[p0 + q] - (base - 3);
-          xv = (float)L.sob[(pt + r) * SOB_STRIDE + pl + c] * (1.0f / 255.0f);
-        }
-        L.xs[i] = xv;  // [176][4]
-      }
-      __syncthreads();
-      {
-        const float *w1t = xw + dmzx::SLASH_W1T;
-        const int j1 = imin(64 + lane, 79);
-        float s0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-        for (int i = 0; i < 176; i++) {
-          const float4 xi = *(const float4 *)(L.xs + 4 * i);
-          const float wa = w1t[i * 80 + lane], wb = w1t[i * 80 + j1];
-          s0[0] += wa * xi.x, s0[1] += wa * xi.y, s0[2] += wa * xi.z, s0[3] += wa * xi.w;
-          s1[0] += wb * xi.x, s1[1] += wb * xi.y, s1[2] += wb * xi.z, s1[3] += wb * xi.w;
-        }
-        const float *sw = wts + dmzw::SLASH;
-        const float ba = sw[dmzw::S_B1 + lane], bb = sw[dmzw::S_B1 + j1];
+    // ---- slash search (643-674): character first+2 of every window of five, sixteen candidates
+    // per pass.  applym_730c4cbd (176 -> 80 tanh -> 2 softmax): the hidden layer is a
+    // [16 x 176] x [176 x 80] product on v_mfma_f32_16x16x4_f32 -- A[m = lane & 15][k = lane >> 4]
+    // is candidate m's Scharr sample k (built from three inter bytes), B the input-major copy of
+    // the weights; D[row = candidate][col = hidden unit] comes back as 4 candidates x 5 tiles per
+    // lane.  The output layer is a DPP row reduction over the 16 lanes that share a candidate. ----
+    for (int p0 = 2; p0 + 2 < n2; p0 += 16) {
+      const int nc = imin(16, n2 - 2 - p0);
+      const int m = lane & 15, kk = lane >> 4;
+      const bool live = m < nc;
+      const int pl = live ? L.cLeft[p0 + m] : 0, pt = live ? L.cTop[p0 + m] - (base - 3) : 0;
+      const float *w1t = xw + dmzx::SLASH_W1T + m;
+      f32x4 acc[5];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          L.hid[q * 80 + lane] = tanhf(s0[q] + ba);
-          if (lane < 16) L.hid[q * 80 + 64 + lane] = tanhf(s1[q] + bb);
+      for (int t = 0; t < 5; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      int r = 0, c = kk;  // sample index k = 4 ks + kk = 11 r + c
+#pragma unroll 4
+      for (int ks = 0; ks < 44; ks++) {
+        const float a = live ? (float)sob_at(L.inter, vmask, pt + r, pl + c) * (1.0f / 255.0f) : 0.0f;
+        const float *wrow = w1t + (4 * ks + kk) * 80;
+#pragma unroll
+        for (int t = 0; t < 5; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[16 * t], acc[t], 0, 0, 0);
+        c += 4;
+        if (c >= TW) c -= TW, r++;
+      }
+      const float *sw = wts + dmzw::SLASH;
+      float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const int hn = 16 * t + m;
+        const float b1 = sw[dmzw::S_B1 + hn], w20 = sw[dmzw::S_W2 + hn], w21 = sw[dmzw::S_W2 + 80 + hn];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const float h = tanhf(acc[t][v] + b1);
+          o0[v] = fmaf(w20, h, o0[v]);
+          o1[v] = fmaf(w21, h, o1[v]);
         }
       }
-      __syncthreads();
-      // lanes 2q, 2q+1: the two output units of candidate q
-      float e = 1.0f;
-      {
-        const int q = (lane >> 1) & 3, o = lane & 1;
-        const float *sw = wts + dmzw::SLASH;
-        float sacc = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < 80; j++) sacc += sw[dmzw::S_W2 + o * 80 + j] * L.hid[q * 80 + j];
-        e = expf(sacc + sw[dmzw::S_B2 + o]);
+      unsigned hits = 0u;  // bit v: candidate 4 kk + v is a slash (valid in lane 15 of each row)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const float e0 = expf(row16_sum(o0[v]) + sw[dmzw::S_B2 + 0]);
+        const float e1 = expf(row16_sum(o1[v]) + sw[dmzw::S_B2 + 1]);
+        if (e0 / (e0 + e1) > 0.7f) hits |= 1u << v;
       }
+      const unsigned hitmask = (unsigned)__builtin_amdgcn_readlane((int)hits, 15) |
+                               ((unsigned)__builtin_amdgcn_readlane((int)hits, 31) << 4) |
+                               ((unsigned)__builtin_amdgcn_readlane((int)hits, 47) << 8) |
+                               ((unsigned)__builtin_amdgcn_readlane((int)hits, 63) << 12);
       for (int q = 0; q < nc; q++) {
-        const float e0 = __shfl(e, 2 * q, 64), e1 = __shfl(e, 2 * q + 1, 64);
-        const float prob = e0 / (e0 + e1);
-        if (prob > 0.7f) {
-          if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
-            const int first = p0 + q - 2;
-            int top = L.cTop[first], gleft = L.cLeft[first], gwidth = SCW, gheight = SCH;
-            for (int i = 0; i < 5; i++) {
-              const int ct = L.cTop[first + i], cl = L.cLeft[first + i];
-              const int former_bottom = top + gheight;
-              top = imin(ct, top);
-              gwidth = (cl + SCW) - gleft;
-              gheight = imax(ct + SCH, former_bottom) - top;
-            }
-            short *h = sg->hdr[n_emitted];
-            h[0] = (short)top, h[1] = (short)gleft, h[2] = (short)gwidth, h[3] = (short)gheight;
-            for (int i = 0; i < 5; i++) {
-              h[4 + i] = (short)L.cTop[first + i];
-              h[9 + i] = (short)L.cLeft[first + i];
-            }
-            h[14] = (short)base;
-            h[15] = 0;
+        if (!((hitmask >> q) & 1u)) continue;
+        if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
+          const int first = p0 + q - 2;
+          int top = L.cTop[first], gleft = L.cLeft[first], gwidth = SCW, gheight = SCH;
+          for (int i = 0; i < 5; i++) {
+            const int ct = L.cTop[first + i], cl = L.cLeft[first + i];
+            const int former_bottom = top + gheight;
+            top = imin(ct, top);
+            gwidth = (cl + SCW) - gleft;
+            gheight = imax(ct + SCH, former_bottom) - top;
           }
-          n_emitted++;
+          short *h = sg->hdr[n_emitted];
+          h[0] = (short)top, h[1] = (short)gleft, h[2] = (short)gwidth, h[3] = (short)gheight;
+          for (int i = 0; i < 5; i++) {
+            h[4 + i] = (short)L.cTop[first + i];
+            h[9 + i] = (short)L.cLeft[first + i];
+          }
+          h[14] = (short)base;
+          h[15] = 0;
         }
+        n_emitted++;
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
   if (lane == 0) sg->n = n_emitted;
 }
