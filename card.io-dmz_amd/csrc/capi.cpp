@@ -451,7 +451,7 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
       for (int i = 0; i < 176; i++) xw[dmzx::SLASH_W1T + i * 80 + j] = sw[j * 176 + i];
     const float *c2 = w + dmzw::EXPIRY + dmzw::X_C2W;
     for (int k = 0; k < 40; k++)
-      for (int t = 0; t < 1250; t++) xw[dmzx::CONV2_T + t * 40 + k] = c2[k * 1250 + t];
+      for (int t = 0; t < 1250; t++) xw[dmzx::CONV2_P + t * 48 + k] = c2[k * 1250 + t];  // rest stays 0
     const float *hw = w + dmzw::EXPIRY + dmzw::X_HW;
     for (int j = 0; j < 176; j++)
       for (int i = 0; i < 120; i++) xw[dmzx::FC1_T + i * 176 + j] = hw[j * 120 + i];

@@ -95,8 +95,8 @@ struct DmzExpiryTables {
 // Re-laid-out copies of the expiry models (float offsets into one device buffer)
 namespace dmzx {
 constexpr int SLASH_W1T = 0;                      // [176][80]  (input-major)
-constexpr int CONV2_T = SLASH_W1T + 176 * 80;     // [50*25][40]
-constexpr int FC1_T = CONV2_T + 1250 * 40;        // [120][176]
+constexpr int CONV2_P = SLASH_W1T + 176 * 80;     // [1252][48]: tap-major, zero-padded to the MFMA tile grid
+constexpr int FC1_T = CONV2_P + 1252 * 48;        // [120][176]
 constexpr int TOTAL = FC1_T + 120 * 176;
 }  // namespace dmzx
 // offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)

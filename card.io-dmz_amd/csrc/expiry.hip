@@ -195,11 +195,9 @@ struct SegLds {
   int cmax[64], csum[64];
 };
 
-// four |p[c+1] - p[c-1]| of dword d of a row, column index clamped (sobel.cpp:729-734), as bytes
-__device__ __forceinline__ uint32_t scharr_inter4(const uint32_t *__restrict__ row, int d) {
-  const uint32_t cur = row[d];
-  const uint32_t prev = d > 0 ? row[d - 1] : 0u;
-  const uint32_t next = d < 106 ? row[d + 1] : 0u;
+// four |p[c+1] - p[c-1]| of dword d of a row (prev / cur / next = dwords d-1, d, d+1), column index
+// clamped at 0 and 427 (sobel.cpp:729-734), as bytes
+__device__ __forceinline__ uint32_t scharr_inter4(uint32_t prev, uint32_t cur, uint32_t next, int d) {
   const uint32_t left = d > 0 ? __builtin_amdgcn_alignbyte(cur, prev, 3) : ((cur << 8) | (cur & 0xFFu));
   const uint32_t right = d < 106 ? __builtin_amdgcn_alignbyte(next, cur, 1) : ((cur >> 8) | (cur & 0xFF000000u));
   uint32_t out = 0u;
@@ -265,16 +263,32 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
     if (R >= y0 && R <= CH - 1) vmask |= 1u << k;
   }
 
-  // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766) ----
+  // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766).
+  // Each dword of a row is loaded once (all 46 loads of a lane in flight together); the
+  // neighbouring dwords come from the adjacent lanes. ----
   {
     const int d0 = lane, d1 = lane + 64;
     const bool has1 = d1 < 107;
+    uint32_t c0[IROWS], c1[IROWS];
 #pragma unroll
     for (int t = 0; t < IROWS; t++) {
       const int rowc = imin(imax(base - 4 + t, y0), CH - 1);
       const uint32_t *row = (const uint32_t *)(card + (size_t)rowc * CW);
-      *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d0) = scharr_inter4(row, d0);
-      if (has1) *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d1) = scharr_inter4(row, d1);
+      c0[t] = row[d0];
+      c1[t] = has1 ? row[d1] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < IROWS; t++) {
+      const uint32_t p0 = (uint32_t)__shfl_up((int)c0[t], 1, 64);      // dword d0 - 1 (lane 0: unused)
+      const uint32_t n0s = (uint32_t)__shfl_down((int)c0[t], 1, 64);   // dword d0 + 1 for lanes < 63
+      const uint32_t first1 = (uint32_t)__shfl((int)c1[t], 0, 64);     // dword 64
+      const uint32_t last0 = (uint32_t)__shfl((int)c0[t], 63, 64);     // dword 63
+      const uint32_t p1s = (uint32_t)__shfl_up((int)c1[t], 1, 64);
+      const uint32_t n1 = (uint32_t)__shfl_down((int)c1[t], 1, 64);    // dword d1 + 1 (lane 42: unused)
+      const uint32_t n0 = lane == 63 ? first1 : n0s;
+      const uint32_t p1 = lane == 0 ? last0 : p1s;
+      *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d0) = scharr_inter4(p0, c0[t], n0, d0);
+      if (has1) *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d1) = scharr_inter4(p1, c1[t], n1, d1);
     }
   }
   __syncthreads();
@@ -583,19 +597,35 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
       const int m = lane & 15, kk = lane >> 4;
       const bool live = m < nc;
       const int pl = live ? L.cLeft[p0 + m] : 0, pt = live ? L.cTop[p0 + m] - (base - 3) : 0;
-      const float *w1t = xw + dmzx::SLASH_W1T + m;
+      const float *w1t = xw + dmzx::SLASH_W1T + kk * 80 + m;
       f32x4 acc[5];
 #pragma unroll
       for (int t = 0; t < 5; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-      int r = 0, c = kk;  // sample index k = 4 ks + kk = 11 r + c
-#pragma unroll 4
-      for (int ks = 0; ks < 44; ks++) {
-        const float a = live ? (float)sob_at(L.inter, vmask, pt + r, pl + c) * (1.0f / 255.0f) : 0.0f;
-        const float *wrow = w1t + (4 * ks + kk) * 80;
+      // software pipeline: the B operands of the next block of four k-steps (20 loads) are in
+      // flight while the current block multiplies -- the matrix comes from L2 on every pass
+      float bnx[4][5];
 #pragma unroll
-        for (int t = 0; t < 5; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[16 * t], acc[t], 0, 0, 0);
-        c += 4;
-        if (c >= TW) c -= TW, r++;
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) bnx[u][t] = w1t[4 * u * 80 + 16 * t];
+#pragma unroll 1
+      for (int kb = 0; kb < 44; kb += 4) {
+        float bc[4][5];
+        const float *wnext = w1t + (kb < 40 ? 4 * (kb + 4) * 80 : 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) {
+            bc[u][t] = bnx[u][t];
+            bnx[u][t] = wnext[4 * u * 80 + 16 * t];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = 4 * (kb + u) + kk, r = (k * 373) >> 12, c = k - TW * r;  // k / 11, k % 11 for k < 176
+          const float a = live ? (float)sob_at(L.inter, vmask, pt + r, pl + c) * (1.0f / 255.0f) : 0.0f;
+#pragma unroll
+          for (int t = 0; t < 5; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[u][t], acc[t], 0, 0, 0);
+        }
       }
       const float *sw = wts + dmzw::SLASH;
       float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -655,15 +685,16 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 constexpr int XC_THREADS = 256;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int XIN_W = 19, XIN_H = 24;  // zero-padded input: 4 rows/cols of padding before, 4/4 after
+constexpr int XIN_W = 20, XIN_H = 24;  // zero-padded input: 4 rows/cols of padding before, 4/5 after
 struct CatLds {
   float l1[4 * 50 * 70];        // 56,000 B; prep-time scratch overlays it
-  float xin[4 * XIN_H * XIN_W]; // 7,296 B
+  __attribute__((aligned(8))) float xin[4 * XIN_H * XIN_W]; // 7,680 B
   float xf[4 * 176];
   float l2[4 * 120];
   float l3[4 * 176];
   float es[4 * 16];
   float mean[4];
+  __attribute__((aligned(8))) float c1w[25 * 50];  // conv1 weights, tap-major
   short hdr[DMZ_HIP_EXPIRY_MAX_GROUPS][16];
   int n_groups;
 };
@@ -674,10 +705,18 @@ __device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar r
   return a + b;
 }
 
+#ifndef DMZ_XCAT_STOP
+#define DMZ_XCAT_STOP 99
+#endif
 // xf[nd][176] raw inputs -> scores (global, nd x 10 floats at `out`, row stride 10)
-__device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__restrict__ xw, CatLds &S, int nd,
+__device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, const float *__restrict__ xw, CatLds &S, int nd,
                                  float *__restrict__ out, int tid) {
   const float *xm = wts + dmzw::EXPIRY;
+  if (DMZ_XCAT_STOP == 1) return;
+  for (int i = tid; i < 1250; i += XC_THREADS) {
+    const int k = i / 25, t = i - k * 25;
+    S.c1w[t * 50 + k] = xm[dmzw::X_C1W + i];
+  }
   // modelc_bf4dd6c8.cpp:13459: subtract the mean (sequential 176-term sum)
   if (tid < nd) {
     const float *x = S.xf + tid * 176;
@@ -699,17 +738,24 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
     const int d = rem / 25, kp = rem - d * 25;
     f32x2 w[25];
 #pragma unroll
-    for (int i = 0; i < 25; i++) w[i] = (f32x2){xm[dmzw::X_C1W + (2 * kp) * 25 + i], xm[dmzw::X_C1W + (2 * kp + 1) * 25 + i]};
+    for (int i = 0; i < 25; i++) {
+      const float2 t = *(const float2 *)(S.c1w + i * 50 + 2 * kp);
+      w[i] = (f32x2){t.x, t.y};
+    }
     const f32x2 bias = {xm[dmzw::X_C1B + 2 * kp], xm[dmzw::X_C1B + 2 * kp + 1]};
     const float *xi = S.xin + d * XIN_H * XIN_W + (2 * pr) * XIN_W;
-    float strip[6][18];
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int b = 0; b < 18; b++) strip[a][b] = xi[a * XIN_W + b];
     float *o0 = S.l1 + (d * 50 + 2 * kp) * 70 + pr * 7, *o1 = o0 + 70;
-#pragma unroll
+#pragma unroll 1
     for (int pc = 0; pc < 7; pc++) {
+      float patch[6][6];
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const float2 t = *(const float2 *)(xi + a * XIN_W + 2 * pc + 2 * b);
+          patch[a][2 * b] = t.x;
+          patch[a][2 * b + 1] = t.y;
+        }
       f32x2 m = {0.0f, 0.0f};
 #pragma unroll
       for (int a = 0; a < 2; a++)
@@ -720,7 +766,7 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
           for (int i = 0; i < 5; i++)
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-              const float x = strip[a + i][2 * pc + b + j];
+              const float x = patch[a + i][b + j];
               acc = __builtin_elementwise_fma(w[i * 5 + j], (f32x2){x, x}, acc);
             }
           m = (a == 0 && b == 0) ? acc : __builtin_elementwise_max(m, acc);
@@ -731,50 +777,100 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
     }
   }
   __syncthreads();
-  // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU.
-  // Work item = (map pair, digit, pooled row): the six positions under one pooled output.
-  if (tid < 20 * nd * 3) {
-    const int g = tid / (20 * nd), rem = tid - g * (20 * nd);
-    const int d = rem / 20, kp = rem - d * 20;
-    const float *c2t = xw + dmzx::CONV2_T + 2 * kp;
-    f32x2 acc[6];
+  if (DMZ_XCAT_STOP == 2) return;
+  // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU,
+  // as the GEMM  out[p][n] = sum_k patch[p][k] W[k][n]  (p = digit x 18 positions = 72 rows,
+  // n = 40 maps, k = map x 5 x 5 = 1250) on v_mfma_f32_16x16x4_f32: 5 x 3 tiles of 16 x 16, the
+  // k range split over the four waves (A gathered from l1, B from the
+  // tap-major zero-padded weight copy, prefetched one k-step ahead); the four partial sums meet in
+  // LDS (over l1, dead by then) where the 2 x 3 max-pool, bias and ReLU finish the layer.
+  {
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    int baseA[5];
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc[i] = (f32x2){0.0f, 0.0f};
-    for (int m = 0; m < 50; m++) {
-      float in[42];
-      const float2 *src = (const float2 *)(S.l1 + (d * 50 + m) * 70 + 14 * g);
-#pragma unroll
-      for (int i = 0; i < 21; i++) {
-        const float2 t = src[i];
-        in[2 * i] = t.x;
-        in[2 * i + 1] = t.y;
-      }
-      f32x2 w[25];
-#pragma unroll
-      for (int i = 0; i < 25; i++) {
-        const float2 t = *(const float2 *)(c2t + (m * 25 + i) * 40);
-        w[i] = (f32x2){t.x, t.y};
-      }
-#pragma unroll
-      for (int i = 0; i < 5; i++)
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const float x = in[(a + i) * 7 + c + j];
-              acc[a * 3 + c] = __builtin_elementwise_fma(w[i * 5 + j], (f32x2){x, x}, acc[a * 3 + c]);
-            }
+    for (int mt = 0; mt < 5; mt++) {
+      const int pp = 16 * mt + m16, pc = pp < 72 ? pp : 0;
+      const int d = pc / 18, pos = pc - 18 * d, r = pos / 3, c = pos - 3 * r;
+      baseA[mt] = d * 3500 + r * 7 + c;
     }
-    f32x2 m = acc[0];
+    f32x4 acc[5][3];
 #pragma unroll
-    for (int i = 1; i < 6; i++) m = __builtin_elementwise_max(m, acc[i]);
-    const f32x2 v = m + (f32x2){xm[dmzw::X_C2B + 2 * kp], xm[dmzw::X_C2B + 2 * kp + 1]};
-    S.l2[d * 120 + (2 * kp) * 3 + g] = v.x > 0.0f ? v.x : 0.0f;
-    S.l2[d * 120 + (2 * kp + 1) * 3 + g] = v.y > 0.0f ? v.y : 0.0f;
+    for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 3; nt++) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const float *c2p = xw + dmzx::CONV2_P + m16;
+    const int ks0 = wave * 79, ks1 = imin(ks0 + 79, 313);
+    // k -> offset of tap (map, i, j) inside l1[d]; the two padded k rows multiply zero weights
+    auto tap_off = [](int k) {
+      const int mp = (k * 1311) >> 15, t = k - 25 * mp, i = (t * 13) >> 6;  // k / 25, k % 25, t / 5
+      return k < 1250 ? mp * 70 + i * 7 + (t - 5 * i) : 0;
+    };
+    // B (global, L2 latency) is fetched one block of four k-steps ahead, A (LDS) one k-step ahead
+    float bnx[4][3], an[5];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int nt = 0; nt < 3; nt++) bnx[u][nt] = c2p[(4 * imin(ks0 + u, ks1 - 1) + kk) * 48 + 16 * nt];
+    {
+      const int off = tap_off(4 * ks0 + kk);
+#pragma unroll
+      for (int mt = 0; mt < 5; mt++) an[mt] = S.l1[baseA[mt] + off];
+    }
+    for (int kb = ks0; kb < ks1; kb += 4) {
+      float bc[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+          bc[u][nt] = bnx[u][nt];
+          bnx[u][nt] = c2p[(4 * imin(kb + 4 + u, ks1 - 1) + kk) * 48 + 16 * nt];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int ks = kb + u;
+        if (ks < ks1) {  // uniform per wave
+          float av[5];
+#pragma unroll
+          for (int mt = 0; mt < 5; mt++) av[mt] = an[mt];
+          const int off = tap_off(4 * imin(ks + 1, ks1 - 1) + kk);
+#pragma unroll
+          for (int mt = 0; mt < 5; mt++) an[mt] = S.l1[baseA[mt] + off];
+#pragma unroll
+          for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bc[u][nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with l1
+    float *part = S.l1;  // [4 waves][72][40]
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int pp = 16 * mt + 4 * kk + v, nn = 16 * nt + m16;
+          if (pp < 72 && nn < 40) part[(wave * 72 + pp) * 40 + nn] = acc[mt][nt][v];
+        }
+    __syncthreads();
+    for (int idx = tid; idx < nd * 120; idx += XC_THREADS) {
+      const int d = idx / 120, rem = idx - d * 120, nn = rem / 3, pr = rem - nn * 3;
+      float m = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int pp = d * 18 + 6 * pr + q;
+        const float t = (part[(0 * 72 + pp) * 40 + nn] + part[(1 * 72 + pp) * 40 + nn]) +
+                        (part[(2 * 72 + pp) * 40 + nn] + part[(3 * 72 + pp) * 40 + nn]);
+        m = q == 0 ? t : fmaxf(m, t);
+      }
+      const float v = m + xm[dmzw::X_C2B + nn];
+      S.l2[idx] = v > 0.0f ? v : 0.0f;
+    }
   }
   __syncthreads();
+  if (DMZ_XCAT_STOP == 3) return;
   // FC 120 -> 176, ReLU
   {
     const float *fc1t = xw + dmzx::FC1_T;
@@ -782,6 +878,7 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
       const int d = idx / 176, j = idx - d * 176;
       const float *l2 = S.l2 + d * 120;
       float s = 0.0f;
+#pragma unroll 8
       for (int i = 0; i < 120; i++) s = fmaf(fc1t[i * 176 + j], l2[i], s);
       const float v = s + xm[dmzw::X_HB + j];
       S.l3[idx] = v > 0.0f ? v : 0.0f;
@@ -794,6 +891,7 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
     const float *lw = xm + dmzw::X_LW + k * 176;
     const float *l3 = S.l3 + d * 176;
     float s = 0.0f;
+#pragma unroll 8
     for (int i = 0; i < 176; i++) s = fmaf(lw[i], l3[i], s);
     S.es[d * 16 + k] = expf(s + xm[dmzw::X_LB + k]);
   }
@@ -805,7 +903,7 @@ __device__ void expiry_cnn_block(const float *__restrict__ wts, const float *__r
   __syncthreads();
 }
 
-__global__ __launch_bounds__(XC_THREADS) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
+__global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
                                                            const DmzExpiryTables *__restrict__ tab,
                                                            const uint8_t *__restrict__ cards, size_t card_stride,
                                                            int n, const dmz_hip_frame_result *__restrict__ results,
@@ -953,7 +1051,7 @@ __global__ __launch_bounds__(64) void k_slash_model(const float *__restrict__ wt
 }
 
 // applyc_bf4dd6c8 on n inputs, four per workgroup
-__global__ __launch_bounds__(XC_THREADS) void k_expiry_model(const float *__restrict__ wts, const float *__restrict__ xw,
+__global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_model(const float *__restrict__ wts, const float *__restrict__ xw,
                                                              const float *__restrict__ x, int n, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   CatLds &S = *(CatLds *)smem_raw;
