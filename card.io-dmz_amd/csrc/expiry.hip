@@ -241,6 +241,12 @@ __device__ __forceinline__ float row16_sum(float x) {  // total of a 16-lane DPP
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32: |error| ~ 2e-7 absolute
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // 2 * log2(e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
                                                       const uint8_t *__restrict__ cards, size_t card_stride, int n,
                                                       const dmz_hip_frame_result *__restrict__ results,
@@ -608,9 +614,17 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
       for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int t = 0; t < 5; t++) bnx[u][t] = w1t[4 * u * 80 + 16 * t];
+      // A operands (Scharr sample k = 4 ks + kk of candidate m) are built one block ahead as well
+      auto a_of = [&](int ks) {
+        const int k = 4 * ks + kk, r = (k * 373) >> 12, c = k - TW * r;  // k / 11, k % 11 for k < 176
+        return live ? (float)sob_at(L.inter, vmask, pt + r, pl + c) * (1.0f / 255.0f) : 0.0f;
+      };
+      float anx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) anx[u] = a_of(u);
 #pragma unroll 1
-      for (int kb = 0; kb < 44; kb += 4) {
-        float bc[4][5];
+      for (int kb = 0; kb < (DMZ_XSEG_STOP == 8 ? 4 : 44); kb += 4) {
+        float bc[4][5], ac[4];
         const float *wnext = w1t + (kb < 40 ? 4 * (kb + 4) * 80 : 0);
 #pragma unroll
         for (int u = 0; u < 4; u++)
@@ -621,11 +635,13 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
           }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int k = 4 * (kb + u) + kk, r = (k * 373) >> 12, c = k - TW * r;  // k / 11, k % 11 for k < 176
-          const float a = live ? (float)sob_at(L.inter, vmask, pt + r, pl + c) * (1.0f / 255.0f) : 0.0f;
-#pragma unroll
-          for (int t = 0; t < 5; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[u][t], acc[t], 0, 0, 0);
+          ac[u] = anx[u];
+          anx[u] = a_of(imin(kb + 4 + u, 43));
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bc[u][t], acc[t], 0, 0, 0);
       }
       const float *sw = wts + dmzw::SLASH;
       float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
         const float b1 = sw[dmzw::S_B1 + hn], w20 = sw[dmzw::S_W2 + hn], w21 = sw[dmzw::S_W2 + 80 + hn];
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-          const float h = tanhf(acc[t][v] + b1);
+          const float h = DMZ_XSEG_STOP == 9 ? acc[t][v] + b1 : fast_tanh(acc[t][v] + b1);
           o0[v] = fmaf(w20, h, o0[v]);
           o1[v] = fmaf(w21, h, o1[v]);
         }
