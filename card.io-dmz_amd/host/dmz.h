@@ -9,7 +9,9 @@
 // (mz_android.cpp:233-240).  Differences, all forced by dropping Eigen/OpenCV types:
 //   * NumberScores / NumberPredictions are plain arrays (reference: Eigen matrices,
 //     n_categorize.h:14, scan.h:17);
-//   * FrameScanResult has no expiry/name group vectors (expiry is not built yet);
+//   * ExpiryGroupScores is a plain 11 x 10 float array (reference: Eigen, expiry_types.h:47);
+//     CharacterRect.sum of the groups a frame reports is 0 (the device does not return it and
+//     nothing downstream reads it);
 //   * IplImage is declared here with OpenCV 2.4's field layout (types_c.h:462-507) unless
 //     OpenCV's own header was included first.
 // There is NO CPU fallback: without a GPU dmz_context_create() returns NULL and the
@@ -18,6 +20,8 @@
 #define DMZ_HIP_HOST_DMZ_H
 
 #include <stdint.h>
+
+#include <vector>
 
 #ifndef __OPENCV_CORE_TYPES_H__
 #define IPL_DEPTH_8U 8
@@ -93,12 +97,54 @@ typedef struct {
 typedef struct { float v[16][10]; } NumberScores;        // row-major, n_categorize.h:14
 typedef struct { long v[16]; } NumberPredictions;        // scan.h:17
 
+// ---- scan/expiry_types.h:16-79 ----
+#define kSmallCharacterWidth 9
+#define kSmallCharacterHeight 15
+#define kTrimmedCharacterImageWidth 11
+#define kTrimmedCharacterImageHeight 16
+#define kExpiryMaxValidLength 11
+enum ExpiryPattern {
+  ExpiryPatternMMsYY,
+  ExpiryPatternMMs20YY,
+  ExpiryPatternXXsXXsYY,
+  ExpiryPatternXXsXXs20YY,
+  ExpiryPatternMMdMMsYY,
+  ExpiryPatternMMdMMs20YY,
+  ExpiryPatternMMsYYdMMsYY,
+};
+typedef struct { float v[kExpiryMaxValidLength][10]; } ExpiryGroupScores;
+struct CharacterRect {
+  int top;
+  int left;
+  long sum;
+  CharacterRect() : top(0), left(0), sum(0) {}
+  CharacterRect(const int top, const int left, const long sum) : top(top), left(left), sum(sum) {}
+};
+typedef std::vector<CharacterRect> CharacterRectList;
+struct GroupedRects {
+  int top;
+  int left;
+  int width;
+  int height;
+  bool grouped_yet;
+  long sum;
+  int character_width;
+  CharacterRectList character_rects;
+  ExpiryPattern pattern;
+  ExpiryGroupScores scores;
+  int recently_seen_count;  // used when aggregating groups across frames
+  int total_seen_count;     // used when aggregating groups across frames
+};
+typedef std::vector<GroupedRects> GroupedRectsList;
+
 // ---- scan/frame.h:14-28 ----
 typedef struct {
   float focus_score;
   NumberScores scores;
   NHorizontalSegmentation hseg;
   NVerticalSegmentation vseg;
+  GroupedRectsList expiry_groups;
+  GroupedRectsList name_groups;
   bool usable;
   bool upside_down;
   bool flipped;
@@ -126,6 +172,8 @@ typedef struct ScannerState {
   unsigned long timeOfCardNumberCompletionInMilliseconds;
   bool scan_expiry;
   int expiry_month, expiry_year;
+  GroupedRectsList expiry_groups;
+  GroupedRectsList name_groups;
   dmz_context *dmz;  // HIP flavour: the context the frames are scanned on (NULL = process default)
 } ScannerState;
 
@@ -159,6 +207,13 @@ void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_e
                                    FrameScanResult *result);
 void scanner_result(ScannerState *state, ScannerResult *result);
 void scanner_destroy(ScannerState *state);
+
+// the cross-frame half of scan/expiry_categorize.cpp (:162-330), exported for the host-logic tests
+void expiry_aggregate_grouped_rects(GroupedRectsList &aggregated_groups, GroupedRectsList &new_groups);
+void get_stable_expiry_month_and_year(GroupedRects &group, int *expiry_month, int *expiry_year);
+// expiry_categorize.cpp:236-248 accepts dates in the past only in the DMZ_DEBUG / CYTHON_DMZ
+// flavours; the production behaviour is the default here, this switches to the other one
+void dmz_hip_host_allow_past_expiry(bool allow);
 
 // dmz_olm.h:70-104
 dmz_point dmz_create_point(float x, float y);

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <time.h>
 
 #include "../../include/dmz_hip.h"
 
@@ -324,18 +325,161 @@ void scanner_reset(ScannerState *state) {
   state->timeOfCardNumberCompletionInMilliseconds = 0;
   state->scan_expiry = false;
   state->expiry_month = state->expiry_year = 0;
+  state->expiry_groups.clear();
+  state->name_groups.clear();
 }
 
 void scanner_add_frame(ScannerState *state, IplImage *y, FrameScanResult *result) {
   scanner_add_frame_with_expiry(state, y, false, result);
 }
 
+// ---- expiry_categorize.cpp:162-330, the cross-frame (session) half of expiry_extract ----
+#define GROUPED_RECTS_VERTICAL_ALLOWANCE (kTrimmedCharacterImageHeight / 2)
+#define GROUPED_RECTS_HORIZONTAL_ALLOWANCE (kTrimmedCharacterImageWidth / 2)
+#define kExpiryDecayFactor 0.7f
+#define kExpiryMinStability 0.7f
+
+static bool g_allow_past_expiry = false;
+void dmz_hip_host_allow_past_expiry(bool allow) { g_allow_past_expiry = allow; }
+
+// expiry_categorize.cpp:162-228
+void expiry_aggregate_grouped_rects(GroupedRectsList &aggregated_groups, GroupedRectsList &new_groups) {
+  // coalesce equivalent groups within new_groups
+  for (size_t i1 = 0; i1 < new_groups.size(); i1++) {
+    GroupedRects &group1 = new_groups[i1];
+    const int top1 = group1.top, left1 = group1.left;
+    const size_t n1 = group1.character_rects.size();
+    float coalesced = 1;
+    for (size_t i2 = new_groups.size() - 1; i2 > i1; i2--) {
+      GroupedRects &group2 = new_groups[i2];
+      if (abs(group2.top - top1) > GROUPED_RECTS_VERTICAL_ALLOWANCE ||
+          abs(group2.left - left1) > GROUPED_RECTS_HORIZONTAL_ALLOWANCE || group2.character_rects.size() != n1)
+        continue;
+      for (int r = 0; r < kExpiryMaxValidLength; r++)
+        for (int c = 0; c < 10; c++)
+          group1.scores.v[r][c] = ((group1.scores.v[r][c] * coalesced) + group2.scores.v[r][c]) / (coalesced + 1);
+      coalesced++;
+      new_groups.erase(new_groups.begin() + i2);
+    }
+  }
+  // coalesce new_groups with equivalent groups inside aggregated_groups
+  for (GroupedRectsList::iterator old_group = aggregated_groups.begin(); old_group != aggregated_groups.end(); ++old_group) {
+    const int old_top = old_group->top, old_left = old_group->left;
+    const size_t old_n = old_group->character_rects.size();
+    for (int ni = (int)new_groups.size() - 1; ni >= 0; ni--) {
+      GroupedRects &new_group = new_groups[ni];
+      if (abs(new_group.top - old_top) > GROUPED_RECTS_VERTICAL_ALLOWANCE ||
+          abs(new_group.left - old_left) > GROUPED_RECTS_HORIZONTAL_ALLOWANCE ||
+          new_group.character_rects.size() != old_n)
+        continue;
+      old_group->recently_seen_count++;
+      old_group->total_seen_count++;
+      for (int r = 0; r < kExpiryMaxValidLength; r++)
+        for (int c = 0; c < 10; c++)
+          old_group->scores.v[r][c] =
+              (old_group->scores.v[r][c] * kExpiryDecayFactor) + (new_group.scores.v[r][c] * (1 - kExpiryDecayFactor));
+      old_group->top = new_group.top;
+      old_group->left = new_group.left;
+      new_groups.erase(new_groups.begin() + ni);
+    }
+  }
+  // forget aggregated groups that have not been seen for a while
+  for (int oi = (int)aggregated_groups.size() - 1; oi >= 0; oi--) {
+    aggregated_groups[oi].recently_seen_count--;
+    if (aggregated_groups[oi].recently_seen_count <= 0) aggregated_groups.erase(aggregated_groups.begin() + oi);
+  }
+  // add the new, non-equivalent groups
+  for (GroupedRectsList::iterator new_group = new_groups.begin(); new_group != new_groups.end(); ++new_group) {
+    GroupedRects fresh_group(*new_group);
+    fresh_group.recently_seen_count = 3;  // stick around for at least the next couple of frames
+    fresh_group.total_seen_count = 1;
+    aggregated_groups.push_back(fresh_group);
+  }
+}
+
+// expiry_categorize.cpp:230-286
+static void expiry_string_to_expiry_month_and_year(char *expiry_string, GroupedRects &group, int *expiry_month,
+                                                   int *expiry_year) {
+  int month = -1, year = -1;
+  if (group.pattern == ExpiryPatternMMsYY && expiry_string[0] != ' ' && expiry_string[1] != ' ' &&
+      expiry_string[3] != ' ' && expiry_string[4] != ' ') {
+    month = ((uint8_t)expiry_string[0] - (uint8_t)'0') * 10 + ((uint8_t)expiry_string[1] - (uint8_t)'0');
+    year = ((uint8_t)expiry_string[3] - (uint8_t)'0') * 10 + ((uint8_t)expiry_string[4] - (uint8_t)'0');
+  }
+  if (month > 12 && year > 0 && year <= 12) {  // YY/MM cards
+    const int temp = month;
+    month = year;
+    year = temp;
+  }
+  int full_year = year + 2000;
+  if (month > 0 && month <= 12 &&
+      (full_year > *expiry_year || ((full_year == *expiry_year) && month > *expiry_month))) {
+    time_t now = time(NULL);
+    struct tm *time_struct = localtime(&now);
+    const int current_year = time_struct->tm_year + 1900, current_month = time_struct->tm_mon + 1;
+    if (full_year < current_year + 5 &&
+        (full_year > current_year || (full_year == current_year && month >= current_month))) {
+      *expiry_month = month;
+      *expiry_year = full_year;
+    } else if (g_allow_past_expiry) {  // the DMZ_DEBUG || CYTHON_DMZ branch
+      if (year > 60) full_year = year + 1900;
+      if (full_year < current_year + 5) {
+        *expiry_month = month;
+        *expiry_year = full_year;
+      }
+    }
+  }
+}
+
+// expiry_categorize.cpp:288-330
+void get_stable_expiry_month_and_year(GroupedRects &group, int *expiry_month, int *expiry_year) {
+  char expiry_string[128];
+  memset(expiry_string, 0, sizeof(expiry_string));
+  for (uint8_t i = 0; i < group.character_rects.size(); i++) {
+    if (group.pattern == ExpiryPatternMMsYY && i == 2) continue;
+    const float *p = group.scores.v[i];
+    int best = 0;  // Eigen maxCoeff: first maximum
+    for (int k = 1; k < 10; k++)
+      if (p[k] > p[best]) best = k;
+    // Eigen 10-element redux tree
+    const float sum = ((p[0] + p[1]) + (p[2] + (p[3] + p[4]))) + ((p[5] + p[6]) + (p[7] + (p[8] + p[9])));
+    const float stability = p[best] / sum;
+    expiry_string[i] = stability < kExpiryMinStability ? ' ' : (char)((uint8_t)'0' + (uint8_t)best);
+  }
+  expiry_string_to_expiry_month_and_year(expiry_string, group, expiry_month, expiry_year);
+}
+
+// FrameScanResult.expiry_groups from the device record (expiry_seg.cpp:651-668 field values)
+static void fill_expiry_groups(const dmz_hip_expiry_result &x, GroupedRectsList *out) {
+  out->clear();
+  for (int g = 0; g < x.n_groups; g++) {
+    const dmz_hip_expiry_group &d = x.groups[g];
+    GroupedRects gr;
+    gr.top = d.top;
+    gr.left = d.left;
+    gr.width = d.width;
+    gr.height = d.height;
+    gr.grouped_yet = false;
+    gr.sum = 0;
+    gr.character_width = kTrimmedCharacterImageWidth;
+    gr.pattern = ExpiryPatternMMsYY;
+    gr.recently_seen_count = 0;
+    gr.total_seen_count = 0;
+    memset(&gr.scores, 0, sizeof(gr.scores));
+    for (int i = 0; i < 5; i++) gr.character_rects.push_back(CharacterRect(d.char_top[i], d.char_left[i], 0));
+    for (int row = 0; row < 4; row++) memcpy(gr.scores.v[row < 2 ? row : row + 1], d.scores[row], sizeof(float) * 10);
+    out->push_back(gr);
+  }
+}
+
 void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_expiry,
                                    FrameScanResult *result) {
-  (void)scan_expiry;  // the expiry path is not built yet (DESIGN.md "out of scope")
   const bool need_number = state->timeOfCardNumberCompletionInMilliseconds == 0;
+  const bool need_expiry = scan_expiry && (state->expiry_month == 0 || state->expiry_year == 0);  // scan.cpp:44
   result->usable = false;
   result->upside_down = false;
+  result->expiry_groups.clear();
+  result->name_groups.clear();
   dmz_hip_context *ctx = hip_of(state->dmz);
   if (!ctx || !y || y->roi || y->width != kCreditCardTargetWidth || y->height != kCreditCardTargetHeight ||
       y->nChannels != 1)
@@ -349,16 +493,33 @@ void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_e
       memcpy(packed + (size_t)r * kCreditCardTargetWidth, y->imageData + (size_t)r * y->widthStep, kCreditCardTargetWidth);
     cards = packed;
   }
+  const size_t card_stride = (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight;
   dmz_hip_frame_result r;
   memset(&r, 0, sizeof(r));
-  const int rc = dmz_hip_scan_cards_batch(ctx, cards, (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight, 1, 0, &r);
+  int rc = dmz_hip_scan_cards_batch(ctx, cards, card_stride, 1, 0, &r);
+  dmz_hip_expiry_result x;
+  memset(&x, 0, sizeof(x));
+  if (rc == DMZ_HIP_OK && need_expiry) rc = dmz_hip_scan_expiry_batch(ctx, cards, card_stride, 1, &r, &x);  // frame.cpp:71-73
   free(packed);
   if (rc != DMZ_HIP_OK) {
     fprintf(stderr, "dmz (HIP): scan failed: %s\n", dmz_hip_last_error(ctx));
     return;
   }
   fill_frame_result(r, result);
+  if (need_expiry) fill_expiry_groups(x, &result->expiry_groups);
   if (result->upside_down || !result->usable) return;  // scan.cpp:51-60
+  if (need_expiry) {                                   // scan.cpp:61-67 + expiry_extract (:332-376)
+    state->scan_expiry = true;
+    if (!result->expiry_groups.empty()) {
+      // the device categorised the digits of every group of this (usable) frame already
+      expiry_aggregate_grouped_rects(state->expiry_groups, result->expiry_groups);
+      for (GroupedRectsList::iterator group = state->expiry_groups.begin(); group != state->expiry_groups.end(); ++group) {
+        if (group->total_seen_count < 3) continue;  // not trusted yet
+        get_stable_expiry_month_and_year(*group, &state->expiry_month, &state->expiry_year);
+      }
+    }
+    state->name_groups = result->name_groups;
+  }
   if (need_number) {                                   // scan.cpp:69-85
     state->mostRecentUsableHSeg = result->hseg;
     state->mostRecentUsableVSeg = result->vseg;
@@ -431,3 +592,40 @@ void scanner_result(ScannerState *state, ScannerResult *result) {
 }
 
 void scanner_destroy(ScannerState *state) { (void)state; }
+
+// ---- flat-array hook for the host-logic tests (tests/test_host_logic.py): replays a session's
+// expiry_extract calls (expiry_categorize.cpp:332-376) on caller-supplied per-frame groups ----
+extern "C" int dmz_hip_host_expiry_session_replay(int n_frames, const int *groups_per_frame, const int16_t *tops,
+                                                  const int16_t *lefts, const float *scores /* [g][4][10] */,
+                                                  int *months_out, int *years_out, int *n_aggregated_out) {
+  GroupedRectsList aggregated;
+  int month = 0, year = 0, g = 0;
+  for (int f = 0; f < n_frames; f++) {
+    dmz_hip_expiry_result x;
+    memset(&x, 0, sizeof(x));
+    x.n_groups = groups_per_frame[f] < DMZ_HIP_EXPIRY_MAX_GROUPS ? groups_per_frame[f] : DMZ_HIP_EXPIRY_MAX_GROUPS;
+    for (int i = 0; i < groups_per_frame[f]; i++, g++) {
+      if (i >= DMZ_HIP_EXPIRY_MAX_GROUPS) continue;
+      dmz_hip_expiry_group &d = x.groups[i];
+      d.top = tops[g];
+      d.left = lefts[g];
+      d.width = 5 * 13;
+      d.height = kSmallCharacterHeight;
+      for (int c = 0; c < 5; c++) d.char_top[c] = tops[g], d.char_left[c] = (int16_t)(lefts[g] + 13 * c);
+      memcpy(d.scores, scores + (size_t)g * 40, sizeof(float) * 40);
+    }
+    GroupedRectsList new_groups;
+    fill_expiry_groups(x, &new_groups);
+    if (!new_groups.empty()) {
+      expiry_aggregate_grouped_rects(aggregated, new_groups);
+      for (GroupedRectsList::iterator group = aggregated.begin(); group != aggregated.end(); ++group) {
+        if (group->total_seen_count < 3) continue;
+        get_stable_expiry_month_and_year(*group, &month, &year);
+      }
+    }
+    months_out[f] = month;
+    years_out[f] = year;
+    n_aggregated_out[f] = (int)aggregated.size();
+  }
+  return 0;
+}

@@ -198,3 +198,43 @@ REF_API void ref_expiry_regrid_group(const int16_t *sobel, int top, int height, 
     rect_sum[i] = g.character_rects[i].sum;
   }
 }
+
+// ---- the cross-frame half of expiry_extract (scan/expiry_categorize.cpp:162-376): pure C++/Eigen ----
+REF_API int ref_expiry_session_replay(int n_frames, const int *groups_per_frame, const int16_t *tops,
+                                      const int16_t *lefts, const float *scores /* [g][4][10] */,
+                                      int *months_out, int *years_out, int *n_aggregated_out) {
+  GroupedRectsList aggregated;
+  int month = 0, year = 0, g = 0;
+  for (int f = 0; f < n_frames; f++) {
+    GroupedRectsList new_groups;
+    for (int i = 0; i < groups_per_frame[f]; i++, g++) {
+      GroupedRects gr;
+      gr.top = tops[g];
+      gr.left = lefts[g];
+      gr.width = 5 * 13;
+      gr.height = kSmallCharacterHeight;
+      gr.grouped_yet = false;
+      gr.sum = 0;
+      gr.character_width = kTrimmedCharacterImageWidth;
+      gr.pattern = ExpiryPatternMMsYY;
+      gr.recently_seen_count = 0;
+      gr.total_seen_count = 0;
+      gr.scores.setZero();
+      for (int c = 0; c < 5; c++) gr.character_rects.push_back(CharacterRect(tops[g], lefts[g] + 13 * c, 0));
+      for (int row = 0; row < 4; row++)
+        for (int k = 0; k < 10; k++) gr.scores(row < 2 ? row : row + 1, k) = scores[(size_t)g * 40 + row * 10 + k];
+      new_groups.push_back(gr);
+    }
+    if (!new_groups.empty()) {
+      expiry_aggregate_grouped_rects(aggregated, new_groups);
+      for (GroupedRectsListIterator group = aggregated.begin(); group != aggregated.end(); ++group) {
+        if (group->total_seen_count < 3) continue;
+        get_stable_expiry_month_and_year(*group, &month, &year);
+      }
+    }
+    months_out[f] = month;
+    years_out[f] = year;
+    n_aggregated_out[f] = (int)aggregated.size();
+  }
+  return 0;
+}

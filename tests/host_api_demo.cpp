@@ -39,15 +39,21 @@ int main(int argc, char **argv) {
       dmz_transform_card(dmz, &y, corners, FrameOrientationLandscapeRight, false, &card);
       unsigned long sum = 0;
       for (int k = 0; k < 428 * 270; k++) sum += (unsigned char)card->imageData[k] * (unsigned long)(k % 251 + 1);
-      FrameScanResult fr;
-      memset(&fr, 0, sizeof(fr));
-      scanner_add_frame_with_expiry(&state, card, false, &fr);
+      FrameScanResult fr = FrameScanResult();
+      scanner_add_frame_with_expiry(&state, card, true, &fr);
       printf(" cardsum %lu usable %d upside %d y_offset %d vscore %.6f digits ", sum, fr.usable, fr.upside_down,
              fr.vseg.y_offset, fr.vseg.score);
       for (int d = 0; d < fr.hseg.n_offsets; d++) {
         int best = 0;
         for (int k = 1; k < 10; k++) if (fr.scores.v[d][k] > fr.scores.v[d][best]) best = k;
         printf("%d", best);
+      }
+      printf(" expiry_groups %d", (int)fr.expiry_groups.size());
+      for (size_t g = 0; g < fr.expiry_groups.size(); g++) {
+        const GroupedRects &gr = fr.expiry_groups[g];
+        printf(" [%d %d %d %d :", gr.top, gr.left, gr.width, gr.height);
+        for (size_t c = 0; c < gr.character_rects.size(); c++) printf(" %d,%d", gr.character_rects[c].left, gr.character_rects[c].top);
+        printf("]");
       }
       dmz_release_image(&card);
     }
@@ -56,6 +62,9 @@ int main(int argc, char **argv) {
   ScannerResult res;
   scanner_result(&state, &res);
   printf("session count15 %d count16 %d complete %d\n", state.count15, state.count16, res.complete);
+  printf("expiry scan_expiry %d aggregated %d seen", state.scan_expiry, (int)state.expiry_groups.size());
+  for (size_t g = 0; g < state.expiry_groups.size(); g++) printf(" %d", state.expiry_groups[g].total_seen_count);
+  printf(" month %d year %d\n", state.expiry_month, state.expiry_year);
   float m[9];
   dmz_point s[4] = {{106, 105}, {533, 105}, {106, 374}, {533, 374}}, d[4];
   dmz_rect_get_points(dmz_create_rect(0, 0, 427, 269), d);

@@ -22,6 +22,7 @@ def test_sdk_style_call_sequence(tmp_path, oracle, ctx):
     frames.tofile(raw)
     out = subprocess.check_output([exe, str(raw), str(n)], text=True).strip().splitlines()
     want, wcard = oracle.scan_frame(frames[0])
+    wexp = oracle.scan_card_expiry(wcard, want)
     weights = (np.arange(428 * 270) % 251 + 1).astype(np.uint64)
     cardsum = int((wcard.reshape(-1).astype(np.uint64) * weights).sum())
     for i in range(n):
@@ -34,11 +35,29 @@ def test_sdk_style_call_sequence(tmp_path, oracle, ctx):
         assert int(t[19]) == int(want["vseg_y_offset"])
         assert abs(float(t[21]) - float(want["vseg_score"])) < 1e-4
         assert t[23] == "".join(str(int(d)) for d in want["digits"][: int(want["n_offsets"])])
+        # expiry groups of the frame (scan_expiry = true): count and character rects as the oracle finds them
+        if i >= 3 and int(t[25]) == 0 and int(wexp["n_groups"]) > 0:
+            # the session settled on an expiry after three sightings: scan.cpp:44 stops scanning for it
+            assert int(out[n + 1].split()[-3]) > 0
+            continue
+        assert int(t[25]) == int(wexp["n_groups"])
+        txt = out[i].split("expiry_groups")[1]
+        for g in range(int(wexp["n_groups"])):
+            grp = wexp["groups"][g]
+            want_txt = "[%d %d %d %d : %s]" % (grp["top"], grp["left"], grp["width"], grp["height"],
+                                               " ".join("%d,%d" % (l, tp) for l, tp in zip(grp["char_left"], grp["char_top"])))
+            assert want_txt in txt, (want_txt, txt)
     sess = out[n].split()
     usable = int(bool(want["flags"] & 1))
     assert int(sess[4]) == usable * n  # count16
+    ex = out[n + 1].split()
+    assert ex[0] == "expiry" and int(ex[2]) == usable
+    if usable and int(wexp["n_groups"]) > 0:
+        # five identical frames: every group of the frame has been seen five times
+        decided = int(ex[-3]) > 0
+        assert int(ex[4]) >= 1 and all(int(v) == n or (decided and int(v) >= 3) for v in ex[6:6 + int(ex[4])])
     m = oracle.calc_persp_transform([106, 105, 533, 105, 106, 374, 533, 374], [0, 0, 427, 0, 0, 269, 427, 269])
-    p = out[n + 1].split()
+    p = out[n + 2].split()
     assert np.float32(p[1]) == m[0] and np.float32(p[2]) == m[2] and np.float32(p[3]) == m[5]
 
 

@@ -47,3 +47,51 @@ def test_luhn_and_card_info_match_reference(reference):
             want_type = reference.lib.ref_card_type(d.ctypes.data, m, int(incomplete), C.byref(nl))
             got = info(d.ctypes.data, m, incomplete)
             assert (got.card_type, got.number_length) == (want_type, nl.value), (d[:m], incomplete)
+
+
+def test_expiry_session_aggregation_matches_reference(reference):
+    """expiry_aggregate_grouped_rects + get_stable_expiry_month_and_year (expiry_categorize.cpp:162-330) on
+    replayed sessions: groups drift by a few pixels, appear/disappear, carry noisy one-hot-ish scores."""
+    host = C.CDLL(os.path.join(PKG, "libdmz_host.so"))
+    getattr(host, "_Z30dmz_hip_host_allow_past_expiryb")(C.c_bool(True))  # the reference build is the CYTHON flavour
+    i16p, f32p, i32p = C.POINTER(C.c_int16), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    for fn in (host.dmz_hip_host_expiry_session_replay, reference.lib.ref_expiry_session_replay):
+        fn.argtypes = [C.c_int, i32p, i16p, i16p, f32p, i32p, i32p, i32p]
+    rng = np.random.default_rng(23)
+    decided = 0
+    for session in range(60):
+        n_frames = int(rng.integers(3, 14))
+        truth = rng.integers(0, 10, (3, 4))  # up to three persistent groups with their own digits
+        truth[:, 0] = rng.integers(0, 2, 3)  # month tens digit 0/1 so that plausible dates occur
+        truth[:, 2] = rng.integers(1, 4, 3)
+        base_top = rng.integers(180, 250, 3)
+        base_left = rng.integers(30, 300, 3)
+        per_frame, tops, lefts, scores = [], [], [], []
+        for f in range(n_frames):
+            k = 0
+            for g in range(3):
+                if rng.random() < 0.7:
+                    reps = 2 if rng.random() < 0.15 else 1  # sometimes the same group twice in one frame
+                    for _ in range(reps):
+                        tops.append(base_top[g] + rng.integers(-3, 4))
+                        lefts.append(base_left[g] + rng.integers(-3, 4))
+                        s = rng.random((4, 10)).astype(np.float32) * 0.08
+                        for c in range(4):
+                            s[c, truth[g, c]] += 0.9 if rng.random() < 0.85 else 0.2
+                        scores.append(s / s.sum(1, keepdims=True))
+                        k += 1
+            per_frame.append(k)
+        gpf = np.array(per_frame, np.int32)
+        t = np.array(tops if tops else [0], np.int16)
+        l = np.array(lefts if lefts else [0], np.int16)
+        sc = np.ascontiguousarray(np.array(scores if scores else np.zeros((1, 4, 10)), np.float32))
+        outs = []
+        for fn in (host.dmz_hip_host_expiry_session_replay, reference.lib.ref_expiry_session_replay):
+            m, y, na = (np.zeros(n_frames, np.int32) for _ in range(3))
+            fn(n_frames, gpf.ctypes.data_as(i32p), t.ctypes.data_as(i16p), l.ctypes.data_as(i16p),
+               sc.ctypes.data_as(f32p), m.ctypes.data_as(i32p), y.ctypes.data_as(i32p), na.ctypes.data_as(i32p))
+            outs.append((m, y, na))
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b), session
+        decided += int(outs[0][0][-1] > 0)
+    assert decided >= 5  # the sessions do reach expiry decisions
