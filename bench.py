@@ -46,7 +46,7 @@ ALGO = {
     "expiry_cat": (4 * 176 + 160,           0.6 * 4 * 2 * 1.27e6),
 }
 PIPELINE_BYTES = 307200 + 115560 + 1024 + 1592
-# HBM traffic per frame (bytes) from the committed PMC passes profiles/r1_pmc_{FETCH,WRITE}_SIZE_*.txt
+# HBM traffic per frame (bytes) from the committed PMC passes profiles/r1*_pmc_{FETCH,WRITE}_SIZE_*.txt
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, KB per dispatch / 4096 frames).
 # FETCH_SIZE is NOT doubled: the guide's x2 gfx950 correction is calibrated for 16 B/lane
 # streams, these kernels load 4 B/lane ("uncalibrated" there); WRITE_SIZE matched known byte
@@ -58,8 +58,8 @@ PMC_TRAFFIC = {
     "vseg": (100604.2 + 3146.3) * 1024 / 4096,
     "hseg": (32576.1 + 256.0) * 1024 / 4096,
     "digits": (24546.8 + 2902.4) * 1024 / 4096,
-    "expiry_seg": None,  # not collected yet
-    "expiry_cat": None,
+    "expiry_seg": (71591.2 + 60866.5 + 7104.1 + 459.7) * 1024 / 4096,  # k_expiry_stripes + k_expiry_seg (r1_v3 passes)
+    "expiry_cat": (5361.5 + 564.6) * 1024 / 4096,
 }
 
 
