@@ -98,17 +98,31 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   if (nrows > 128 || nrows < 18) return;  // y_offset >= 121 for a card that is not upside down
   const uint8_t *card = cards + (size_t)f * card_stride;
 
-  for (int r = 0; r < nrows; r++) {
-    const uint32_t *row = (const uint32_t *)(card + (size_t)(y0 + r) * CW);
-    const uint32_t a = row[6 + lane], b = row[7 + lane];
-    const uint32_t left = __builtin_amdgcn_alignbyte(b, a, 2);  // p[26 + 4 lane ..]
-    unsigned s = __builtin_amdgcn_sad_u8(b, left, 0u);          // p[28 + 4 lane ..] vs left
-    if (lane == 0) {
-      const uint8_t *p = (const uint8_t *)row;
-      s += (unsigned)iabs((int)p[284] - (int)p[282]) + (unsigned)iabs((int)p[285] - (int)p[283]);
+  // eight rows per trip: 16 dword loads in flight per lane (the rows come from HBM)
+  for (int r0 = 0; r0 < nrows; r0 += 8) {
+    uint32_t a[8], b[8];
+    unsigned extra[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int r = imin(r0 + u, nrows - 1);
+      const uint32_t *row = (const uint32_t *)(card + (size_t)(y0 + r) * CW);
+      a[u] = row[6 + lane];
+      b[u] = row[7 + lane];
+      extra[u] = 0u;
+      if (lane == 0) {
+        const uint32_t w70 = row[70], w71 = row[71];  // p[280..287]
+        // |p[284] - p[282]| + |p[285] - p[283]|
+        extra[u] = (unsigned)iabs((int)(w71 & 255u) - (int)((w70 >> 16) & 255u)) +
+                   (unsigned)iabs((int)((w71 >> 8) & 255u) - (int)(w70 >> 24));
+      }
     }
-    s = (unsigned)wave_sum_i32((int)s);
-    if (lane == 0) I[r] = (int)s;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t left = __builtin_amdgcn_alignbyte(b[u], a[u], 2);  // p[26 + 4 lane ..]
+      unsigned s = __builtin_amdgcn_sad_u8(b[u], left, extra[u]);       // p[28 + 4 lane ..] vs left
+      s = (unsigned)wave_sum_i32((int)s);
+      if (lane == 0 && r0 + u < nrows) I[r0 + u] = (int)s;
+    }
   }
   __syncthreads();
   for (int r = lane; r < nrows; r += 64)
