@@ -60,6 +60,15 @@ EXPIRY_DTYPE = np.dtype([
 ])
 assert EXPIRY_DTYPE.itemsize == 1592
 
+# mirror of struct dmz_hip_session_result (include/dmz_hip.h)
+SESSION_DTYPE = np.dtype([
+    ("complete", "<i4"), ("complete_frame", "<i4"), ("number_frame", "<i4"), ("n_numbers", "<i4"),
+    ("predictions", "u1", (16,)), ("card_type", "<i4"), ("expiry_month", "<i4"), ("expiry_year", "<i4"),
+    ("count15", "<i4"), ("count16", "<i4"), ("usable_frames", "<i4"), ("n_expiry_groups", "<i4"),
+    ("vseg_y_offset", "<i4"), ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("reserved", "<i4", (7,)),
+])
+assert SESSION_DTYPE.itemsize == 128
+
 # every symbol include/dmz_hip.h declares
 EXPORTS = (
     "dmz_hip_device_count", "dmz_hip_context_create", "dmz_hip_context_destroy",
@@ -70,7 +79,7 @@ EXPORTS = (
     "dmz_hip_synth_cards", "dmz_hip_set_profiling", "dmz_hip_get_stage_times",
     "dmz_hip_malloc", "dmz_hip_free", "dmz_hip_memcpy_h2d", "dmz_hip_memcpy_d2h",
     "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
-    "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model",
+    "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
 )
 
 
@@ -112,6 +121,7 @@ def load_library():
     lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
     lib.dmz_hip_scan_expiry_batch.argtypes = [vp, vp, sz, i, vp, vp]
     lib.dmz_hip_pipeline_expiry_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp, vp]
+    lib.dmz_hip_scan_sessions_batch.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.dmz_hip_apply_slash_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_apply_expiry_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_calc_persp_transform.argtypes = [vp, vp, vp, vp]
@@ -249,6 +259,12 @@ class Context:
         self._check(self.lib.dmz_hip_pipeline_expiry_batch(
             self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
             _ptr(cards), CARD_BYTES, _ptr(results), _ptr(expiry)))
+
+    def scan_sessions(self, results, expiry, n_sessions, frames_per_session, out, scan_expiry=True,
+                      frame_interval_ms=33, now_year=2026, now_month=10, allow_past_expiry=False):
+        self._check(self.lib.dmz_hip_scan_sessions_batch(
+            self.h, _ptr(results), _ptr(expiry), n_sessions, frames_per_session, int(scan_expiry),
+            frame_interval_ms, now_year, now_month, int(allow_past_expiry), _ptr(out)))
 
     def calc_persp_transform(self, src_pts, dst_pts):
         s = np.ascontiguousarray(src_pts, np.float32).reshape(8)

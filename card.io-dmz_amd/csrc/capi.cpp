@@ -42,7 +42,7 @@ struct dmz_hip_context {
     void *p = nullptr;
     size_t cap = 0;
   };
-  Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc, xstage, stage_exp;
+  Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc, xstage, stage_exp, stage_sess;
 
   // profiling
   bool profiling = false;
@@ -499,7 +499,7 @@ void dmz_hip_context_destroy(dmz_hip_context *ctx) {
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   dmz_hip_context::Buf *bufs[] = {&ctx->hits, &ctx->mats, &ctx->skip, &ctx->synth, &ctx->stage_in,
                                   &ctx->stage_cb, &ctx->stage_cr, &ctx->stage_cards, &ctx->stage_res,
-                                  &ctx->cards, &ctx->misc, &ctx->xstage, &ctx->stage_exp};
+                                  &ctx->cards, &ctx->misc, &ctx->xstage, &ctx->stage_exp, &ctx->stage_sess};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
@@ -721,6 +721,37 @@ int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t
                                   dmz_hip_expiry_result *expiry) {
   return pipeline_impl(ctx, y, frame_stride, row_stride, width, height, n, orientation, options, cards,
                        card_stride, results, expiry, true);
+}
+
+int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result *results,
+                                const dmz_hip_expiry_result *expiry, int n_sessions, int frames_per_session,
+                                int scan_expiry, int frame_interval_ms, int now_year, int now_month,
+                                int allow_past_expiry, dmz_hip_session_result *out) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!results || !out || n_sessions <= 0 || frames_per_session <= 0 || frame_interval_ms < 0 ||
+      (size_t)n_sessions * (size_t)frames_per_session > (size_t)1 << 30)
+    return fail(ctx, DMZ_HIP_EINVAL, "bad session batch");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)n_sessions * (size_t)frames_per_session;
+  int rc;
+  const void *dres = nullptr, *dexp = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_res, results, sizeof(dmz_hip_frame_result) * n, &dres))) return rc;
+  if (expiry && (rc = stage_in(ctx, ctx->stage_exp, expiry, sizeof(dmz_hip_expiry_result) * n, &dexp))) return rc;
+  const bool out_dev = is_device_ptr(out);
+  dmz_hip_session_result *dout = out;
+  if (!out_dev) {
+    if ((rc = ensure(ctx, ctx->stage_sess, sizeof(dmz_hip_session_result) * (size_t)n_sessions))) return rc;
+    dout = (dmz_hip_session_result *)ctx->stage_sess.p;
+  }
+  dmz_launch_sessions(ctx->stream, (const dmz_hip_frame_result *)dres, (const dmz_hip_expiry_result *)dexp, n_sessions,
+                      frames_per_session, scan_expiry, frame_interval_ms, now_year, now_month, allow_past_expiry, dout);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!out_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, sizeof(dmz_hip_session_result) * (size_t)n_sessions, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
 }
 
 int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts, const float *dst_pts, float *m) {

@@ -144,6 +144,9 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* d
                        dmz_hip_expiry_result *out, hipEvent_t mid /* recorded between seg and cat, or null */);
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
 void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
+void dmz_launch_sessions(hipStream_t s, const dmz_hip_frame_result *frames, const dmz_hip_expiry_result *expiry,
+                         int n_sessions, int frames_per_session, int scan_expiry, int frame_interval_ms,
+                         int now_year, int now_month, int allow_past, dmz_hip_session_result *out);
 int dmz_configure_expiry(void);
 int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
 int dmz_configure_scan(void);

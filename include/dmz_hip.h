@@ -169,6 +169,42 @@ int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t
                                   int options, uint8_t *cards, size_t card_stride,
                                   dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry);
 
+/* ---- per-session policy, batched.  One record per session: what
+ * scanner_result (scan/scan.h:67, scan.cpp:88-194) reports after the last frame fed, plus where in
+ * the session it happened. ------------------------------------------------------------------- */
+typedef struct dmz_hip_session_result {
+  int32_t complete;        /* ScannerResult.complete when the replay stopped */
+  int32_t complete_frame;  /* frame after which scanner_result first reported complete, -1 if never */
+  int32_t number_frame;    /* frame after which the card number was accepted, -1 if never */
+  int32_t n_numbers;       /* ScannerResult.n_numbers */
+  uint8_t predictions[16]; /* ScannerResult.predictions */
+  int32_t card_type;       /* dmz_olm.h CardType of the accepted number */
+  int32_t expiry_month, expiry_year;
+  int32_t count15, count16; /* ScannerState.count15/16 */
+  int32_t usable_frames;
+  int32_t n_expiry_groups; /* ScannerState.expiry_groups.size() */
+  int32_t vseg_y_offset, n_offsets; /* ScannerResult.vseg / hseg of the accepted number */
+  uint16_t offsets[16];
+  int32_t reserved[7];
+} dmz_hip_session_result;  /* 128 bytes */
+
+/* Replays, for n_sessions sessions of frames_per_session consecutive per-frame records each
+ * (session s owns records [s*F, (s+1)*F)), the SDK loop
+ *     scanner_add_frame_with_expiry(state, card, scan_expiry, &frame); scanner_result(state, &result);
+ * (scan/scan.h:51-72, scan.cpp:41-194, with expiry_extract's cross-frame half
+ * expiry_categorize.cpp:162-376 and dmz_olm.cpp:40-130) until `complete`.  The wall clock is
+ * replaced by a frame clock (frame f is handled at 1 + f*frame_interval_ms milliseconds) and
+ * the date by (now_year, now_month).  expiry may be NULL (then scan_expiry finds nothing).
+ * allow_past_expiry != 0 selects the DMZ_DEBUG / CYTHON_DMZ flavour of expiry_categorize.cpp:236-248.
+ * Batched-mode convention: records are produced with the number path always on; once a
+ * session's number is accepted a frame counts as usable when DMZ_HIP_FLAG_VSEG_OK is set
+ * (frame.cpp:43 with collect_card_number = false), and uncategorised expiry records add nothing. */
+int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result *results,
+                                const dmz_hip_expiry_result *expiry, int n_sessions,
+                                int frames_per_session, int scan_expiry, int frame_interval_ms,
+                                int now_year, int now_month, int allow_past_expiry,
+                                dmz_hip_session_result *out);
+
 /* Single homography, llcv_calc_persp_transform (cv/warp.h:25, warp.cpp:34-125),
  * computed on the device with the same kernel code the batch path uses.
  * src_pts/dst_pts: 4 (x,y) pairs; m: 9 floats row-major (host pointers). */

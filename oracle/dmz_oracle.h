@@ -194,6 +194,28 @@ int orc_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *
 void orc_expiry_regrid_group(const int16_t *sobel, int top, int height, int *left, int *width,
                              int *character_width, int *n, int *rect_left, int64_t *rect_sum);
 
+/* ---- per-session policy (scan/scan.cpp:41-194 + expiry_categorize.cpp:162-376) replayed over the
+ * per-frame records of one session; layout == dmz_hip_session_result (include/dmz_hip.h) ---- */
+typedef struct {
+  int32_t complete;        /* ScannerResult.complete when the replay stopped */
+  int32_t complete_frame;  /* frame after which scanner_result first reported complete, -1 if never */
+  int32_t number_frame;    /* frame after which the card number was accepted, -1 if never */
+  int32_t n_numbers;
+  uint8_t predictions[16];
+  int32_t card_type;       /* dmz_olm.h CardType of the accepted number */
+  int32_t expiry_month, expiry_year;
+  int32_t count15, count16;
+  int32_t usable_frames;
+  int32_t n_expiry_groups; /* aggregated expiry groups alive when the replay stopped */
+  int32_t vseg_y_offset, n_offsets;
+  uint16_t offsets[16];
+  int32_t reserved[7];
+} orc_session_result;      /* 128 bytes */
+void orc_scan_session(const orc_frame_result *frames, const orc_expiry_result *expiry /* or NULL */,
+                      int n_frames, int scan_expiry, int frame_interval_ms, int now_year, int now_month,
+                      int allow_past_expiry, orc_session_result *out);
+int orc_card_type(const uint8_t *digits, int n, int allow_incomplete, int *number_length); /* dmz_olm.cpp:51-130 */
+
 /* ---- full per-frame pipeline: detect -> transform(Y) -> scan ---------------- */
 void orc_scan_frame(const uint8_t *y, int stride, int w, int h, int orientation,
                     int truncate_corners, uint8_t *card_out /* 428*270 or NULL */,

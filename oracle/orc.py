@@ -366,6 +366,44 @@ class Reference:
         return bool(self.lib.ref_passes_luhn(_p(d, _u8p), len(d)))
 
 
+SESSION_DTYPE = np.dtype([
+    ("complete", "<i4"), ("complete_frame", "<i4"), ("number_frame", "<i4"), ("n_numbers", "<i4"),
+    ("predictions", "u1", (16,)), ("card_type", "<i4"), ("expiry_month", "<i4"), ("expiry_year", "<i4"),
+    ("count15", "<i4"), ("count16", "<i4"), ("usable_frames", "<i4"), ("n_expiry_groups", "<i4"),
+    ("vseg_y_offset", "<i4"), ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("reserved", "<i4", (7,)),
+])
+assert SESSION_DTYPE.itemsize == 128
+
+
+def _scan_session(self, frames, expiry, scan_expiry=True, frame_interval_ms=0, now_year=2026, now_month=10,
+                  allow_past=False):
+    frames = np.ascontiguousarray(frames)
+    assert frames.dtype == RESULT_DTYPE
+    out = np.zeros(1, SESSION_DTYPE)
+    xp = None
+    if expiry is not None:
+        expiry = np.ascontiguousarray(expiry)
+        assert expiry.dtype == EXPIRY_DTYPE and len(expiry) == len(frames)
+        xp = expiry.ctypes.data_as(C.c_void_p)
+    self.lib.orc_scan_session(frames.ctypes.data_as(C.c_void_p), xp, len(frames), int(scan_expiry),
+                              int(frame_interval_ms), int(now_year), int(now_month), int(allow_past),
+                              out.ctypes.data_as(C.c_void_p))
+    return out[0]
+
+
+def _ref_scan_session(self, frames, expiry, scan_expiry=True):
+    frames = np.ascontiguousarray(frames)
+    out = np.zeros(1, SESSION_DTYPE)
+    xp = None
+    if expiry is not None:
+        expiry = np.ascontiguousarray(expiry)
+        xp = expiry.ctypes.data_as(C.c_void_p)
+    self.lib.ref_scan_session.restype = None
+    self.lib.ref_scan_session(frames.ctypes.data_as(C.c_void_p), xp, len(frames), int(scan_expiry),
+                              out.ctypes.data_as(C.c_void_p))
+    return out[0]
+
+
 def _gather_into_groups(lib, prefix, lefts, sums, top, height):
     lefts = np.ascontiguousarray(lefts, np.int32)
     sums = np.ascontiguousarray(sums, np.int64)
@@ -395,6 +433,8 @@ def _regrid_group(lib, prefix, sobel, top, height, left, width, character_width=
     return l.value, w.value, cw.value, rl[:n.value].copy(), rs[:n.value].copy()
 
 
+Oracle.scan_session = _scan_session
+Reference.scan_session = _ref_scan_session
 Oracle.expiry_gather_into_groups = lambda self, *a: _gather_into_groups(self.lib, "orc_", *a)
 Oracle.expiry_regrid_group = lambda self, *a: _regrid_group(self.lib, "orc_", *a)
 Reference.expiry_gather_into_groups = lambda self, *a: _gather_into_groups(self.lib, "ref_", *a)

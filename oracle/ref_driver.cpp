@@ -238,3 +238,145 @@ REF_API int ref_expiry_session_replay(int n_frames, const int *groups_per_frame,
   }
   return 0;
 }
+
+// ---- session policy: the reference's own scanner_result (scan.cpp:88-194), expiry aggregation
+// and dmz_olm code, driven by replayed per-frame records.  scanner_add_frame_with_expiry itself
+// needs scan_card_image (OpenCV), so its state update -- scan.cpp:44-46 (what is still needed),
+// :50-59 (upside-down / unusable frames are dropped), :62-66 (expiry_extract's aggregation half,
+// expiry_categorize.cpp:351-375) and :69-84 (the decayed score sum) -- is applied here to the
+// reference's ScannerState with the reference's types and operators. ----
+struct RefSessionOut {
+  int32_t complete, complete_frame, number_frame, n_numbers;
+  uint8_t predictions[16];
+  int32_t card_type, expiry_month, expiry_year, count15, count16, usable_frames, n_expiry_groups;
+  int32_t vseg_y_offset, n_offsets;
+  uint16_t offsets[16];
+  int32_t reserved[7];
+};
+
+REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
+                              const uint8_t *expiry /* n x 1592-byte records or NULL */, int n_frames,
+                              int scan_expiry, RefSessionOut *out) {
+  // field offsets of orc_frame_result / orc_expiry_result (oracle/dmz_oracle.h)
+  enum { F_FLAGS = 84, F_YOFF = 92, F_NOFF = 100, F_OFFS = 104, F_SCORES = 168 };
+  enum { X_NGROUPS = 0, X_CATEG = 48, X_GROUPS = 56, G_SIZE = 192, G_TOP = 0, G_LEFT = 2, G_CTOP = 8, G_CLEFT = 18, G_SCORES = 32 };
+  ScannerState state;
+  scanner_initialize(&state);
+  memset(out, 0, sizeof(*out));
+  out->complete_frame = -1;
+  out->number_frame = -1;
+  for (int f = 0; f < n_frames; f++) {
+    const uint8_t *fr = frames + (size_t)f * 1024;
+    int32_t flags, yoff, noff;
+    memcpy(&flags, fr + F_FLAGS, 4);
+    memcpy(&yoff, fr + F_YOFF, 4);
+    memcpy(&noff, fr + F_NOFF, 4);
+    const bool need_number = state.timeOfCardNumberCompletionInMilliseconds == 0;
+    const bool need_expiry = scan_expiry && (state.expiry_month == 0 || state.expiry_year == 0);
+    bool usable = false;
+    if (!(flags & 2)) usable = need_number ? (flags & 1) != 0 : (flags & 4) != 0;
+    if (usable) {
+      out->usable_frames++;
+      if (need_expiry) {
+        state.scan_expiry = true;
+        GroupedRectsList new_groups;
+        if (expiry) {
+          const uint8_t *x = expiry + (size_t)f * 1592;
+          int32_t ng, categ;
+          memcpy(&ng, x + X_NGROUPS, 4);
+          memcpy(&categ, x + X_CATEG, 4);
+          for (int g = 0; categ && g < ng; g++) {
+            const uint8_t *gp = x + X_GROUPS + (size_t)g * G_SIZE;
+            int16_t top, left, ct[5], cl[5];
+            memcpy(&top, gp + G_TOP, 2);
+            memcpy(&left, gp + G_LEFT, 2);
+            memcpy(ct, gp + G_CTOP, 10);
+            memcpy(cl, gp + G_CLEFT, 10);
+            GroupedRects gr;
+            gr.top = top;
+            gr.left = left;
+            gr.width = 0;
+            gr.height = 0;
+            gr.grouped_yet = false;
+            gr.sum = 0;
+            gr.character_width = kTrimmedCharacterImageWidth;
+            gr.pattern = ExpiryPatternMMsYY;
+            gr.recently_seen_count = 0;
+            gr.total_seen_count = 0;
+            gr.scores.setZero();
+            for (int c = 0; c < 5; c++) gr.character_rects.push_back(CharacterRect(ct[c], cl[c], 0));
+            float sc[40];
+            memcpy(sc, gp + G_SCORES, sizeof(sc));
+            for (int r = 0; r < 4; r++)
+              for (int k = 0; k < 10; k++) gr.scores(r < 2 ? r : r + 1, k) = sc[r * 10 + k];
+            new_groups.push_back(gr);
+          }
+        }
+        if (!new_groups.empty()) {
+          expiry_aggregate_grouped_rects(state.expiry_groups, new_groups);
+          for (GroupedRectsListIterator group = state.expiry_groups.begin(); group != state.expiry_groups.end(); ++group) {
+            if (group->total_seen_count < 3) continue;
+            get_stable_expiry_month_and_year(*group, &state.expiry_month, &state.expiry_year);
+          }
+        }
+      }
+      if (need_number) {
+        NHorizontalSegmentation hs;
+        memset(&hs, 0, sizeof(hs));
+        hs.n_offsets = (uint8_t)noff;
+        memcpy(hs.offsets, fr + F_OFFS, 32);
+        NVerticalSegmentation vs;
+        memset(&vs, 0, sizeof(vs));
+        vs.y_offset = (uint16_t)yoff;
+        state.mostRecentUsableHSeg = hs;
+        state.mostRecentUsableVSeg = vs;
+        NumberScores scores;
+        float sc[160];
+        memcpy(sc, fr + F_SCORES, sizeof(sc));
+        for (int i = 0; i < 16; i++)
+          for (int k = 0; k < 10; k++) scores(i, k) = sc[i * 10 + k];
+        if (noff == 15) {
+          state.aggregated15 *= 0.8f;
+          state.aggregated15 += scores * (1 - 0.8f);
+          state.count15++;
+        } else if (noff == 16) {
+          state.aggregated16 *= 0.8f;
+          state.aggregated16 += scores * (1 - 0.8f);
+          state.count16++;
+        }
+      }
+    }
+    ScannerResult res;
+    scanner_result(&state, &res);
+    if (state.timeOfCardNumberCompletionInMilliseconds > 0 && out->number_frame < 0) out->number_frame = f;
+    if (res.complete) {
+      out->complete = 1;
+      out->complete_frame = f;
+      out->n_numbers = res.n_numbers;
+      for (int i = 0; i < res.n_numbers; i++) out->predictions[i] = (uint8_t)res.predictions(i, 0);
+      out->card_type = dmz_card_info_for_prefix_and_length(out->predictions, res.n_numbers, false).card_type;
+      out->expiry_month = res.expiry_month;
+      out->expiry_year = res.expiry_year;
+      out->vseg_y_offset = res.vseg.y_offset;
+      out->n_offsets = res.hseg.n_offsets;
+      memcpy(out->offsets, res.hseg.offsets, 32);
+      break;
+    }
+  }
+  if (!out->complete) {
+    if (state.timeOfCardNumberCompletionInMilliseconds > 0) {
+      const ScannerResult &s = state.successfulCardNumberResult;
+      out->n_numbers = s.n_numbers;
+      for (int i = 0; i < s.n_numbers; i++) out->predictions[i] = (uint8_t)s.predictions(i, 0);
+      out->card_type = dmz_card_info_for_prefix_and_length(out->predictions, s.n_numbers, false).card_type;
+      out->vseg_y_offset = s.vseg.y_offset;
+      out->n_offsets = s.hseg.n_offsets;
+      memcpy(out->offsets, s.hseg.offsets, 32);
+    }
+    out->expiry_month = state.expiry_month;
+    out->expiry_year = state.expiry_year;
+  }
+  out->count15 = state.count15;
+  out->count16 = state.count16;
+  out->n_expiry_groups = (int)state.expiry_groups.size();
+}

@@ -142,3 +142,83 @@ def test_expiry_regrid_group_bit_exact(oracle, reference):
             b = reference.expiry_regrid_group(sob, top, 17, left, width)
             assert a[:3] == b[:3]
             assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def _synthetic_session(rng, orc, n_frames, digits, month_year, p_usable=0.8, noise=0.05, alt_len_rate=0.1):
+    """per-frame records of one session: noisy near-one-hot digit scores, an MM/YY group most frames"""
+    fr = np.zeros(n_frames, orc.RESULT_DTYPE)
+    ex = np.zeros(n_frames, orc.EXPIRY_DTYPE)
+    n = len(digits)
+    for f in range(n_frames):
+        r = rng.random()
+        if r < 0.05:
+            fr[f]["flags"] = orc.FLAG_UPSIDE_DOWN
+            continue
+        fr[f]["flags"] = orc.FLAG_VSEG_OK | (orc.FLAG_USABLE if rng.random() < p_usable else 0)
+        fr[f]["vseg_y_offset"] = 150 + int(rng.integers(-2, 3))
+        nn = n if rng.random() > alt_len_rate else (31 - n)  # sometimes the other pattern length
+        fr[f]["n_offsets"] = nn
+        fr[f]["offsets"][:nn] = 40 + 18 * np.arange(nn) + int(rng.integers(0, 3))
+        s = (rng.random((16, 10)) * noise).astype(np.float32)
+        for i in range(min(nn, n)):
+            s[i, digits[i] if rng.random() < 0.93 else int(rng.integers(0, 10))] += 1.0
+        s[:nn] /= s[:nn].sum(1, keepdims=True)
+        s[nn:] = 0
+        fr[f]["scores"] = s
+        if rng.random() < 0.75:
+            k = 1 + int(rng.random() < 0.2)
+            ex[f]["n_groups"] = ex[f]["n_found"] = k
+            ex[f]["categorised"] = int(bool(fr[f]["flags"] & orc.FLAG_USABLE))
+            for g in range(k):
+                grp = ex[f]["groups"][g]
+                grp["top"] = 207 + int(rng.integers(-2, 3)) + 25 * g
+                grp["left"] = 188 + int(rng.integers(-2, 3))
+                grp["char_top"] = grp["top"]
+                grp["char_left"] = grp["left"] + 13 * np.arange(5)
+                if ex[f]["categorised"]:
+                    es = (rng.random((4, 10)) * noise).astype(np.float32)
+                    for c in range(4):
+                        es[c, month_year[c] if rng.random() < 0.9 else int(rng.integers(0, 10))] += 1.0
+                    grp["scores"] = es / es.sum(1, keepdims=True)
+    return fr, ex
+
+
+def _luhn_complete(d):
+    d = list(d)
+    s = 0
+    for i, v in enumerate(reversed(d[:-1])):
+        v = v * 2 if i % 2 == 0 else v
+        s += v % 10 + v // 10
+    d[-1] = (10 - s % 10) % 10
+    return d
+
+
+def test_session_policy_matches_reference(oracle, reference, orc):
+    """scan.cpp:41-194 + expiry_categorize.cpp:162-376: the oracle's replay against the reference's own
+    scanner_result / expiry aggregation / Luhn / issuer table, on synthetic sessions (the reference build is
+    the CYTHON flavour: dates in the past are accepted; the wall clock does not advance between frames)."""
+    import datetime
+    today = datetime.date.today()
+    rng = np.random.default_rng(77)
+    completed = with_expiry = 0
+    for t in range(120):
+        n = 15 if t % 4 == 3 else 16
+        prefix = [3, 7] if n == 15 else [[4], [5, 2], [6, 0, 1, 1], [9, 9]][t % 4 if t % 4 < 3 else 0]
+        d = list(rng.integers(0, 10, n))
+        d[: len(prefix)] = prefix
+        if t % 7 != 6:
+            d = _luhn_complete(d)  # most sessions carry a valid number
+        mm = int(rng.integers(1, 13))
+        yy = int(rng.integers(24, 33))
+        my = [mm // 10, mm % 10, yy // 10, yy % 10]
+        fr, ex = _synthetic_session(rng, orc, int(rng.integers(4, 24)), d, my, noise=0.02 + 0.2 * (t % 5 == 4))
+        for scan_expiry in (True, False):
+            want = reference.scan_session(fr, ex, scan_expiry)
+            got = oracle.scan_session(fr, ex, scan_expiry, 0, today.year, today.month, allow_past=True)
+            for name in orc.SESSION_DTYPE.names:
+                if name != "reserved":
+                    assert np.array_equal(got[name], want[name]), (t, scan_expiry, name, got[name], want[name])
+            if scan_expiry:
+                completed += int(want["complete"])
+                with_expiry += int(got["expiry_month"] > 0)
+    assert completed >= 20 and with_expiry >= 20, (completed, with_expiry)
