@@ -30,6 +30,7 @@ ORIENTATION_LANDSCAPE_LEFT = 4
 
 FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
 OPT_TRUNCATE_CORNERS = 1
+OPT_UPSAMPLE = 2
 STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
 
 # mirror of struct dmz_hip_frame_result (include/dmz_hip.h), 1024 bytes
@@ -80,6 +81,7 @@ EXPORTS = (
     "dmz_hip_malloc", "dmz_hip_free", "dmz_hip_memcpy_h2d", "dmz_hip_memcpy_d2h",
     "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
     "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
+    "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
 )
 
 
@@ -121,6 +123,9 @@ def load_library():
     lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
     lib.dmz_hip_scan_expiry_batch.argtypes = [vp, vp, sz, i, vp, vp]
     lib.dmz_hip_pipeline_expiry_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp, vp]
+    lib.dmz_hip_deinterleave_c2.argtypes = [vp, vp, sz, vp, vp]
+    lib.dmz_hip_deinterleave_rgba_to_r.argtypes = [vp, vp, vp, sz]
+    lib.dmz_hip_ycbcr_to_rgb.argtypes = [vp, vp, vp, vp, sz, i, vp]
     lib.dmz_hip_scan_sessions_batch.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.dmz_hip_apply_slash_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_apply_expiry_model.argtypes = [vp, vp, i, vp]
@@ -259,6 +264,15 @@ class Context:
         self._check(self.lib.dmz_hip_pipeline_expiry_batch(
             self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
             _ptr(cards), CARD_BYTES, _ptr(results), _ptr(expiry)))
+
+    def deinterleave_c2(self, interleaved, n_pairs, channel1, channel2):
+        self._check(self.lib.dmz_hip_deinterleave_c2(self.h, _ptr(interleaved), n_pairs, _ptr(channel1), _ptr(channel2)))
+
+    def deinterleave_rgba_to_r(self, source, dest, size):
+        self._check(self.lib.dmz_hip_deinterleave_rgba_to_r(self.h, _ptr(source), _ptr(dest), size))
+
+    def ycbcr_to_rgb(self, y, cb, cr, n_pixels, rgb, channels=3):
+        self._check(self.lib.dmz_hip_ycbcr_to_rgb(self.h, _ptr(y), _ptr(cb), _ptr(cr), n_pixels, channels, _ptr(rgb)))
 
     def scan_sessions(self, results, expiry, n_sessions, frames_per_session, out, scan_expiry=True,
                       frame_interval_ms=33, now_year=2026, now_month=10, allow_past_expiry=False):

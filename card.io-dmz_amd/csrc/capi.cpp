@@ -723,6 +723,89 @@ int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t
                        card_stride, results, expiry, true);
 }
 
+// stage `bytes` of a host buffer into `buf` (or pass a device pointer through); out buffers likewise
+static int plumbing_io(dmz_hip_context *ctx, const void *in, size_t in_bytes, dmz_hip_context::Buf &in_buf,
+                       const void **din) {
+  return stage_in(ctx, in_buf, in, in_bytes, din);
+}
+
+int dmz_hip_deinterleave_c2(dmz_hip_context *ctx, const uint8_t *interleaved, size_t n_pairs, uint8_t *channel1,
+                            uint8_t *channel2) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!interleaved || !channel1 || !channel2 || n_pairs == 0) return fail(ctx, DMZ_HIP_EINVAL, "bad deinterleave arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *din = nullptr;
+  if ((rc = plumbing_io(ctx, interleaved, n_pairs * 2, ctx->stage_in, &din))) return rc;
+  const bool dev1 = is_device_ptr(channel1), dev2 = is_device_ptr(channel2);
+  uint8_t *d1 = channel1, *d2 = channel2;
+  if (!dev1 || !dev2) {
+    if ((rc = ensure(ctx, ctx->stage_cards, n_pairs * 2 + 16))) return rc;
+    if (!dev1) d1 = (uint8_t *)ctx->stage_cards.p;
+    if (!dev2) d2 = (uint8_t *)ctx->stage_cards.p + ((n_pairs + 15) & ~(size_t)15);
+  }
+  if ((((uintptr_t)din) & 7) || (((uintptr_t)d1) & 3) || (((uintptr_t)d2) & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "deinterleave buffers must be 8- (source) and 4-byte (planes) aligned");
+  dmz_launch_split_c2(ctx->stream, (const uint8_t *)din, n_pairs, d1, d2);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!dev1) HIP_TRY(ctx, hipMemcpyAsync(channel1, d1, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  if (!dev2) HIP_TRY(ctx, hipMemcpyAsync(channel2, d2, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  if (!dev1 || !dev2) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_deinterleave_rgba_to_r(dmz_hip_context *ctx, const uint8_t *source, uint8_t *dest, size_t size) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!source || !dest || size == 0 || (size & 3)) return fail(ctx, DMZ_HIP_EINVAL, "size must be a positive multiple of 4");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *din = nullptr;
+  if ((rc = plumbing_io(ctx, source, size * 4, ctx->stage_in, &din))) return rc;
+  const bool dev = is_device_ptr(dest);
+  uint8_t *dd = dest;
+  if (!dev) {
+    if ((rc = ensure(ctx, ctx->stage_cards, size))) return rc;
+    dd = (uint8_t *)ctx->stage_cards.p;
+  }
+  if ((((uintptr_t)din) & 15) || (((uintptr_t)dd) & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "RGBA source must be 16-byte aligned, destination 4-byte aligned");
+  dmz_launch_rgba_to_r(ctx->stream, (const uint8_t *)din, size, dd);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(dest, dd, size, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_ycbcr_to_rgb(dmz_hip_context *ctx, const uint8_t *y, const uint8_t *cb, const uint8_t *cr, size_t n_pixels,
+                         int channels, uint8_t *rgb) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!y || !cb || !cr || !rgb || n_pixels == 0 || (channels != 3 && channels != 4))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad YCbCr arguments (channels must be 3 or 4)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
+  if ((rc = plumbing_io(ctx, y, n_pixels, ctx->stage_in, &dy))) return rc;
+  if ((rc = plumbing_io(ctx, cb, n_pixels, ctx->stage_cb, &dcb))) return rc;
+  if ((rc = plumbing_io(ctx, cr, n_pixels, ctx->stage_cr, &dcr))) return rc;
+  const bool dev = is_device_ptr(rgb);
+  uint8_t *dd = rgb;
+  if (!dev) {
+    if ((rc = ensure(ctx, ctx->stage_cards, n_pixels * (size_t)channels))) return rc;
+    dd = (uint8_t *)ctx->stage_cards.p;
+  }
+  if ((((uintptr_t)dy) & 3) || (((uintptr_t)dcb) & 3) || (((uintptr_t)dcr) & 3) || (((uintptr_t)dd) & 15))
+    return fail(ctx, DMZ_HIP_EINVAL, "planes must be 4-byte aligned, the RGB buffer 16-byte aligned");
+  dmz_launch_ycbcr_to_rgb(ctx->stream, (const uint8_t *)dy, (const uint8_t *)dcb, (const uint8_t *)dcr, n_pixels, channels, dd);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, dd, n_pixels * (size_t)channels, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
 int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result *results,
                                 const dmz_hip_expiry_result *expiry, int n_sessions, int frames_per_session,
                                 int scan_expiry, int frame_interval_ms, int now_year, int now_month,

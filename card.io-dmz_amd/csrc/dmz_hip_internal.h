@@ -147,6 +147,10 @@ void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *x
 void dmz_launch_sessions(hipStream_t s, const dmz_hip_frame_result *frames, const dmz_hip_expiry_result *expiry,
                          int n_sessions, int frames_per_session, int scan_expiry, int frame_interval_ms,
                          int now_year, int now_month, int allow_past, dmz_hip_session_result *out);
+void dmz_launch_split_c2(hipStream_t s, const uint8_t *src, size_t n_pairs, uint8_t *c1, uint8_t *c2);
+void dmz_launch_rgba_to_r(hipStream_t s, const uint8_t *src, size_t n_px, uint8_t *dst);
+void dmz_launch_ycbcr_to_rgb(hipStream_t s, const uint8_t *y, const uint8_t *cb, const uint8_t *cr, size_t n_px,
+                             int channels, uint8_t *rgb);
 int dmz_configure_expiry(void);
 int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
 int dmz_configure_scan(void);

@@ -211,6 +211,10 @@ __global__ void k_homography(int n, int orientation, int options,
         px = (float)(int)px;
         py = (float)(int)py;
       }
+      if (options & DMZ_HIP_OPT_UPSAMPLE) {  // dmz.cpp:473-481: a half-size chroma plane is being rectified
+        px /= 2.0f;
+        py /= 2.0f;
+      }
       sp[2 * i] = px;
       sp[2 * i + 1] = py;
     }

@@ -1,0 +1,116 @@
+// plumbing.hip -- camera-side plumbing around the scan path, batched and
+// HBM-bound: every byte is read once and written once with 4- to 16-byte accesses per lane.
+//   dmz_deinterleave_uint8_c2  dmz.cpp:49-56 -> llcv_split_u8 cv/convert.cpp:105-107 (cvSplit)
+//   dmz_deinterleave_RGBA_to_R dmz.cpp:62-105
+//   dmz_YCbCr_to_RGB           dmz.cpp:58-60 -> llcv_YCbCr2RGB_u8_c cv/convert.cpp:448-490
+// Integer arithmetic only: bit-exact against oracle/orc_plumbing.c.
+#include "dmz_hip_internal.h"
+
+namespace {
+
+// 8 interleaved bytes (4 pixel pairs) -> 4 bytes to each plane
+__global__ __launch_bounds__(256) void k_split_c2(const uint8_t *__restrict__ src, size_t n_pairs,
+                                                  uint8_t *__restrict__ c1, uint8_t *__restrict__ c2) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;  // group of 4 pairs
+  const size_t first = q * 4;
+  if (first >= n_pairs) return;
+  if (first + 4 <= n_pairs) {
+    const uint2 v = *(const uint2 *)(src + first * 2);
+    // bytes: a0 b0 a1 b1 | a2 b2 a3 b3
+    const uint32_t a = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u), b = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+    *(uint32_t *)(c1 + first) = a;
+    *(uint32_t *)(c2 + first) = b;
+  } else {
+    for (size_t i = first; i < n_pairs; i++) {
+      c1[i] = src[2 * i];
+      c2[i] = src[2 * i + 1];
+    }
+  }
+}
+
+// 16 RGBA bytes -> 4 R bytes
+__global__ __launch_bounds__(256) void k_rgba_to_r(const uint8_t *__restrict__ src, size_t n_px, uint8_t *__restrict__ dst) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t first = q * 4;
+  if (first >= n_px) return;  // n_px is a multiple of 4
+  const uint4 v = *(const uint4 *)(src + first * 4);
+  *(uint32_t *)(dst + first) = (v.x & 255u) | ((v.y & 255u) << 8) | ((v.z & 255u) << 16) | ((v.w & 255u) << 24);
+}
+
+__device__ __forceinline__ uint32_t sat8(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// 4 pixels per lane: three dword loads, 12 (RGB) or 16 (RGBA) bytes stored
+template <int CH>
+__global__ __launch_bounds__(256) void k_ycbcr_to_rgb(const uint8_t *__restrict__ y, const uint8_t *__restrict__ cb,
+                                                      const uint8_t *__restrict__ cr, size_t n_px,
+                                                      uint8_t *__restrict__ rgb) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t first = q * 4;
+  if (first >= n_px) return;
+  const int cnt = n_px - first >= 4 ? 4 : (int)(n_px - first);
+  uint32_t wy = 0, wb = 0, wr = 0;
+  if (cnt == 4) {
+    wy = *(const uint32_t *)(y + first);
+    wb = *(const uint32_t *)(cb + first);
+    wr = *(const uint32_t *)(cr + first);
+  } else {
+    for (int k = 0; k < cnt; k++) {
+      wy |= (uint32_t)y[first + k] << (8 * k);
+      wb |= (uint32_t)cb[first + k] << (8 * k);
+      wr |= (uint32_t)cr[first + k] << (8 * k);
+    }
+  }
+  uint32_t R[4], G[4], B[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int py = (int)((wy >> (8 * k)) & 255u);
+    const int sCb = (int)((wb >> (8 * k)) & 255u) - 128, sCr = (int)((wr >> (8 * k)) & 255u) - 128;  // int8 range
+    B[k] = sat8(py + ((sCb * 29049 + (1 << 13)) >> 14));
+    G[k] = sat8(py + ((sCb * -5636 + sCr * -11698 + (1 << 13)) >> 14));
+    R[k] = sat8(py + ((sCr * 22987 + (1 << 13)) >> 14));
+  }
+  uint8_t *o = rgb + first * CH;
+  if (cnt == 4) {
+    if (CH == 3) {
+      uint32_t *o32 = (uint32_t *)o;  // first * 3 is a multiple of 12
+      o32[0] = R[0] | (G[0] << 8) | (B[0] << 16) | (R[1] << 24);
+      o32[1] = G[1] | (B[1] << 8) | (R[2] << 16) | (G[2] << 24);
+      o32[2] = B[2] | (R[3] << 8) | (G[3] << 16) | (B[3] << 24);
+    } else {
+      uint4 v;
+      v.x = R[0] | (G[0] << 8) | (B[0] << 16) | 0xFF000000u;
+      v.y = R[1] | (G[1] << 8) | (B[1] << 16) | 0xFF000000u;
+      v.z = R[2] | (G[2] << 8) | (B[2] << 16) | 0xFF000000u;
+      v.w = R[3] | (G[3] << 8) | (B[3] << 16) | 0xFF000000u;
+      *(uint4 *)o = v;
+    }
+  } else {
+    for (int k = 0; k < cnt; k++) {
+      o[k * CH + 0] = (uint8_t)R[k];
+      o[k * CH + 1] = (uint8_t)G[k];
+      o[k * CH + 2] = (uint8_t)B[k];
+      if (CH == 4) o[k * CH + 3] = 0xff;
+    }
+  }
+}
+
+}  // namespace
+
+void dmz_launch_split_c2(hipStream_t s, const uint8_t *src, size_t n_pairs, uint8_t *c1, uint8_t *c2) {
+  const size_t groups = (n_pairs + 3) / 4;
+  hipLaunchKernelGGL(k_split_c2, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, n_pairs, c1, c2);
+}
+
+void dmz_launch_rgba_to_r(hipStream_t s, const uint8_t *src, size_t n_px, uint8_t *dst) {
+  const size_t groups = n_px / 4;
+  hipLaunchKernelGGL(k_rgba_to_r, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, n_px, dst);
+}
+
+void dmz_launch_ycbcr_to_rgb(hipStream_t s, const uint8_t *y, const uint8_t *cb, const uint8_t *cr, size_t n_px,
+                             int channels, uint8_t *rgb) {
+  const size_t groups = (n_px + 3) / 4;
+  if (channels == 4)
+    hipLaunchKernelGGL(k_ycbcr_to_rgb<4>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, y, cb, cr, n_px, rgb);
+  else
+    hipLaunchKernelGGL(k_ycbcr_to_rgb<3>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, y, cb, cr, n_px, rgb);
+}

@@ -199,6 +199,11 @@ void llcv_unwarp(dmz_context *dmz, IplImage *input, const dmz_point source_point
                  const dmz_rect to_rect, IplImage *output);
 bool llcv_warp_auto_upsamples(void);
 
+// camera-side plumbing (dmz.h:64-72); *channel1 / *channel2 / *rgb are allocated when NULL (caller frees)
+void dmz_deinterleave_uint8_c2(IplImage *interleaved, IplImage **channel1, IplImage **channel2);
+void dmz_deinterleave_RGBA_to_R(uint8_t *source, uint8_t *dest, int size);
+void dmz_YCbCr_to_RGB(IplImage *y, IplImage *cb, IplImage *cr, IplImage **rgb);
+
 // scanning (scan/scan.h:51-72)
 void scanner_initialize(ScannerState *state);
 void scanner_reset(ScannerState *state);

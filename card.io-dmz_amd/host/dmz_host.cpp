@@ -308,6 +308,68 @@ void dmz_transform_card(dmz_context *dmz, IplImage *sample, dmz_corner_points co
   llcv_unwarp(dmz, sample, src, dst, *transformed);
 }
 
+// ---- camera-side plumbing (dmz.cpp:49-105) --------------------------------------------
+// The reference's versions take no dmz_context; like dmz_detect_edges they run on the process
+// default context.  Rows are repacked when widthStep carries padding.
+static uint8_t *packed_rows(const IplImage *im, int bytes_per_px, bool *owned) {
+  const int row = im->width * bytes_per_px;
+  if (im->widthStep == row) {
+    *owned = false;
+    return (uint8_t *)im->imageData;
+  }
+  uint8_t *p = (uint8_t *)malloc((size_t)row * im->height);
+  for (int r = 0; r < im->height; r++) memcpy(p + (size_t)r * row, im->imageData + (size_t)r * im->widthStep, row);
+  *owned = true;
+  return p;
+}
+static void unpack_rows(IplImage *im, int bytes_per_px, const uint8_t *p) {
+  const int row = im->width * bytes_per_px;
+  for (int r = 0; r < im->height; r++) memcpy(im->imageData + (size_t)r * im->widthStep, p + (size_t)r * row, row);
+}
+
+void dmz_deinterleave_uint8_c2(IplImage *interleaved, IplImage **channel1, IplImage **channel2) {
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx || !interleaved || interleaved->nChannels != 2 || !channel1 || !channel2) return;
+  if (!*channel1) *channel1 = dmz_create_image_8u(interleaved->width, interleaved->height, 1);
+  if (!*channel2) *channel2 = dmz_create_image_8u(interleaved->width, interleaved->height, 1);
+  const size_t n = (size_t)interleaved->width * interleaved->height;
+  bool owned;
+  uint8_t *src = packed_rows(interleaved, 2, &owned);
+  uint8_t *c1 = (uint8_t *)malloc(n), *c2 = (uint8_t *)malloc(n);
+  if (dmz_hip_deinterleave_c2(ctx, src, n, c1, c2) != DMZ_HIP_OK)
+    fprintf(stderr, "dmz (HIP): deinterleave failed: %s\n", dmz_hip_last_error(ctx));
+  unpack_rows(*channel1, 1, c1);
+  unpack_rows(*channel2, 1, c2);
+  free(c1);
+  free(c2);
+  if (owned) free(src);
+}
+
+void dmz_deinterleave_RGBA_to_R(uint8_t *source, uint8_t *dest, int size) {
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx || !source || !dest || size <= 0) return;
+  if (dmz_hip_deinterleave_rgba_to_r(ctx, source, dest, (size_t)size) != DMZ_HIP_OK)
+    fprintf(stderr, "dmz (HIP): deinterleave failed: %s\n", dmz_hip_last_error(ctx));
+}
+
+void dmz_YCbCr_to_RGB(IplImage *y, IplImage *cb, IplImage *cr, IplImage **rgb) {
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx || !y || !cb || !cr || !rgb) return;
+  if (*rgb == NULL) *rgb = dmz_create_image_8u(y->width, y->height, 3);
+  const int ch = (*rgb)->nChannels;
+  const size_t n = (size_t)y->width * y->height;
+  bool oy, ob, orr;
+  uint8_t *py = packed_rows(y, 1, &oy), *pb = packed_rows(cb, 1, &ob), *pr = packed_rows(cr, 1, &orr);
+  uint8_t *out = (uint8_t *)malloc(n * ch);
+  if (dmz_hip_ycbcr_to_rgb(ctx, py, pb, pr, n, ch, out) != DMZ_HIP_OK)
+    fprintf(stderr, "dmz (HIP): colour conversion failed: %s\n", dmz_hip_last_error(ctx));
+  unpack_rows(*rgb, ch, out);
+  free(out);
+  if (oy) free(py);
+  if (ob) free(pb);
+  if (orr) free(pr);
+}
+
 // ---- session aggregator (scan/scan.cpp:22-200) ---------------------------------------
 #define kDecayFactor 0.8f
 #define kMinStability 0.7f

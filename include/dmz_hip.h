@@ -105,6 +105,8 @@ typedef struct dmz_hip_expiry_result {
 
 /* dmz_hip_transform_batch / pipeline option bits */
 #define DMZ_HIP_OPT_TRUNCATE_CORNERS 1 /* cast corner points to int like cython_dmz/dmz.pyx:267-270 */
+#define DMZ_HIP_OPT_UPSAMPLE 2         /* dmz_transform_card(upsample = true), dmz.cpp:473-481: the plane is a
+                                          half-size Cb/Cr plane, the corner points are halved */
 
 typedef struct dmz_hip_context dmz_hip_context;
 
@@ -168,6 +170,18 @@ int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t
                                   int row_stride, int width, int height, int n, int orientation,
                                   int options, uint8_t *cards, size_t card_stride,
                                   dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry);
+
+/* ---- camera-side plumbing; all buffers tightly packed, device or host ----
+ * dmz_deinterleave_uint8_c2 (dmz.h:64, dmz.cpp:49-56): n_pairs interleaved 2-channel pixels ->
+ * two planes (channel1 = first byte of each pair, as cvSplit). */
+int dmz_hip_deinterleave_c2(dmz_hip_context *ctx, const uint8_t *interleaved, size_t n_pairs,
+                            uint8_t *channel1, uint8_t *channel2);
+/* dmz_deinterleave_RGBA_to_R (dmz.h:67, dmz.cpp:62-105): dest[i] = source[4 i]; size % 4 == 0. */
+int dmz_hip_deinterleave_rgba_to_r(dmz_hip_context *ctx, const uint8_t *source, uint8_t *dest, size_t size);
+/* dmz_YCbCr_to_RGB (dmz.h:72, dmz.cpp:58-60, cv/convert.cpp:448-490) on n_pixels pixels of three
+ * equally sized planes (e.g. a batch of rectified Y / Cb / Cr cards); channels = 3 (RGB) or 4 (RGBA). */
+int dmz_hip_ycbcr_to_rgb(dmz_hip_context *ctx, const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
+                         size_t n_pixels, int channels, uint8_t *rgb);
 
 /* ---- per-session policy, batched.  One record per session: what
  * scanner_result (scan/scan.h:67, scan.cpp:88-194) reports after the last frame fed, plus where in

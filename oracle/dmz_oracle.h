@@ -120,9 +120,10 @@ void orc_calc_persp_transform(const float src_pts[8], const float dst_pts[8], fl
 /* cvWarpPerspective(INTER_LINEAR|FILL_OUTLIERS, 0), SURVEY Appendix A10 */
 void orc_warp_perspective(const uint8_t *src, int stride, int sw, int sh,
                           const float m[9], uint8_t *dst, int dstride, int dw, int dh);
-/* dmz.cpp:443-497 for a 1-channel plane, upsample=false */
+/* dmz.cpp:443-497 for a 1-channel plane.  options: bit 0 = cast the corner points to int
+ * (cython_dmz/dmz.pyx:267-270), bit 1 = `upsample` (half-size chroma plane: points / 2, dmz.cpp:473-481) */
 void orc_transform_card(const uint8_t *plane, int stride, int w, int h,
-                        const float corners[8], int orientation, int truncate_corners,
+                        const float corners[8], int orientation, int options,
                         uint8_t *card /* 428x270, stride 428 */);
 
 /* ---- scan/ ----------------------------------------------------------------- */
@@ -193,6 +194,12 @@ int orc_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *
                                   int64_t *rect_sum);
 void orc_expiry_regrid_group(const int16_t *sobel, int top, int height, int *left, int *width,
                              int *character_width, int *n, int *rect_left, int64_t *rect_sum);
+
+/* ---- camera-side plumbing ---- */
+void orc_split_u8(const uint8_t *interleaved, int stride, int w, int h, uint8_t *c1, uint8_t *c2); /* convert.cpp:105-107 */
+void orc_deinterleave_rgba_to_r(const uint8_t *source, uint8_t *dest, int size);                  /* dmz.cpp:62-105 */
+void orc_ycbcr_to_rgb(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, int w, int h, int channels,
+                      uint8_t *rgb);                                                               /* convert.cpp:448-490 */
 
 /* ---- per-session policy (scan/scan.cpp:41-194 + expiry_categorize.cpp:162-376) replayed over the
  * per-frame records of one session; layout == dmz_hip_session_result (include/dmz_hip.h) ---- */

@@ -162,12 +162,32 @@ class Oracle:
                                       _p(m, _f32p), _p(dst, _u8p), dw, dw, dh)
         return dst
 
-    def transform_card(self, plane, corners, orientation=3, truncate=False):
+    def split_u8(self, interleaved):
+        a = np.ascontiguousarray(interleaved, np.uint8)  # (h, w, 2)
+        h, w = a.shape[:2]
+        c1, c2 = np.empty((h, w), np.uint8), np.empty((h, w), np.uint8)
+        self.lib.orc_split_u8(_p(a, _u8p), 2 * w, w, h, _p(c1, _u8p), _p(c2, _u8p))
+        return c1, c2
+
+    def deinterleave_rgba_to_r(self, rgba):
+        a = np.ascontiguousarray(rgba, np.uint8).reshape(-1)
+        out = np.empty(a.size // 4, np.uint8)
+        self.lib.orc_deinterleave_rgba_to_r(_p(a, _u8p), _p(out, _u8p), out.size)
+        return out
+
+    def ycbcr_to_rgb(self, y, cb, cr, channels=3):
+        y, cb, cr = (np.ascontiguousarray(v, np.uint8) for v in (y, cb, cr))
+        out = np.empty(y.shape + (channels,), np.uint8)
+        self.lib.orc_ycbcr_to_rgb(_p(y, _u8p), _p(cb, _u8p), _p(cr, _u8p), y.shape[-1], int(y.size // y.shape[-1]),
+                                  channels, _p(out, _u8p))
+        return out
+
+    def transform_card(self, plane, corners, orientation=3, truncate=False, upsample=False):
         plane = np.ascontiguousarray(plane, np.uint8)
         c = np.ascontiguousarray(corners, np.float32).reshape(8)
         card = np.empty((270, 428), np.uint8)
         self.lib.orc_transform_card(_p(plane, _u8p), plane.shape[1], plane.shape[1], plane.shape[0],
-                                    _p(c, _f32p), orientation, int(truncate), _p(card, _u8p))
+                                    _p(c, _f32p), orientation, int(truncate) | (2 if upsample else 0), _p(card, _u8p))
         return card
 
     # ---- scan ----

@@ -573,7 +573,8 @@ void orc_warp_perspective(const uint8_t *src, int stride, int sw, int sh, const 
 
 /* dmz.cpp:443-497 (1-channel plane, upsample=false) + warp.cpp:153-166 */
 void orc_transform_card(const uint8_t *plane, int stride, int w, int h, const float c[8],
-                        int orientation, int truncate_corners, uint8_t *card) {
+                        int orientation, int options, uint8_t *card) {
+  const int truncate_corners = options & 1, upsample = options & 2;
   /* corners in: tl(0,1) bl(2,3) tr(4,5) br(6,7) */
   static const int order[5][4] = {
       {0, 2, 1, 3}, /* unused */
@@ -589,6 +590,10 @@ void orc_transform_card(const uint8_t *plane, int stride, int w, int h, const fl
     if (truncate_corners) { /* cython_dmz/dmz.pyx:267-270 casts corner points to int */
       px = (float)(int)px;
       py = (float)(int)py;
+    }
+    if (upsample) { /* dmz.cpp:473-481: Cb/Cr planes are half size */
+      px /= 2.0f;
+      py /= 2.0f;
     }
     sp[2 * i] = px;
     sp[2 * i + 1] = py;

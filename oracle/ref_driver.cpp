@@ -380,3 +380,8 @@ REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
   out->count16 = state.count16;
   out->n_expiry_groups = (int)state.expiry_groups.size();
 }
+
+// ---- dmz_deinterleave_RGBA_to_R (dmz.cpp:62-105): plain C, no OpenCV symbol ----
+REF_API void ref_deinterleave_rgba_to_r(uint8_t *source, uint8_t *dest, int size) {
+  dmz_deinterleave_RGBA_to_R(source, dest, size);
+}

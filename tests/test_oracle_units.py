@@ -125,3 +125,24 @@ def test_luhn(oracle):
     for i in range(8):
         _, d = oracle.synth_frame(9, i)
         assert oracle.passes_luhn(d)
+
+
+def test_plumbing_hand_checked(oracle):
+    """cvSplit order; BT.601 fixed point of convert.cpp:448-490 on hand-computed pixels"""
+    inter = np.arange(2 * 3 * 2, dtype=np.uint8).reshape(2, 3, 2)
+    c1, c2 = oracle.split_u8(inter)
+    assert c1.tolist() == [[0, 2, 4], [6, 8, 10]] and c2.tolist() == [[1, 3, 5], [7, 9, 11]]
+    y = np.array([[100, 16, 235, 255, 0]], np.uint8)
+    cb = np.array([[128, 128, 255, 0, 200]], np.uint8)
+    cr = np.array([[128, 255, 128, 0, 30]], np.uint8)
+    rgb = oracle.ycbcr_to_rgb(y, cb, cr)
+    # grey stays grey
+    assert rgb[0, 0].tolist() == [100, 100, 100]
+    # Cr = +127: R = 16 + round(127 * 22987 / 16384) = 16 + 178, G = 16 + floor((127 * -11698 + 8192) / 16384) = 16 - 91 -> 0
+    assert rgb[0, 1].tolist() == [194, 0, 16]
+    # Cb = +127: B = 235 + 225 -> 255, G = 235 + floor((127 * -5636 + 8192) / 16384) = 235 - 44
+    assert rgb[0, 2].tolist() == [235, 191, 255]
+    # Cb = Cr = -128: R = 255 - 180 = 75, G = 255 + floor((721408 + 1497344 + 8192) / 16384) -> 255, B = 255 - 227 = 28
+    assert rgb[0, 3].tolist() == [75, 255, 28]
+    rgba = oracle.ycbcr_to_rgb(y, cb, cr, channels=4)
+    assert np.array_equal(rgba[..., :3], rgb) and (rgba[..., 3] == 255).all()

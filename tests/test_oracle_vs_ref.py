@@ -222,3 +222,13 @@ def test_session_policy_matches_reference(oracle, reference, orc):
                 completed += int(want["complete"])
                 with_expiry += int(got["expiry_month"] > 0)
     assert completed >= 20 and with_expiry >= 20, (completed, with_expiry)
+
+
+def test_deinterleave_rgba_to_r_matches_reference(oracle, reference):
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for size in (4, 8, 12, 16, 20, 64, 4 * 777):
+        src = rng.integers(0, 256, size * 4).astype(np.uint8)
+        want = np.zeros(size, np.uint8)
+        reference.lib.ref_deinterleave_rgba_to_r(src.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), size)
+        assert np.array_equal(oracle.deinterleave_rgba_to_r(src), want), size

@@ -13,7 +13,7 @@ for FLAG in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude $FLAG \
      -c $P/csrc/$FILE -o gpurun_out/ablate/var_$i.o 2>/dev/null
   OBJS=""
-  for f in detect geometry warp vseg hseg digits expiry session synth capi weights_blob; do
+  for f in detect geometry warp vseg hseg digits expiry session plumbing synth capi weights_blob; do
     if [ "$f.hip" == "$FILE" ]; then OBJS="$OBJS gpurun_out/ablate/var_$i.o"; else OBJS="$OBJS $P/csrc/$f.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
