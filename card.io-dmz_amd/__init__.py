@@ -82,6 +82,7 @@ EXPORTS = (
     "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
     "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
     "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
+    "dmz_hip_scores_batch",
 )
 
 
@@ -123,6 +124,7 @@ def load_library():
     lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
     lib.dmz_hip_scan_expiry_batch.argtypes = [vp, vp, sz, i, vp, vp]
     lib.dmz_hip_pipeline_expiry_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp, vp]
+    lib.dmz_hip_scores_batch.argtypes = [vp, vp, sz, i, i, i, i, i, vp, vp]
     lib.dmz_hip_deinterleave_c2.argtypes = [vp, vp, sz, vp, vp]
     lib.dmz_hip_deinterleave_rgba_to_r.argtypes = [vp, vp, vp, sz]
     lib.dmz_hip_ycbcr_to_rgb.argtypes = [vp, vp, vp, vp, sz, i, vp]
@@ -264,6 +266,10 @@ class Context:
         self._check(self.lib.dmz_hip_pipeline_expiry_batch(
             self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
             _ptr(cards), CARD_BYTES, _ptr(results), _ptr(expiry)))
+
+    def scores(self, y, n, focus, brightness, width=FRAME_W, height=FRAME_H, use_full_image=False):
+        self._check(self.lib.dmz_hip_scores_batch(self.h, _ptr(y), width * height, width, width, height, n,
+                                                  int(use_full_image), _ptr(focus), _ptr(brightness)))
 
     def deinterleave_c2(self, interleaved, n_pairs, channel1, channel2):
         self._check(self.lib.dmz_hip_deinterleave_c2(self.h, _ptr(interleaved), n_pairs, _ptr(channel1), _ptr(channel2)))

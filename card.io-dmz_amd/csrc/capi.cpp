@@ -806,6 +806,52 @@ int dmz_hip_ycbcr_to_rgb(dmz_hip_context *ctx, const uint8_t *y, const uint8_t *
   return DMZ_HIP_OK;
 }
 
+// dmz.cpp:138-185: the scoring ROI of a (width x height) image
+static void scoring_roi(int width, int height, int use_full_image, int rc[4]) {
+  const int cw = use_full_image ? DMZ_CARD_WIDTH : DMZ_CARD_WIDTH / 3, ch = use_full_image ? DMZ_CARD_HEIGHT : DMZ_CARD_HEIGHT / 3;
+  const int sw = 640, sh = 480;  // kLandscapeSampleWidth / Height
+  int rw, rh;
+  if (width == sw && height == sh) {
+    rw = cw;
+    rh = ch;
+  } else {
+    const float wr = ((float)width) / ((float)sw), hr = ((float)height) / ((float)sh);
+    const float ratio = wr < hr ? wr : hr;
+    rw = (int)(cw * ratio);
+    rh = (int)(ch * ratio);
+  }
+  rc[0] = (width - rw) / 2;
+  rc[1] = (height - rh) / 2;
+  rc[2] = rw;
+  rc[3] = rh;
+}
+
+int dmz_hip_scores_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride, int width,
+                         int height, int n, int use_full_image, float *focus, float *brightness) {
+  int rc = check_frames(ctx, y, frame_stride, row_stride, width, height, n);
+  if (rc) return rc;
+  if (!focus && !brightness) return fail(ctx, DMZ_HIP_EINVAL, "no output requested");
+  int roi[4];
+  scoring_roi(width, height, use_full_image, roi);
+  if (roi[2] <= 0 || roi[3] <= 0 || roi[0] < 0 || roi[1] < 0) return fail(ctx, DMZ_HIP_EINVAL, "image too small for the scoring ROI");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const void *dy = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, frame_stride * (size_t)n, &dy))) return rc;
+  const bool fdev = focus && is_device_ptr(focus), bdev = brightness && is_device_ptr(brightness);
+  float *df = focus, *db = brightness;
+  if ((focus && !fdev) || (brightness && !bdev)) {
+    if ((rc = ensure(ctx, ctx->misc, sizeof(float) * 2 * (size_t)n))) return rc;
+    if (focus && !fdev) df = (float *)ctx->misc.p;
+    if (brightness && !bdev) db = (float *)ctx->misc.p + n;
+  }
+  dmz_launch_scores(ctx->stream, (const uint8_t *)dy, frame_stride, row_stride, n, roi[0], roi[1], roi[2], roi[3], df, db);
+  HIP_TRY(ctx, hipGetLastError());
+  if (focus && !fdev) HIP_TRY(ctx, hipMemcpyAsync(focus, df, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (brightness && !bdev) HIP_TRY(ctx, hipMemcpyAsync(brightness, db, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if ((focus && !fdev) || (brightness && !bdev)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMZ_HIP_OK;
+}
+
 int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result *results,
                                 const dmz_hip_expiry_result *expiry, int n_sessions, int frames_per_session,
                                 int scan_expiry, int frame_interval_ms, int now_year, int now_month,

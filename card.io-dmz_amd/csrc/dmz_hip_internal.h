@@ -151,6 +151,8 @@ void dmz_launch_split_c2(hipStream_t s, const uint8_t *src, size_t n_pairs, uint
 void dmz_launch_rgba_to_r(hipStream_t s, const uint8_t *src, size_t n_px, uint8_t *dst);
 void dmz_launch_ycbcr_to_rgb(hipStream_t s, const uint8_t *y, const uint8_t *cb, const uint8_t *cr, size_t n_px,
                              int channels, uint8_t *rgb);
+void dmz_launch_scores(hipStream_t s, const uint8_t *y, size_t frame_stride, int row_stride, int n, int rx, int ry,
+                       int rw, int rh, float *focus, float *brightness);
 int dmz_configure_expiry(void);
 int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
 int dmz_configure_scan(void);

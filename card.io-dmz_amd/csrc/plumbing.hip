@@ -114,3 +114,64 @@ void dmz_launch_ycbcr_to_rgb(hipStream_t s, const uint8_t *y, const uint8_t *cb,
   else
     hipLaunchKernelGGL(k_ycbcr_to_rgb<3>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, y, cb, cr, n_px, rgb);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Quality scores: dmz_focus_score / dmz_brightness_score (dmz.cpp:114-199) on
+// the scoring ROI of every frame of a batch.  focus = stddev of |sobel3_dx_dy| (sobel.cpp:556-607,
+// stats.cpp:97-102 -> cv::meanStdDev), brightness = cvAvg.  The sums are exact integers; the
+// final mean / variance / sqrt steps are the reference's double operations in the same order.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_scores(const uint8_t *__restrict__ y, size_t frame_stride, int row_stride, int n,
+                                                int rx, int ry, int rw, int rh, float *__restrict__ focus,
+                                                float *__restrict__ brightness) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= n) return;
+  const uint8_t *roi = y + (size_t)f * frame_stride + (size_t)ry * row_stride + rx;
+  unsigned s_abs = 0u, s_px = 0u;
+  unsigned long long s_sq = 0ull;
+  for (int i = tid; i < rw * rh; i += 256) {
+    const int r = i / rw, c = i - r * rw;
+    const uint8_t *r1 = roi + (size_t)(r == 0 ? 0 : r - 1) * row_stride;
+    const uint8_t *r2 = roi + (size_t)(r == rh - 1 ? rh - 1 : r + 1) * row_stride;
+    const int cl = c == 0 ? 0 : c - 1, cr = c == rw - 1 ? rw - 1 : c + 1;
+    int d = (int)r1[cl] - (int)r1[cr] - (int)r2[cl] + (int)r2[cr];
+    d = d < 0 ? -d : d;
+    s_abs += (unsigned)d;
+    s_sq += (unsigned long long)(d * d);
+    s_px += roi[(size_t)r * row_stride + c];
+  }
+  __shared__ unsigned sh_abs[256], sh_px[256];
+  __shared__ unsigned long long sh_sq[256];
+  sh_abs[tid] = s_abs;
+  sh_px[tid] = s_px;
+  sh_sq[tid] = s_sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      sh_abs[tid] += sh_abs[tid + o];
+      sh_px[tid] += sh_px[tid + o];
+      sh_sq[tid] += sh_sq[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double scale = 1. / ((double)rw * (double)rh);
+    if (focus) {
+      const double mean = (double)sh_abs[0] * scale;
+      double var = (double)sh_sq[0] * scale - mean * mean;
+      if (!(var > 0.)) var = 0.;
+      focus[f] = (float)sqrt(var);
+    }
+    if (brightness) brightness[f] = (float)((double)sh_px[0] * scale);
+  }
+}
+
+}  // namespace
+
+void dmz_launch_scores(hipStream_t s, const uint8_t *y, size_t frame_stride, int row_stride, int n, int rx, int ry,
+                       int rw, int rh, float *focus, float *brightness) {
+  hipLaunchKernelGGL(k_scores, dim3((unsigned)n), dim3(256), 0, s, y, frame_stride, row_stride, n, rx, ry, rw, rh, focus,
+                     brightness);
+}

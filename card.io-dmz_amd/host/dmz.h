@@ -204,6 +204,10 @@ void dmz_deinterleave_uint8_c2(IplImage *interleaved, IplImage **channel1, IplIm
 void dmz_deinterleave_RGBA_to_R(uint8_t *source, uint8_t *dest, int size);
 void dmz_YCbCr_to_RGB(IplImage *y, IplImage *cb, IplImage *cr, IplImage **rgb);
 
+// quality scores (dmz.h:77-79, dmz.cpp:114-199)
+float dmz_focus_score(IplImage *image, bool use_full_image);
+float dmz_brightness_score(IplImage *image, bool use_full_image);
+
 // scanning (scan/scan.h:51-72)
 void scanner_initialize(ScannerState *state);
 void scanner_reset(ScannerState *state);

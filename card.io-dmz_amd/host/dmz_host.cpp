@@ -370,6 +370,20 @@ void dmz_YCbCr_to_RGB(IplImage *y, IplImage *cb, IplImage *cr, IplImage **rgb) {
   if (orr) free(pr);
 }
 
+// ---- quality scores (dmz.cpp:114-199) ---------------------------------------------------
+static float score_of(IplImage *image, bool use_full_image, bool want_focus) {
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx || !image || image->nChannels != 1) return 0.0f;
+  float v = 0.0f;
+  const int rc = dmz_hip_scores_batch(ctx, (const uint8_t *)image->imageData, (size_t)image->widthStep * image->height,
+                                      image->widthStep, image->width, image->height, 1, use_full_image,
+                                      want_focus ? &v : NULL, want_focus ? NULL : &v);
+  if (rc != DMZ_HIP_OK) fprintf(stderr, "dmz (HIP): score failed: %s\n", dmz_hip_last_error(ctx));
+  return v;
+}
+float dmz_focus_score(IplImage *image, bool use_full_image) { return score_of(image, use_full_image, true); }
+float dmz_brightness_score(IplImage *image, bool use_full_image) { return score_of(image, use_full_image, false); }
+
 // ---- session aggregator (scan/scan.cpp:22-200) ---------------------------------------
 #define kDecayFactor 0.8f
 #define kMinStability 0.7f

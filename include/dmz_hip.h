@@ -183,6 +183,13 @@ int dmz_hip_deinterleave_rgba_to_r(dmz_hip_context *ctx, const uint8_t *source, 
 int dmz_hip_ycbcr_to_rgb(dmz_hip_context *ctx, const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
                          size_t n_pixels, int channels, uint8_t *rgb);
 
+/* Quality scores: dmz_focus_score / dmz_brightness_score (dmz.h:77-79,
+ * dmz.cpp:114-199) of n luma planes: the scoring ROI is the centre ninth of the guide frame, or the
+ * whole guide frame when use_full_image != 0 (dmz.cpp:167-185).  focus / brightness: n floats each,
+ * either may be NULL. */
+int dmz_hip_scores_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
+                         int width, int height, int n, int use_full_image, float *focus, float *brightness);
+
 /* ---- per-session policy, batched.  One record per session: what
  * scanner_result (scan/scan.h:67, scan.cpp:88-194) reports after the last frame fed, plus where in
  * the session it happened. ------------------------------------------------------------------- */

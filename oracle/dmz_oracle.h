@@ -201,6 +201,12 @@ void orc_deinterleave_rgba_to_r(const uint8_t *source, uint8_t *dest, int size);
 void orc_ycbcr_to_rgb(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, int w, int h, int channels,
                       uint8_t *rgb);                                                               /* convert.cpp:448-490 */
 
+/* ---- quality scores ---- */
+void orc_card_rect_for_screen(int card_w, int card_h, int std_w, int std_h, int act_w, int act_h, int rect[4]); /* dmz.cpp:138-165 */
+void orc_scoring_roi(int img_w, int img_h, int use_full_image, int rect[4]);                                     /* dmz.cpp:167-185 */
+float orc_focus_score(const uint8_t *img, int stride, int w, int h, int use_full_image);       /* dmz.cpp:114-126,187-192 */
+float orc_brightness_score(const uint8_t *img, int stride, int w, int h, int use_full_image);  /* dmz.cpp:128-135,194-199 */
+
 /* ---- per-session policy (scan/scan.cpp:41-194 + expiry_categorize.cpp:162-376) replayed over the
  * per-frame records of one session; layout == dmz_hip_session_result (include/dmz_hip.h) ---- */
 typedef struct {

@@ -182,6 +182,21 @@ class Oracle:
                                   channels, _p(out, _u8p))
         return out
 
+    def scoring_roi(self, w, h, use_full):
+        rc = np.zeros(4, np.int32)
+        self.lib.orc_scoring_roi(w, h, int(use_full), _p(rc, _i32p))
+        return rc
+
+    def focus_score(self, img, use_full=False):
+        img = np.ascontiguousarray(img, np.uint8)
+        self.lib.orc_focus_score.restype = C.c_float
+        return np.float32(self.lib.orc_focus_score(_p(img, _u8p), img.shape[1], img.shape[1], img.shape[0], int(use_full)))
+
+    def brightness_score(self, img, use_full=False):
+        img = np.ascontiguousarray(img, np.uint8)
+        self.lib.orc_brightness_score.restype = C.c_float
+        return np.float32(self.lib.orc_brightness_score(_p(img, _u8p), img.shape[1], img.shape[1], img.shape[0], int(use_full)))
+
     def transform_card(self, plane, corners, orientation=3, truncate=False, upsample=False):
         plane = np.ascontiguousarray(plane, np.uint8)
         c = np.ascontiguousarray(corners, np.float32).reshape(8)

@@ -41,3 +41,70 @@ void orc_ycbcr_to_rgb(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, in
       if (channels == 4) o[3] = 0xff;
     }
 }
+
+/* ---- quality scores: dmz_focus_score / dmz_brightness_score ---------------- */
+#include <math.h>
+
+/* dmz.cpp:138-165 */
+void orc_card_rect_for_screen(int card_w, int card_h, int std_w, int std_h, int act_w, int act_h, int rect[4]) {
+  rect[0] = rect[1] = rect[2] = rect[3] = 0;
+  if (card_w == 0 || card_h == 0 || std_w == 0 || std_h == 0 || act_w == 0 || act_h == 0) return;
+  int rw, rh;
+  if (act_w == std_w && act_h == std_h) {
+    rw = card_w;
+    rh = card_h;
+  } else {
+    float wr = ((float)act_w) / ((float)std_w), hr = ((float)act_h) / ((float)std_h);
+    float ratio = wr < hr ? wr : hr;
+    rw = (int)(card_w * ratio);
+    rh = (int)(card_h * ratio);
+  }
+  rect[0] = (act_w - rw) / 2;
+  rect[1] = (act_h - rh) / 2;
+  rect[2] = rw;
+  rect[3] = rh;
+}
+
+/* dmz.cpp:167-185: the centre 1/9th of the guide frame unless use_full_image */
+void orc_scoring_roi(int img_w, int img_h, int use_full_image, int rect[4]) {
+  const int fw = use_full_image ? ORC_CARD_W : ORC_CARD_W / 3, fh = use_full_image ? ORC_CARD_H : ORC_CARD_H / 3;
+  orc_card_rect_for_screen(fw, fh, 640, 480, img_w, img_h, rect);
+}
+
+/* dmz.cpp:114-126 + 187-192: llcv_sobel3_dx_dy (sobel.cpp:556-607, indices clamped at the ROI edge),
+ * cvAbs, cvAvgSdv = cv::meanStdDev: exact integer sums, mean = s * (1/N), sqrt(max(sq/N - mean^2, 0)) in double */
+float orc_focus_score(const uint8_t *img, int stride, int w, int h, int use_full_image) {
+  int rc[4];
+  orc_scoring_roi(w, h, use_full_image, rc);
+  const uint8_t *roi = img + (size_t)rc[1] * stride + rc[0];
+  const int rw = rc[2], rh = rc[3];
+  if (rw <= 0 || rh <= 0) return 0.0f;
+  double s = 0.0, sq = 0.0;
+  for (int r = 0; r < rh; r++) {
+    const uint8_t *r1 = roi + (size_t)(r == 0 ? 0 : r - 1) * stride;
+    const uint8_t *r2 = roi + (size_t)(r == rh - 1 ? rh - 1 : r + 1) * stride;
+    for (int c = 0; c < rw; c++) {
+      const int cl = c == 0 ? 0 : c - 1, cr = c == rw - 1 ? rw - 1 : c + 1;
+      int d = r1[cl] - r1[cr] - r2[cl] + r2[cr];
+      if (d < 0) d = -d;
+      s += d;
+      sq += (double)d * d;
+    }
+  }
+  const double scale = 1. / ((double)rw * rh);
+  const double mean = s * scale;
+  double var = sq * scale - mean * mean;
+  if (!(var > 0.)) var = 0.;
+  return (float)sqrt(var);
+}
+
+/* dmz.cpp:128-135 + 194-199: cvAvg over the same ROI */
+float orc_brightness_score(const uint8_t *img, int stride, int w, int h, int use_full_image) {
+  int rc[4];
+  orc_scoring_roi(w, h, use_full_image, rc);
+  if (rc[2] <= 0 || rc[3] <= 0) return 0.0f;
+  double s = 0.0;
+  for (int r = 0; r < rc[3]; r++)
+    for (int c = 0; c < rc[2]; c++) s += img[(size_t)(rc[1] + r) * stride + rc[0] + c];
+  return (float)(s * (1. / ((double)rc[2] * rc[3])));
+}

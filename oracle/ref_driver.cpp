@@ -385,3 +385,12 @@ REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
 REF_API void ref_deinterleave_rgba_to_r(uint8_t *source, uint8_t *dest, int size) {
   dmz_deinterleave_RGBA_to_R(source, dest, size);
 }
+
+// ---- dmz_card_rect_for_screen (dmz.cpp:138-165): header-only CvRect / CvSize ----
+REF_API void ref_card_rect_for_screen(int card_w, int card_h, int std_w, int std_h, int act_w, int act_h, int *rect) {
+  CvRect r = dmz_card_rect_for_screen(cvSize(card_w, card_h), cvSize(std_w, std_h), cvSize(act_w, act_h));
+  rect[0] = r.x;
+  rect[1] = r.y;
+  rect[2] = r.width;
+  rect[3] = r.height;
+}

@@ -88,3 +88,30 @@ def test_colour_card_chain(ctx, pkg, oracle):
         wcr = oracle.transform_card(crp[i], w["corners"], upsample=True)
         assert np.array_equal(ycard[i], wy) and np.array_equal(cbcard[i], wcb) and np.array_equal(crcard[i], wcr), i
         assert np.array_equal(rgb[i], oracle.ycbcr_to_rgb(wy, wcb, wcr)), i
+
+
+def test_focus_and_brightness_scores(ctx, pkg, oracle):
+    """dmz_focus_score / dmz_brightness_score: float bits equal the oracle's (exact integer sums, then the
+    same double operations)"""
+    rng = np.random.default_rng(12)
+    n = 12
+    frames = np.stack([oracle.synth_frame(5, i)[0] for i in range(n - 3)] +
+                      [np.zeros((480, 640), np.uint8), np.full((480, 640), 255, np.uint8),
+                       rng.integers(0, 256, (480, 640)).astype(np.uint8)])
+    for full in (False, True):
+        focus = np.zeros(n, np.float32)
+        bright = np.zeros(n, np.float32)
+        ctx.scores(frames, n, focus, bright, use_full_image=full)
+        for i in range(n):
+            assert focus[i].view(np.uint32) == oracle.focus_score(frames[i], full).view(np.uint32), (i, full)
+            assert bright[i].view(np.uint32) == oracle.brightness_score(frames[i], full).view(np.uint32), (i, full)
+    # other image sizes scale the ROI (dmz.cpp:152-160); device-resident input, one output only
+    for (w, h) in ((1280, 720), (320, 240), (480, 640)):
+        img = rng.integers(0, 256, (3, h, w)).astype(np.uint8)
+        d = ctx.alloc(img.nbytes)
+        d.upload(img)
+        focus = np.zeros(3, np.float32)
+        ctx.scores(d.ptr, 3, focus, None, width=w, height=h)
+        for i in range(3):
+            assert focus[i].view(np.uint32) == oracle.focus_score(img[i]).view(np.uint32), (w, h, i)
+        d.free()

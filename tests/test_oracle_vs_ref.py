@@ -232,3 +232,19 @@ def test_deinterleave_rgba_to_r_matches_reference(oracle, reference):
         want = np.zeros(size, np.uint8)
         reference.lib.ref_deinterleave_rgba_to_r(src.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), size)
         assert np.array_equal(oracle.deinterleave_rgba_to_r(src), want), size
+
+
+def test_card_rect_for_screen_matches_reference(oracle, reference):
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    for _ in range(500):
+        a = [int(v) for v in rng.integers(0, 2000, 6)]
+        if rng.random() < 0.3:
+            a[2], a[3] = 640, 480
+            if rng.random() < 0.5:
+                a[4], a[5] = 640, 480
+        want = (C.c_int * 4)()
+        reference.lib.ref_card_rect_for_screen(*a, want)
+        got = np.zeros(4, np.int32)
+        oracle.lib.orc_card_rect_for_screen(*a, got.ctypes.data_as(C.POINTER(C.c_int)))
+        assert list(got) == list(want), a
