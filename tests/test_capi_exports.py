@@ -24,6 +24,13 @@ def test_result_record_layout(pkg, orc):
     assert pkg.RESULT_DTYPE.fields["reserved"][1] == 816
 
 
+def test_expiry_and_session_record_layouts(pkg, orc):
+    assert pkg.EXPIRY_DTYPE == orc.EXPIRY_DTYPE and pkg.EXPIRY_DTYPE.itemsize == 1592
+    assert pkg.SESSION_DTYPE == orc.SESSION_DTYPE and pkg.SESSION_DTYPE.itemsize == 128
+    header = open(os.path.join(ROOT, "include", "dmz_hip.h")).read()
+    assert "#define DMZ_HIP_EXPIRY_MAX_GROUPS 8" in header and "/* 1592 bytes */" in header and "/* 128 bytes */" in header
+
+
 def test_no_gpu_means_loud_failure(pkg):
     import pytest
     lib = pkg.load_library()
