@@ -66,7 +66,7 @@ SESSION_DTYPE = np.dtype([
     ("complete", "<i4"), ("complete_frame", "<i4"), ("number_frame", "<i4"), ("n_numbers", "<i4"),
     ("predictions", "u1", (16,)), ("card_type", "<i4"), ("expiry_month", "<i4"), ("expiry_year", "<i4"),
     ("count15", "<i4"), ("count16", "<i4"), ("usable_frames", "<i4"), ("n_expiry_groups", "<i4"),
-    ("vseg_y_offset", "<i4"), ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("reserved", "<i4", (7,)),
+    ("vseg_y_offset", "<i4"), ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("number_width", "<f4"), ("reserved", "<i4", (6,)),
 ])
 assert SESSION_DTYPE.itemsize == 128
 
@@ -82,7 +82,7 @@ EXPORTS = (
     "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
     "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
     "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
-    "dmz_hip_scores_batch",
+    "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch",
 )
 
 
@@ -124,6 +124,7 @@ def load_library():
     lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
     lib.dmz_hip_scan_expiry_batch.argtypes = [vp, vp, sz, i, vp, vp]
     lib.dmz_hip_pipeline_expiry_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp, vp]
+    lib.dmz_hip_blur_cards_batch.argtypes = [vp, vp, sz, i, i, vp, i]
     lib.dmz_hip_scores_batch.argtypes = [vp, vp, sz, i, i, i, i, i, vp, vp]
     lib.dmz_hip_deinterleave_c2.argtypes = [vp, vp, sz, vp, vp]
     lib.dmz_hip_deinterleave_rgba_to_r.argtypes = [vp, vp, vp, sz]
@@ -266,6 +267,10 @@ class Context:
         self._check(self.lib.dmz_hip_pipeline_expiry_batch(
             self.h, _ptr(y), width * height, width, width, height, n, orientation, options,
             _ptr(cards), CARD_BYTES, _ptr(results), _ptr(expiry)))
+
+    def blur_cards(self, rgb, n, sessions, unblur_digits, channels=3):
+        self._check(self.lib.dmz_hip_blur_cards_batch(self.h, _ptr(rgb), CARD_BYTES * channels, channels, n,
+                                                      _ptr(sessions), unblur_digits))
 
     def scores(self, y, n, focus, brightness, width=FRAME_W, height=FRAME_H, use_full_image=False):
         self._check(self.lib.dmz_hip_scores_batch(self.h, _ptr(y), width * height, width, width, height, n,

@@ -852,6 +852,32 @@ int dmz_hip_scores_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
   return DMZ_HIP_OK;
 }
 
+int dmz_hip_blur_cards_batch(dmz_hip_context *ctx, uint8_t *rgb, size_t card_stride, int channels, int n,
+                             const dmz_hip_session_result *sessions, int unblur_digits) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!rgb || !sessions || n <= 0 || (channels != 3 && channels != 4) ||
+      card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT * (size_t)channels)
+    return fail(ctx, DMZ_HIP_EINVAL, "bad blur arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dsess = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_sess, sessions, sizeof(dmz_hip_session_result) * (size_t)n, &dsess))) return rc;
+  const bool dev = is_device_ptr(rgb);
+  uint8_t *drgb = rgb;
+  if (!dev) {
+    if ((rc = ensure(ctx, ctx->stage_cards, card_stride * (size_t)n))) return rc;
+    drgb = (uint8_t *)ctx->stage_cards.p;
+    HIP_TRY(ctx, hipMemcpyAsync(drgb, rgb, card_stride * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  dmz_launch_blur_cards(ctx->stream, drgb, card_stride, channels, n, (const dmz_hip_session_result *)dsess, unblur_digits);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, drgb, card_stride * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
 int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result *results,
                                 const dmz_hip_expiry_result *expiry, int n_sessions, int frames_per_session,
                                 int scan_expiry, int frame_interval_ms, int now_year, int now_month,

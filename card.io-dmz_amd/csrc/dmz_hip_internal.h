@@ -153,6 +153,8 @@ void dmz_launch_ycbcr_to_rgb(hipStream_t s, const uint8_t *y, const uint8_t *cb,
                              int channels, uint8_t *rgb);
 void dmz_launch_scores(hipStream_t s, const uint8_t *y, size_t frame_stride, int row_stride, int n, int rx, int ry,
                        int rw, int rh, float *focus, float *brightness);
+void dmz_launch_blur_cards(hipStream_t s, uint8_t *rgb, size_t card_stride, int channels, int n,
+                           const dmz_hip_session_result *sessions, int unblur_digits);
 int dmz_configure_expiry(void);
 int dmz_configure_detect(void);  // one-time hipFuncSetAttribute calls; return hipError_t
 int dmz_configure_scan(void);

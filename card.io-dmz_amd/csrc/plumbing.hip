@@ -175,3 +175,78 @@ void dmz_launch_scores(hipStream_t s, const uint8_t *y, size_t frame_stride, int
   hipLaunchKernelGGL(k_scores, dim3((unsigned)n), dim3(256), 0, s, y, frame_stride, row_stride, n, rx, ry, rw, rh, focus,
                      brightness);
 }
+
+// ---------------------------------------------------------------------------------------------
+// dmz_blur_card (dmz.cpp:499-515): cv::medianBlur(25) in place on the boxes of the leading digits
+// of the result image -- a one-shot step per finished session, batched over cards.  One workgroup per
+// card walks its boxes in digit order (a box sees what the previous boxes left); per box the ROI is
+// copied to LDS (BORDER_REPLICATE at the ROI edge) and every output is the exact median of its
+// 25 x 25 window, found by bisection on the value (8 counting passes).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int BLUR_MAX_W = 64, BLUR_MAX_H = 58, BLUR_K = 25;
+
+__global__ __launch_bounds__(256) void k_blur_cards(uint8_t *__restrict__ rgb, size_t card_stride, int channels, int n,
+                                                    const dmz_hip_session_result *__restrict__ sessions,
+                                                    int unblur_digits) {
+  const int card = blockIdx.x, tid = threadIdx.x;
+  if (card >= n || unblur_digits < 0) return;
+  __shared__ unsigned char roi[BLUR_MAX_W * BLUR_MAX_H * 4];
+  uint8_t *img = rgb + (size_t)card * card_stride;
+  const dmz_hip_session_result *ss = sessions + card;
+  const int n_offsets = ss->n_offsets, blur_count = n_offsets - unblur_digits;
+  const int stride = DMZ_CARD_WIDTH * channels;
+  for (int i = 0; i < n_offsets && i < blur_count && i < 16; i++) {
+    int x = (int)ss->offsets[i] - 1, y = ss->vseg_y_offset - 1;
+    int w = (int)(ss->number_width + 2), h = 27 + 2;
+    if (i < 4) h *= 2;
+    int x1 = x + w, y1 = y + h;
+    x = x < 0 ? 0 : x;
+    y = y < 0 ? 0 : y;
+    x1 = x1 > DMZ_CARD_WIDTH ? DMZ_CARD_WIDTH : x1;
+    y1 = y1 > DMZ_CARD_HEIGHT ? DMZ_CARD_HEIGHT : y1;
+    w = x1 - x;
+    h = y1 - y;
+    if (w <= 0 || h <= 0) continue;
+    if (w > BLUR_MAX_W) w = BLUR_MAX_W;  // number_width beyond any real segmentation (validated by the host)
+    const int rowb = w * channels;
+    for (int k = tid; k < rowb * h; k += 256) {
+      const int yy = k / rowb, b = k - yy * rowb;
+      roi[k] = img[(size_t)(y + yy) * stride + (size_t)x * channels + b];
+    }
+    __syncthreads();
+    const int r = BLUR_K / 2, t = BLUR_K * BLUR_K / 2;
+    for (int k = tid; k < rowb * h; k += 256) {
+      const int yy = k / rowb, b = k - yy * rowb, xx = b / channels, c = b - xx * channels;
+      int lo = 0, hi = 255;  // smallest v with count(<= v) > t
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int cnt = 0;
+        for (int dy = -r; dy <= r; dy++) {
+          int sy = yy + dy;
+          sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy);
+          const unsigned char *row = roi + sy * rowb + c;
+          for (int dx = -r; dx <= r; dx++) {
+            int sx = xx + dx;
+            sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);
+            cnt += row[sx * channels] <= mid ? 1 : 0;
+          }
+        }
+        if (cnt > t) hi = mid;
+        else lo = mid + 1;
+      }
+      img[(size_t)(y + yy) * stride + (size_t)x * channels + b] = (unsigned char)lo;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void dmz_launch_blur_cards(hipStream_t s, uint8_t *rgb, size_t card_stride, int channels, int n,
+                           const dmz_hip_session_result *sessions, int unblur_digits) {
+  hipLaunchKernelGGL(k_blur_cards, dim3((unsigned)n), dim3(256), 0, s, rgb, card_stride, channels, n, sessions,
+                     unblur_digits);
+}

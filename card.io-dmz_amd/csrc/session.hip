@@ -332,6 +332,7 @@ __global__ __launch_bounds__(64) void k_scan_sessions(const dmz_hip_frame_result
         r.vseg_y_offset = fr->vseg_y_offset;
         r.n_offsets = fr->n_offsets;
         for (int i = 0; i < 16; i++) r.offsets[i] = fr->offsets[i];
+        r.number_width = fr->number_width;
       }
     }
     r.expiry_month = complete ? res_em : em;

@@ -217,6 +217,9 @@ void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_e
 void scanner_result(ScannerState *state, ScannerResult *result);
 void scanner_destroy(ScannerState *state);
 
+// dmz.h:101, dmz.cpp:499-515 (8-bit, 3 or 4 channels, 428 x 270)
+void dmz_blur_card(IplImage *cardImageRGB, ScannerState *state, int unblurDigits);
+
 // the cross-frame half of scan/expiry_categorize.cpp (:162-330), exported for the host-logic tests
 void expiry_aggregate_grouped_rects(GroupedRectsList &aggregated_groups, GroupedRectsList &new_groups);
 void get_stable_expiry_month_and_year(GroupedRects &group, int *expiry_month, int *expiry_year);

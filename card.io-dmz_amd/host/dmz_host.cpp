@@ -669,6 +669,32 @@ void scanner_result(ScannerState *state, ScannerResult *result) {
 
 void scanner_destroy(ScannerState *state) { (void)state; }
 
+// ---- dmz_blur_card (dmz.cpp:499-515) -----------------------------------------------------
+void dmz_blur_card(IplImage *cardImageRGB, ScannerState *state, int unblurDigits) {
+  dmz_hip_context *ctx = hip_of(state ? state->dmz : NULL);
+  if (!ctx || !cardImageRGB || !state || unblurDigits < 0) return;
+  if (cardImageRGB->width != kCreditCardTargetWidth || cardImageRGB->height != kCreditCardTargetHeight ||
+      (cardImageRGB->nChannels != 3 && cardImageRGB->nChannels != 4))
+    return;
+  const int ch = cardImageRGB->nChannels;
+  dmz_hip_session_result s;
+  memset(&s, 0, sizeof(s));
+  s.n_offsets = state->mostRecentUsableHSeg.n_offsets;
+  memcpy(s.offsets, state->mostRecentUsableHSeg.offsets, sizeof(s.offsets));
+  s.number_width = state->mostRecentUsableHSeg.number_width;
+  s.vseg_y_offset = state->mostRecentUsableVSeg.y_offset;
+  bool owned;
+  uint8_t *p = packed_rows(cardImageRGB, ch, &owned);
+  if (!owned) {
+    if (dmz_hip_blur_cards_batch(ctx, p, (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight * ch, ch, 1, &s, unblurDigits) != DMZ_HIP_OK)
+      fprintf(stderr, "dmz (HIP): blur failed: %s\n", dmz_hip_last_error(ctx));
+  } else {
+    if (dmz_hip_blur_cards_batch(ctx, p, (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight * ch, ch, 1, &s, unblurDigits) == DMZ_HIP_OK)
+      unpack_rows(cardImageRGB, ch, p);
+    free(p);
+  }
+}
+
 // ---- flat-array hook for the host-logic tests (tests/test_host_logic.py): replays a session's
 // expiry_extract calls (expiry_categorize.cpp:332-376) on caller-supplied per-frame groups ----
 extern "C" int dmz_hip_host_expiry_session_replay(int n_frames, const int *groups_per_frame, const int16_t *tops,

@@ -206,7 +206,8 @@ typedef struct dmz_hip_session_result {
   int32_t n_expiry_groups; /* ScannerState.expiry_groups.size() */
   int32_t vseg_y_offset, n_offsets; /* ScannerResult.vseg / hseg of the accepted number */
   uint16_t offsets[16];
-  int32_t reserved[7];
+  float number_width;      /* NHorizontalSegmentation.number_width of the accepted number */
+  int32_t reserved[6];
 } dmz_hip_session_result;  /* 128 bytes */
 
 /* Replays, for n_sessions sessions of frames_per_session consecutive per-frame records each
@@ -225,6 +226,14 @@ int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result
                                 int frames_per_session, int scan_expiry, int frame_interval_ms,
                                 int now_year, int now_month, int allow_past_expiry,
                                 dmz_hip_session_result *out);
+
+/* dmz_blur_card (dmz.h:101, dmz.cpp:499-515) on n result images (428 x 270, `channels` = 3 or 4 interleaved
+ * bytes per pixel, card i at rgb + i*card_stride, rows tightly packed), in place: the boxes of the first
+ * n_offsets - unblur_digits digits of sessions[i] (offsets, number_width, vseg_y_offset as
+ * dmz_hip_scan_sessions_batch reports them, = ScannerState.mostRecentUsableHSeg/VSeg) are median-blurred
+ * with a 25 x 25 window.  unblur_digits < 0: nothing happens, as in the reference. */
+int dmz_hip_blur_cards_batch(dmz_hip_context *ctx, uint8_t *rgb, size_t card_stride, int channels, int n,
+                             const dmz_hip_session_result *sessions, int unblur_digits);
 
 /* Single homography, llcv_calc_persp_transform (cv/warp.h:25, warp.cpp:34-125),
  * computed on the device with the same kernel code the batch path uses.

@@ -207,6 +207,10 @@ void orc_scoring_roi(int img_w, int img_h, int use_full_image, int rect[4]);    
 float orc_focus_score(const uint8_t *img, int stride, int w, int h, int use_full_image);       /* dmz.cpp:114-126,187-192 */
 float orc_brightness_score(const uint8_t *img, int stride, int w, int h, int use_full_image);  /* dmz.cpp:128-135,194-199 */
 
+/* dmz.cpp:499-515: median-blur (25 x 25, per channel) the boxes of the first n_offsets - unblur_digits digits, in place */
+void orc_blur_card(uint8_t *rgb, int width, int height, int channels, const uint16_t *offsets, int n_offsets,
+                   float number_width, int y_offset, int unblur_digits);
+
 /* ---- per-session policy (scan/scan.cpp:41-194 + expiry_categorize.cpp:162-376) replayed over the
  * per-frame records of one session; layout == dmz_hip_session_result (include/dmz_hip.h) ---- */
 typedef struct {
@@ -222,7 +226,8 @@ typedef struct {
   int32_t n_expiry_groups; /* aggregated expiry groups alive when the replay stopped */
   int32_t vseg_y_offset, n_offsets;
   uint16_t offsets[16];
-  int32_t reserved[7];
+  float number_width;      /* NHorizontalSegmentation.number_width of the accepted number */
+  int32_t reserved[6];
 } orc_session_result;      /* 128 bytes */
 void orc_scan_session(const orc_frame_result *frames, const orc_expiry_result *expiry /* or NULL */,
                       int n_frames, int scan_expiry, int frame_interval_ms, int now_year, int now_month,

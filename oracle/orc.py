@@ -182,6 +182,15 @@ class Oracle:
                                   channels, _p(out, _u8p))
         return out
 
+    def blur_card(self, rgb, offsets, n_offsets, number_width, y_offset, unblur_digits):
+        out = np.ascontiguousarray(rgb, np.uint8).copy()
+        offs = np.ascontiguousarray(offsets, np.uint16)
+        self.lib.orc_blur_card.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                           C.c_int, C.c_int]
+        self.lib.orc_blur_card(out.ctypes.data, out.shape[1], out.shape[0], out.shape[2], offs.ctypes.data,
+                               int(n_offsets), float(number_width), int(y_offset), int(unblur_digits))
+        return out
+
     def scoring_roi(self, w, h, use_full):
         rc = np.zeros(4, np.int32)
         self.lib.orc_scoring_roi(w, h, int(use_full), _p(rc, _i32p))
@@ -405,7 +414,7 @@ SESSION_DTYPE = np.dtype([
     ("complete", "<i4"), ("complete_frame", "<i4"), ("number_frame", "<i4"), ("n_numbers", "<i4"),
     ("predictions", "u1", (16,)), ("card_type", "<i4"), ("expiry_month", "<i4"), ("expiry_year", "<i4"),
     ("count15", "<i4"), ("count16", "<i4"), ("usable_frames", "<i4"), ("n_expiry_groups", "<i4"),
-    ("vseg_y_offset", "<i4"), ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("reserved", "<i4", (7,)),
+    ("vseg_y_offset", "<i4"), ("n_offsets", "<i4"), ("offsets", "<u2", (16,)), ("number_width", "<f4"), ("reserved", "<i4", (6,)),
 ])
 assert SESSION_DTYPE.itemsize == 128
 

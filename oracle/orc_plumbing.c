@@ -108,3 +108,57 @@ float orc_brightness_score(const uint8_t *img, int stride, int w, int h, int use
     for (int c = 0; c < rc[2]; c++) s += img[(size_t)(rc[1] + r) * stride + rc[0] + c];
   return (float)(s * (1. / ((double)rc[2] * rc[3])));
 }
+
+/* ---- dmz_blur_card (dmz.cpp:499-515): cv::medianBlur(25) in place on the boxes of the leading digits of
+ * the RGB result image.  cv::medianBlur on a Mat made from the IplImage ROI works on a copy of the ROI padded
+ * by BORDER_REPLICATE (the ROI edge, not the surrounding image) and writes the exact per-channel median of
+ * the 25 x 25 window; the boxes are processed in digit order, each on the image the previous ones left. ---- */
+#include <stdlib.h>
+#include <string.h>
+
+static void median_blur_roi(uint8_t *img, int stride, int ch, int x, int y, int w, int h, int ksize) {
+  const int r = ksize / 2, t = ksize * ksize / 2;
+  uint8_t *copy = (uint8_t *)malloc((size_t)w * h * ch);
+  for (int yy = 0; yy < h; yy++) memcpy(copy + (size_t)yy * w * ch, img + (size_t)(y + yy) * stride + (size_t)x * ch, (size_t)w * ch);
+  for (int yy = 0; yy < h; yy++)
+    for (int xx = 0; xx < w; xx++)
+      for (int c = 0; c < ch; c++) {
+        int hist[256];
+        memset(hist, 0, sizeof(hist));
+        for (int dy = -r; dy <= r; dy++) {
+          int sy = yy + dy;
+          sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy);
+          for (int dx = -r; dx <= r; dx++) {
+            int sx = xx + dx;
+            sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);
+            hist[copy[((size_t)sy * w + sx) * ch + c]]++;
+          }
+        }
+        int acc = 0, v = 0;
+        for (; v < 256; v++) {
+          acc += hist[v];
+          if (acc > t) break;
+        }
+        img[(size_t)(y + yy) * stride + (size_t)(x + xx) * ch + c] = (uint8_t)v;
+      }
+  free(copy);
+}
+
+void orc_blur_card(uint8_t *rgb, int width, int height, int channels, const uint16_t *offsets, int n_offsets,
+                   float number_width, int y_offset, int unblur_digits) {
+  if (unblur_digits < 0) return;
+  const int blur_count = n_offsets - unblur_digits;
+  for (int i = 0; i < n_offsets && i < blur_count; i++) {
+    int x = offsets[i] - 1, y = y_offset - 1;
+    int w = (int)(number_width + 2), h = ORC_NUM_H + 2;  /* int num_w = hseg.number_width + 2 (float sum, truncated) */
+    if (i < 4) h *= 2;
+    /* cvSetImageROI clips the rectangle to the image */
+    int x1 = x + w, y1 = y + h;
+    if (x < 0) x = 0;
+    if (y < 0) y = 0;
+    if (x1 > width) x1 = width;
+    if (y1 > height) y1 = height;
+    if (x1 <= x || y1 <= y) continue;
+    median_blur_roi(rgb, width * channels, channels, x, y, x1 - x, y1 - y, 25);
+  }
+}

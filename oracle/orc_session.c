@@ -239,6 +239,7 @@ void orc_scan_session(const orc_frame_result *frames, const orc_expiry_result *e
         res.vseg_y_offset = recent->vseg_y_offset;
         res.n_offsets = recent->n_offsets;
         memcpy(res.offsets, recent->offsets, sizeof(res.offsets));
+        res.number_width = recent->number_width;
         float(*agg)[10];
         if (count15 > count16) res.n_numbers = 15, agg = agg15;
         else res.n_numbers = 16, agg = agg16;

@@ -251,14 +251,15 @@ struct RefSessionOut {
   int32_t card_type, expiry_month, expiry_year, count15, count16, usable_frames, n_expiry_groups;
   int32_t vseg_y_offset, n_offsets;
   uint16_t offsets[16];
-  int32_t reserved[7];
+  float number_width;
+  int32_t reserved[6];
 };
 
 REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
                               const uint8_t *expiry /* n x 1592-byte records or NULL */, int n_frames,
                               int scan_expiry, RefSessionOut *out) {
   // field offsets of orc_frame_result / orc_expiry_result (oracle/dmz_oracle.h)
-  enum { F_FLAGS = 84, F_YOFF = 92, F_NOFF = 100, F_OFFS = 104, F_SCORES = 168 };
+  enum { F_FLAGS = 84, F_YOFF = 92, F_NOFF = 100, F_OFFS = 104, F_NWIDTH = 140, F_SCORES = 168 };
   enum { X_NGROUPS = 0, X_CATEG = 48, X_GROUPS = 56, G_SIZE = 192, G_TOP = 0, G_LEFT = 2, G_CTOP = 8, G_CLEFT = 18, G_SCORES = 32 };
   ScannerState state;
   scanner_initialize(&state);
@@ -325,6 +326,7 @@ REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
         memset(&hs, 0, sizeof(hs));
         hs.n_offsets = (uint8_t)noff;
         memcpy(hs.offsets, fr + F_OFFS, 32);
+        memcpy(&hs.number_width, fr + F_NWIDTH, 4);
         NVerticalSegmentation vs;
         memset(&vs, 0, sizeof(vs));
         vs.y_offset = (uint16_t)yoff;
@@ -360,6 +362,7 @@ REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
       out->vseg_y_offset = res.vseg.y_offset;
       out->n_offsets = res.hseg.n_offsets;
       memcpy(out->offsets, res.hseg.offsets, 32);
+      out->number_width = res.hseg.number_width;
       break;
     }
   }
@@ -372,6 +375,7 @@ REF_API void ref_scan_session(const uint8_t *frames /* n x 1024-byte records */,
       out->vseg_y_offset = s.vseg.y_offset;
       out->n_offsets = s.hseg.n_offsets;
       memcpy(out->offsets, s.hseg.offsets, 32);
+      out->number_width = s.hseg.number_width;
     }
     out->expiry_month = state.expiry_month;
     out->expiry_year = state.expiry_year;

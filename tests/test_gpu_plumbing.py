@@ -115,3 +115,32 @@ def test_focus_and_brightness_scores(ctx, pkg, oracle):
         for i in range(3):
             assert focus[i].view(np.uint32) == oracle.focus_score(img[i]).view(np.uint32), (w, h, i)
         d.free()
+
+
+def test_blur_cards(ctx, pkg, oracle):
+    """dmz_blur_card: 25 x 25 median of the leading digit boxes, in place, in digit order; byte-exact"""
+    rng = np.random.default_rng(13)
+    n = 5
+    rgb = rng.integers(0, 256, (n, 270, 428, 3)).astype(np.uint8)
+    rgb[1] = (np.indices((270, 428)).sum(0)[..., None] % 251).astype(np.uint8)  # smooth ramps
+    sess = np.zeros(n, pkg.SESSION_DTYPE)
+    cases = [(16, 17.9, 150, 4), (15, 19.2, 241, 0), (16, 18.0, 0, 12), (16, 17.0, 130, 16), (16, 20.5, 200, 4)]
+    for i, (no, nw, yo, _) in enumerate(cases):
+        sess[i]["n_offsets"] = no
+        sess[i]["offsets"][:no] = 30 + 19 * np.arange(no) + i
+        sess[i]["number_width"] = np.float32(nw)
+        sess[i]["vseg_y_offset"] = yo
+    sess[4]["offsets"][0] = 0      # box clipped at the left edge
+    sess[4]["offsets"][15] = 420   # and at the right edge (only reached with unblur 0)
+    for unblur in (4, 0, -1):
+        got = rgb.copy()
+        ctx.blur_cards(got, n, sess, unblur)
+        for i in range(n):
+            want = oracle.blur_card(rgb[i], sess[i]["offsets"], sess[i]["n_offsets"], sess[i]["number_width"],
+                                    sess[i]["vseg_y_offset"], unblur)
+            assert np.array_equal(got[i], want), (i, unblur)
+    # RGBA
+    rgba = rng.integers(0, 256, (1, 270, 428, 4)).astype(np.uint8)
+    got = rgba.copy()
+    ctx.blur_cards(got, 1, sess[:1], 4, channels=4)
+    assert np.array_equal(got[0], oracle.blur_card(rgba[0], sess[0]["offsets"], 16, sess[0]["number_width"], 150, 4))

@@ -159,6 +159,7 @@ def _synthetic_session(rng, orc, n_frames, digits, month_year, p_usable=0.8, noi
         nn = n if rng.random() > alt_len_rate else (31 - n)  # sometimes the other pattern length
         fr[f]["n_offsets"] = nn
         fr[f]["offsets"][:nn] = 40 + 18 * np.arange(nn) + int(rng.integers(0, 3))
+        fr[f]["number_width"] = np.float32(17.0 + rng.random())
         s = (rng.random((16, 10)) * noise).astype(np.float32)
         for i in range(min(nn, n)):
             s[i, digits[i] if rng.random() < 0.93 else int(rng.integers(0, 10))] += 1.0
