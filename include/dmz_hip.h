@@ -231,7 +231,8 @@ int dmz_hip_scan_sessions_batch(dmz_hip_context *ctx, const dmz_hip_frame_result
  * bytes per pixel, card i at rgb + i*card_stride, rows tightly packed), in place: the boxes of the first
  * n_offsets - unblur_digits digits of sessions[i] (offsets, number_width, vseg_y_offset as
  * dmz_hip_scan_sessions_batch reports them, = ScannerState.mostRecentUsableHSeg/VSeg) are median-blurred
- * with a 25 x 25 window.  unblur_digits < 0: nothing happens, as in the reference. */
+ * with a 25 x 25 window.  unblur_digits < 0: nothing happens, as in the reference.  Boxes wider than 64
+ * pixels (number_width > 62; real segmentations are <= 24) are cut to 64. */
 int dmz_hip_blur_cards_batch(dmz_hip_context *ctx, uint8_t *rgb, size_t card_stride, int channels, int n,
                              const dmz_hip_session_result *sessions, int unblur_digits);
 
