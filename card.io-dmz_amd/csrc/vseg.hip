@@ -162,7 +162,23 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
                                               int lane) {
   const int ii = lane & 15, kk = lane >> 4;
   const int ntiles = (nrows + 15) >> 4;
-  for (int mt = 0; mt < ntiles; mt += 2) {
+  // D layout: column (hidden unit) = lane & 15, row = 4 * (lane >> 4) + v
+  auto finish_tile = [&](const f32x4 &acc, int tile) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float hv = fast_tanh(acc[v] + b1);  // units >= 50 have zero logistic weights
+      // sum over the 16 hidden units of this wave (one DPP row)
+      const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
+      const int row = tile * 16 + 4 * kk + v;
+      if (ii == 15 && row < nrows) {
+        float *p = part + (wave * 80 + row) * 4;
+        p[0] = o0; p[1] = o1; p[2] = o2;
+      }
+    }
+  };
+  int mt = 0;
+  // tiles two at a time (two independent accumulator chains) ...
+  for (; mt + 1 < ntiles; mt += 2) {
     const int r0 = imin(mt * 16 + ii, nrows - 1), r1 = imin(mt * 16 + 16 + ii, nrows - 1);
     const uint32_t *a0p = (const uint32_t *)(grad + r0 * VS_GSTRIDE + 4 * kk);
     const uint32_t *a1p = (const uint32_t *)(grad + r1 * VS_GSTRIDE + 4 * kk);
@@ -181,22 +197,24 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), bw[u].w, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 3, fs1, fb1), bw[u].w, acc1, 0, 0, 0);
     }
-    // D layout: column (hidden unit) = lane & 15, row = 4 * (lane >> 4) + v
+    finish_tile(acc0, mt);
+    finish_tile(acc1, mt + 1);
+  }
+  // ... and an odd last tile on its own instead of paired with a copy of itself
+  if (mt < ntiles) {
+    const int r0 = imin(mt * 16 + ii, nrows - 1);
+    const uint32_t *a0p = (const uint32_t *)(grad + r0 * VS_GSTRIDE + 4 * kk);
+    const float fs0 = norm[2 * r0], fb0 = norm[2 * r0 + 1];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const f32x4 acc = t ? acc1 : acc0;
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const float hv = fast_tanh(acc[v] + b1);  // units >= 50 have zero logistic weights
-        // sum over the 16 hidden units of this wave (one DPP row)
-        const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
-        const int row = (mt + t) * 16 + 4 * kk + v;
-        if (ii == 15 && row < nrows) {
-          float *p = part + (wave * 80 + row) * 4;
-          p[0] = o0; p[1] = o1; p[2] = o2;
-        }
-      }
+    for (int u = 0; u < VS_KSTEPS; u++) {
+      const uint32_t g0 = a0p[4 * u];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), bw[u].x, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), bw[u].y, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), bw[u].z, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), bw[u].w, acc0, 0, 0, 0);
     }
+    finish_tile(acc0, mt);
   }
 }
 
