@@ -58,8 +58,8 @@ PMC_TRAFFIC = {
     "vseg": (100604.2 + 3146.3) * 1024 / 4096,
     "hseg": (32576.1 + 256.0) * 1024 / 4096,
     "digits": (24546.8 + 2902.4) * 1024 / 4096,
-    "expiry_seg": (71591.2 + 60866.5 + 7104.1 + 459.7) * 1024 / 4096,  # k_expiry_stripes + k_expiry_seg (r1_v3 passes)
-    "expiry_cat": (5361.5 + 564.6) * 1024 / 4096,
+    "expiry_seg": (80991.8 + 60865.6 + 7104.0 + 459.7) * 1024 / 4096,  # k_expiry_stripes + k_expiry_seg (r1_v3 passes)
+    "expiry_cat": (5369.0 + 564.5) * 1024 / 4096,
 }
 
 
