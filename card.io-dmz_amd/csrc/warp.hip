@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   const int wcols = bx1 + 2 - wx0;   // + the right bilinear tap
   const int wrows = by1 + 2 - wy0;
   const uint8_t *src = planes + (size_t)frame * frame_stride;
-  const bool staged = same_sign && wcols <= LWMAX && wrows <= LH;
+  const bool fastxy = same_sign && wcols <= LWMAX && wrows <= LH;
+  const bool staged = fastxy && DMZ_WARP_ABLATE != 4;
 
   // ---- stage the window: thread (tid & 31) owns one dword column, 8 rows per pass.  For a
   // window that lies inside the image (every card that is inside the frame) the loads are
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
     const double X0 = M0 * x + M1 * y + M2;
     const double Y0 = M3 * x + M4 * y + M5;
     const double W0 = M6 * x + M7 * y + M8;
-    if (staged) {
+    if (fastxy) {
 #pragma unroll
       for (int k = 0; k < 4; k++) P[h][k] = map_pixel<true>(X0, Y0, W0, M0, M3, M6, xq + k);
     } else {
