@@ -38,8 +38,18 @@ def _worker(rank, world, port, q):
         recs[k], _ = o.scan_frame(y, want_card=False)
     local = torch.from_numpy(recs.view(np.uint8).reshape(hi - lo, 1024).copy())
     out = sharding.gather_results(local, world)
+    # the asynchronous gather-to-root bench.py uses: two batches in flight on alternating slots
+    g = sharding.RootGatherer(world)
+    a = g.submit(local, slot=0)
+    second = local.flip(0).contiguous()
+    b = g.submit(second, slot=1)
+    g.wait()
     if rank == 0:
+        assert torch.equal(a, out)
+        assert torch.equal(b, torch.cat([c.flip(0) for c in out.chunk(world, dim=0)]))
         q.put(out.numpy().copy())
+    else:
+        assert a is None and b is None
     dist.barrier()
     dist.destroy_process_group()
 
