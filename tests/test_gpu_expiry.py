@@ -151,3 +151,66 @@ def test_expiry_bad_arguments(ctx, pkg):
         ctx.scan_expiry(card, 0, res, exp)
     with pytest.raises(pkg.DmzHipError):
         ctx.scan_expiry(card, 1, res, None)
+
+
+def _text_card(rng, oracle, seed_idx):
+    """a synthetic card with several lines of random stroke patterns below the number: exercises the
+    multi-group / white-space stripping / regrid / many-candidate branches of the segmentation"""
+    card, _ = oracle.synth_card(SEED, 500 + seed_idx)
+    card = card.copy()
+    y = 185 + int(rng.integers(0, 8))
+    for _ in range(int(rng.integers(1, 4))):
+        if y > 250:
+            break
+        h = int(rng.integers(9, 16))
+        x = int(rng.integers(5, 120))
+        pitch = int(rng.integers(9, 17))
+        nchar = int(rng.integers(3, 26))
+        ink = int(rng.integers(40, 130))
+        for c in range(nchar):
+            if rng.random() < 0.15:
+                x += pitch  # word gap
+            cx = x + c * pitch
+            if cx + 9 >= 428:
+                break
+            kind = rng.integers(0, 4)
+            box = card[y:y + h, cx:cx + 8].astype(np.int32)
+            if kind == 0:    # two vertical strokes
+                box[:, 0:2] -= ink
+                box[:, 6:8] -= ink
+            elif kind == 1:  # slash-like diagonal
+                for r in range(h):
+                    cc = min(7, max(0, 7 - (r * 8) // h))
+                    box[r, max(0, cc - 1):cc + 1] -= ink
+            elif kind == 2:  # box outline
+                box[0:2, :] -= ink
+                box[-2:, :] -= ink
+                box[:, 0:2] -= ink
+                box[:, 6:8] -= ink
+            else:            # single stroke
+                box[:, 3:5] -= ink
+            card[y:y + h, cx:cx + 8] = np.clip(box, 0, 255).astype(np.uint8)
+        y += h + int(rng.integers(3, 14))
+    return card
+
+
+def test_expiry_on_random_text_cards(ctx, pkg, oracle):
+    rng = np.random.default_rng(2718)
+    n = 64
+    cards = np.ascontiguousarray(np.stack([_text_card(rng, oracle, i) for i in range(n)]))
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_cards(cards, n, res)
+    # open the gates on every card so that the segmentation always runs; vary the row it starts from
+    forced = res.copy()
+    forced["flags"] = pkg.FLAG_VSEG_OK | pkg.FLAG_USABLE
+    forced["vseg_y_offset"] = 130 + (np.arange(n) % 40)
+    ctx.scan_expiry(cards, n, forced, exp)
+    found = many = 0
+    for i in range(n):
+        want = oracle.scan_card_expiry(cards[i], forced[i])
+        _compare(pkg, exp[i], want, i)
+        found += int(want["n_found"] > 0)
+        many += int(want["n_found"] > 1)
+    print("random text cards: %d with groups, %d with several" % (found, many))
+    assert found >= 8
