@@ -2,6 +2,7 @@
 OpenCV (parity unpinned by the reference: SURVEY Appendix A) and for the in-tree stages
 that need an OpenCV library symbol to run (Canny, Hough, equalise)."""
 import numpy as np
+import pytest
 
 
 def test_detection_boxes_known_answers(oracle):
@@ -146,3 +147,41 @@ def test_plumbing_hand_checked(oracle):
     assert rgb[0, 3].tolist() == [75, 255, 28]
     rgba = oracle.ycbcr_to_rgb(y, cb, cr, channels=4)
     assert np.array_equal(rgba[..., :3], rgb) and (rgba[..., 3] == 255).all()
+
+
+def test_blur_card_median_against_pillow(oracle):
+    """orc_blur_card's box = exact 25 x 25 per-channel median with replicated borders at the ROI edge:
+    corroborated by an independent implementation (Pillow's RankFilter pads by edge replication)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageFilter
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (270, 428, 3)).astype(np.uint8)
+    # one box covering x 0..427, y 0..57 (the first digit's box is two number heights tall)
+    out = oracle.blur_card(img, [1], 1, 426.0, 1, 0)
+    for c in range(3):
+        want = np.asarray(Image.fromarray(img[:58, :, c]).filter(ImageFilter.MedianFilter(25)))
+        assert np.array_equal(out[:58, :, c], want), c
+    assert np.array_equal(out[58:], img[58:])
+
+
+def test_sobel7_and_morph_gradient_against_scipy(oracle):
+    """independent corroboration of two restated OpenCV semantics: the 7-tap
+    separable Sobel with BORDER_REPLICATE and the 3x3-cross morphological gradient"""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(22)
+    img = rng.integers(0, 256, (46, 97)).astype(np.uint8)
+    deriv = np.array([-1, -4, -5, 0, 5, 4, 1], np.int64)
+    smooth = np.array([1, 6, 15, 20, 15, 6, 1], np.int64)
+    a = img.astype(np.int64)
+    dx = ndi.correlate1d(ndi.correlate1d(a, deriv, axis=1, mode="nearest"), smooth, axis=0, mode="nearest")
+    dy = ndi.correlate1d(ndi.correlate1d(a, smooth, axis=1, mode="nearest"), deriv, axis=0, mode="nearest")
+    assert np.array_equal(oracle.sobel7(img, True), np.clip(dx, -32768, 32767).astype(np.int16))
+    assert np.array_equal(oracle.sobel7(img, False), np.clip(dy, -32768, 32767).astype(np.int16))
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+    grad = ndi.grey_dilation(img, footprint=cross, mode="nearest").astype(np.int32) - \
+        ndi.grey_erosion(img, footprint=cross, mode="nearest").astype(np.int32)
+    got = np.zeros_like(img)
+    import ctypes as C
+    oracle.lib.orc_morph_grad3_2d_cross(img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[1], img.shape[0],
+                                        got.ctypes.data_as(C.c_void_p), img.shape[1])
+    assert np.array_equal(got, grad.astype(np.uint8))
