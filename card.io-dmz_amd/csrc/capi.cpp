@@ -723,12 +723,6 @@ int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t
                        card_stride, results, expiry, true);
 }
 
-// stage `bytes` of a host buffer into `buf` (or pass a device pointer through); out buffers likewise
-static int plumbing_io(dmz_hip_context *ctx, const void *in, size_t in_bytes, dmz_hip_context::Buf &in_buf,
-                       const void **din) {
-  return stage_in(ctx, in_buf, in, in_bytes, din);
-}
-
 int dmz_hip_deinterleave_c2(dmz_hip_context *ctx, const uint8_t *interleaved, size_t n_pairs, uint8_t *channel1,
                             uint8_t *channel2) {
   if (!ctx) return DMZ_HIP_EINVAL;
@@ -736,7 +730,7 @@ int dmz_hip_deinterleave_c2(dmz_hip_context *ctx, const uint8_t *interleaved, si
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
   const void *din = nullptr;
-  if ((rc = plumbing_io(ctx, interleaved, n_pairs * 2, ctx->stage_in, &din))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, interleaved, n_pairs * 2, &din))) return rc;
   const bool dev1 = is_device_ptr(channel1), dev2 = is_device_ptr(channel2);
   uint8_t *d1 = channel1, *d2 = channel2;
   if (!dev1 || !dev2) {
@@ -760,7 +754,7 @@ int dmz_hip_deinterleave_rgba_to_r(dmz_hip_context *ctx, const uint8_t *source, 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
   const void *din = nullptr;
-  if ((rc = plumbing_io(ctx, source, size * 4, ctx->stage_in, &din))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, source, size * 4, &din))) return rc;
   const bool dev = is_device_ptr(dest);
   uint8_t *dd = dest;
   if (!dev) {
@@ -786,9 +780,9 @@ int dmz_hip_ycbcr_to_rgb(dmz_hip_context *ctx, const uint8_t *y, const uint8_t *
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
   const void *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
-  if ((rc = plumbing_io(ctx, y, n_pixels, ctx->stage_in, &dy))) return rc;
-  if ((rc = plumbing_io(ctx, cb, n_pixels, ctx->stage_cb, &dcb))) return rc;
-  if ((rc = plumbing_io(ctx, cr, n_pixels, ctx->stage_cr, &dcr))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, n_pixels, &dy))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_cb, cb, n_pixels, &dcb))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_cr, cr, n_pixels, &dcr))) return rc;
   const bool dev = is_device_ptr(rgb);
   uint8_t *dd = rgb;
   if (!dev) {

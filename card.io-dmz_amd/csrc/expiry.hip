@@ -402,9 +402,14 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
     if (m == 0u) break;
     const int pl = 511 - (int)(m & 511u);
     if (lane == 0) L.u.a.colA[pl] = (int)(m >> 9);
-#pragma unroll
-    for (int j = 0; j < 7; j++)
-      if (iabs(lane + 64 * j - pl) < SCW) key[j] = 0u;  // either end would hit the mask
+    // either end of a rect within 8 columns of the pick would hit the mask
+    key[0] = iabs(lane - pl) < SCW ? 0u : key[0];
+    key[1] = iabs(lane + 64 - pl) < SCW ? 0u : key[1];
+    key[2] = iabs(lane + 128 - pl) < SCW ? 0u : key[2];
+    key[3] = iabs(lane + 192 - pl) < SCW ? 0u : key[3];
+    key[4] = iabs(lane + 256 - pl) < SCW ? 0u : key[4];
+    key[5] = iabs(lane + 320 - pl) < SCW ? 0u : key[5];
+    key[6] = iabs(lane + 384 - pl) < SCW ? 0u : key[6];
   }
   __syncthreads();
   XSEG_STOP(4, L.u.a.colA[lane])
