@@ -38,7 +38,9 @@ ALGO = {
     #            bytes/frame                flop/frame
     "detect":   (307200 + 64,               2 * 2.2e6 + 1.2e6),
     "geometry": (64 + 152 + 80,             2.0e3),
-    "warp":     (115560,                    1.2e6 + 0.9e6),
+    # the card quad covers ~427 x 269 source pixels (guide frame at ~1:1 scale): every one is read once,
+    # every card pixel written once
+    "warp":     (114863 + 115560,           1.2e6 + 0.9e6),
     "vseg":     (103 * 408 + 24,            2 * 103 * (204 * 50 + 150)),
     "hseg":     (27 * 428 + 48,             2.0e5),
     "digits":   (16 * 27 * 19 + 744,        16 * 3 * 2 * (8 * 360 * 9 + 320 * 32 + 320)),
