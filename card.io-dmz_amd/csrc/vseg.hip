@@ -63,6 +63,7 @@ __device__ __forceinline__ float row16_sum(float x) {
 constexpr int VS_THREADS = 256;
 constexpr int VS_WAVES = 4;
 constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
+constexpr int VS_PROWS = 68;     // rows of the per-wave partial-sum table
 constexpr int VS_GSTRIDE = 208;  // gradient row stride in bytes (13 x 16 k-values, zero tail)
 constexpr int VS_KSTEPS = 13;    // 13 x 16 = 208 >= 204
 constexpr int VS_RIF = 6;        // rows in flight per wave while loading
@@ -128,7 +129,7 @@ __device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned cha
 
 // wave `wave` prepares rows wave, wave+4, ... of the list row_y[0..nrows)
 __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ card,
-                                                  const int *__restrict__ row_y, int nrows,
+                                                  const unsigned short *__restrict__ row_y, int nrows,
                                                   unsigned char *__restrict__ grad,
                                                   float *__restrict__ norm, int wave, int lane) {
   for (int i0 = wave; i0 < nrows; i0 += VS_WAVES * VS_RIF) {
@@ -158,7 +159,7 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
                                               float w21, float w22,
                                               const unsigned char *__restrict__ grad,
                                               const float *__restrict__ norm, int nrows,
-                                              float *__restrict__ part /* [4][80][4] */, int wave,
+                                              float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
                                               int lane) {
   const int ii = lane & 15, kk = lane >> 4;
   const int ntiles = (nrows + 15) >> 4;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
       const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
       const int row = tile * 16 + 4 * kk + v;
       if (ii == 15 && row < nrows) {
-        float *p = part + (wave * 80 + row) * 4;
+        float *p = part + (wave * VS_PROWS + row) * 3;
         p[0] = o0; p[1] = o1; p[2] = o2;
       }
     }
@@ -261,15 +262,15 @@ __device__ void vseg_best_segmentation(const float *__restrict__ vis, const floa
 // logistic bias + softmax of the rows just evaluated (modelm_befe75da.cpp:1781-1784)
 __device__ __forceinline__ void vseg_finish_rows(const float *__restrict__ wts,
                                                  const float *__restrict__ part,
-                                                 const int *__restrict__ row_y, int nrows,
+                                                 const unsigned short *__restrict__ row_y, int nrows,
                                                  float *__restrict__ vis, float *__restrict__ amx,
                                                  int tid) {
   if (tid < nrows) {
     float o[3];
 #pragma unroll
     for (int c = 0; c < 3; c++)
-      o[c] = ((part[(0 * 80 + tid) * 4 + c] + part[(1 * 80 + tid) * 4 + c]) +
-              (part[(2 * 80 + tid) * 4 + c] + part[(3 * 80 + tid) * 4 + c])) + wts[dmzw::VSEG_B2 + c];
+      o[c] = ((part[(0 * VS_PROWS + tid) * 3 + c] + part[(1 * VS_PROWS + tid) * 3 + c]) +
+              (part[(2 * VS_PROWS + tid) * 3 + c] + part[(3 * VS_PROWS + tid) * 3 + c])) + wts[dmzw::VSEG_B2 + c];
     const float e0 = expf(o[0]), e1 = expf(o[1]), e2 = expf(o[2]);
     const float sum = e0 + (e1 + e2);  // Eigen 3-element redux tree
     const int y = row_y[tid];
@@ -299,15 +300,15 @@ __device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts,
   w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
 }
 
-__global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict__ wts,
+__global__ __launch_bounds__(VS_THREADS, 7) void k_vseg(const float *__restrict__ wts,
                                                       const uint8_t *__restrict__ cards,
                                                       size_t card_stride, int n, int only_warped,
                                                       dmz_hip_frame_result *__restrict__ results) {
   __shared__ __attribute__((aligned(16))) unsigned char grad[VS_MAXROWS * VS_GSTRIDE];  // 14,144 B
   __shared__ float norm[2 * VS_MAXROWS];
-  __shared__ float part[4 * 80 * 4];  // 5,120 B
+  __shared__ float part[4 * VS_PROWS * 3];  // 3,264 B
   __shared__ float vis[288], amx[288];
-  __shared__ int row_y[VS_MAXROWS];
+  __shared__ unsigned short row_y[VS_MAXROWS];
   __shared__ int s_int[4];
 
   const int f = blockIdx.x;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict_
 
   for (int i = tid; i < 288; i += VS_THREADS) { vis[i] = 0.0f; amx[i] = 0.0f; }
   // coarse pass: rows 0, 4, ..., 268 (n_vseg.cpp:116-125)
-  for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = 4 * i;
+  for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = (unsigned short)(4 * i);
   __syncthreads();
   vseg_prepare_rows(card, row_y, VS_MAXROWS, grad, norm, wave, lane);
   VsegWeights w;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(VS_THREADS, 4) void k_vseg(const float *__restrict_
     const int ymax = imin(270, y_off + 27 + 8);
     int cnt = 0;
     for (int y = ymin; y < ymax; y++)
-      if (vis[y] == 0.0f && amx[y] == 0.0f) row_y[cnt++] = y;
+      if (vis[y] == 0.0f && amx[y] == 0.0f) row_y[cnt++] = (unsigned short)y;
     s_int[0] = cnt;
   }
   __syncthreads();
