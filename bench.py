@@ -226,7 +226,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 images / int32 votes / f32 scores (f64 warp coordinates)",
+            "dtype": "u8 (int32 accumulators; f32 model scores; f64 warp coordinates)",
             "data": "synthetic",
             "config": {
                 "workload": "full pipeline detect->warp->vseg->hseg->digits->expiry (BASELINE configs[3]), "
