@@ -562,7 +562,9 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
 #pragma unroll
           for (int j = 0; j < 18; j++) mx = imax(mx, L.cmax[sl * 21 + j]);
         }
-        const float scale = mx > 0 ? (float)(255.0 / (double)mx) : 0.0f;
+        // cvNormalize's scale is (float)(255.0 / (double)max); for every integer max in [1, 32767] that
+        // equals the correctly rounded float quotient (checked exhaustively, tests/test_oracle_units.py)
+        const float scale = mx > 0 ? 255.0f / (float)mx : 0.0f;
         int cs = 0;
         if (sl < 3) {
 #pragma unroll

@@ -185,3 +185,12 @@ def test_sobel7_and_morph_gradient_against_scipy(oracle):
     oracle.lib.orc_morph_grad3_2d_cross(img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[1], img.shape[0],
                                         got.ctypes.data_as(C.c_void_p), img.shape[1])
     assert np.array_equal(got, grad.astype(np.uint8))
+
+
+def test_normalize_scale_float_division_is_exact():
+    """expiry.hip computes cvNormalize's (float)(255.0 / (double)max) as a float division: the two agree for
+    every possible maximum of an int16 image"""
+    mx = np.arange(1, 32768)
+    a = (255.0 / mx.astype(np.float64)).astype(np.float32)
+    b = np.float32(255.0) / mx.astype(np.float32)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
