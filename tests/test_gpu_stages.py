@@ -198,3 +198,52 @@ def test_detect_other_frame_geometries(ctx, pkg, oracle):
         assert np.array_equal(res[0]["theta"][m].view(np.uint32), want["theta"][m].view(np.uint32))
         assert np.array_equal(res[0]["corners"].view(np.uint32), want["corners"].view(np.uint32))
         assert res[0]["found_all"] == want["found_all"]
+
+
+def test_padded_and_unaligned_strides(ctx, pkg, oracle):
+    """frames embedded in larger buffers: row stride > width (aligned and odd), frame stride with slack, an
+    unaligned base address -- detect and transform must not depend on the packing"""
+    n = 5
+    frames = np.stack([oracle.synth_frame(SEED, 300 + i)[0] for i in range(n)])
+    want = [oracle.scan_frame(f) for f in frames]
+    for row_stride, slack, base_off in ((704, 0, 0), (643, 1931, 0), (640, 64, 3), (641, 7, 1)):
+        frame_stride = row_stride * 480 + slack
+        buf = np.full(base_off + n * frame_stride + 64, 0x5A, np.uint8)
+        for i in range(n):
+            view = buf[base_off + i * frame_stride: base_off + i * frame_stride + row_stride * 480]
+            view = view.reshape(480, row_stride)
+            view[:, :640] = frames[i]
+        d = ctx.alloc(buf.nbytes)
+        d.upload(buf)
+        res = np.zeros(n, pkg.RESULT_DTYPE)
+        cards = np.zeros((n, 270, 428), np.uint8)
+        ctx.detect(d.ptr + base_off, n, res, frame_stride=frame_stride, row_stride=row_stride)
+        ctx.transform(d.ptr + base_off, n, res, cards, frame_stride=frame_stride, row_stride=row_stride)
+        for i in range(n):
+            w, wcard = want[i]
+            assert np.array_equal(res[i]["found"], w["found"]), (row_stride, i)
+            assert np.array_equal(res[i]["corners"].view(np.uint32), w["corners"].view(np.uint32)), (row_stride, i)
+            if w["found_all"]:
+                assert np.array_equal(cards[i], wcard), (row_stride, base_off, i)
+        d.free()
+
+
+def test_card_stride_with_slack(ctx, pkg, oracle):
+    """scan + expiry on cards that sit 116 KiB apart instead of tightly packed"""
+    n = 6
+    stride = pkg.CARD_BYTES + 3224  # multiple of 4
+    cards = np.stack([oracle.synth_card(SEED, 40 + i)[0] for i in range(n)])
+    buf = np.full(n * stride, 0xA5, np.uint8)
+    for i in range(n):
+        buf[i * stride: i * stride + pkg.CARD_BYTES] = cards[i].reshape(-1)
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx._check(ctx.lib.dmz_hip_scan_cards_batch(ctx.h, buf.ctypes.data, stride, n, 0, res.ctypes.data))
+    ctx._check(ctx.lib.dmz_hip_scan_expiry_batch(ctx.h, buf.ctypes.data, stride, n, res.ctypes.data, exp.ctypes.data))
+    res2 = np.zeros(n, pkg.RESULT_DTYPE)
+    exp2 = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_cards(cards, n, res2)
+    ctx.scan_expiry(cards, n, res2, exp2)
+    assert res.tobytes() == res2.tobytes() and exp.tobytes() == exp2.tobytes()
+    with pytest.raises(pkg.DmzHipError):
+        ctx._check(ctx.lib.dmz_hip_scan_cards_batch(ctx.h, buf.ctypes.data, stride + 2, n, 0, res.ctypes.data))
