@@ -247,3 +247,40 @@ def test_card_stride_with_slack(ctx, pkg, oracle):
     assert res.tobytes() == res2.tobytes() and exp.tobytes() == exp2.tobytes()
     with pytest.raises(pkg.DmzHipError):
         ctx._check(ctx.lib.dmz_hip_scan_cards_batch(ctx.h, buf.ctypes.data, stride + 2, n, 0, res.ctypes.data))
+
+
+def test_contexts_are_independent(pkg, oracle):
+    """context life cycle: repeated create/destroy, and two contexts driven from two host threads at once
+    (one context per thread, like dmz_context) produce the single-context result"""
+    import threading
+    for _ in range(8):
+        c = pkg.Context(0)
+        c.close()
+    n = 64
+    ref_ctx = pkg.Context(0)
+    y = ref_ctx.alloc(n * pkg.FRAME_BYTES)
+    ref_ctx.synth_frames(SEED, 900, n, y.ptr)
+    ref_ctx.synchronize()
+    want_res = np.zeros(n, pkg.RESULT_DTYPE)
+    want_exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ref_ctx.pipeline_expiry(y.ptr, n, want_res, want_exp)
+    out = {}
+
+    def worker(k):
+        c = pkg.Context(0)
+        for rep in range(4):
+            res = np.zeros(n, pkg.RESULT_DTYPE)
+            exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+            c.pipeline_expiry(y.ptr, n, res, exp)
+            out[(k, rep)] = (res.tobytes(), exp.tobytes())
+        c.close()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for key, (r, e) in out.items():
+        assert r == want_res.tobytes() and e == want_exp.tobytes(), key
+    y.free()
+    ref_ctx.close()
