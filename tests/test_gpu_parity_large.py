@@ -1,6 +1,8 @@
 """Parity statistics on a larger seeded corpus (1024 frames): every integer/index output
 must match the oracle; float scores within 1e-4; y_offset may differ only on float near-ties
 of the window sums, and such frames are counted and bounded."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,7 +11,7 @@ SEED = 31337
 
 
 def test_1024_frames_against_oracle(ctx, pkg, oracle):
-    n = 1024
+    n = int(os.environ.get("DMZ_PARITY_FRAMES", "1024"))  # raise for a one-off sweep (the oracle does ~215 frames/s)
     y = ctx.alloc(n * pkg.FRAME_BYTES)
     res = ctx.alloc(n * 1024)
     cards = ctx.alloc(n * pkg.CARD_BYTES)
@@ -73,10 +75,10 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
     print("parity stats over %d frames: %s" % (n, stats))
     assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
     assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
-    assert stats["ties"] <= 2 and stats["flag_diff"] <= 2
+    assert stats["ties"] <= 2 + n // 4096 and stats["flag_diff"] <= 2 + n // 4096
     # a label can only flip when two vote scores of a digit are within the float tolerance
-    assert stats["label_diff"] <= 2
-    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 and stats["max_expiry_err"] <= 1e-4
+    assert stats["label_diff"] <= 2 + n // 4096
+    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 + n // 8192 and stats["max_expiry_err"] <= 1e-4
     assert stats["expiry_frames"] >= n // 4
     for b in (y, res, cards, exp):
         b.free()
