@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-SEED = 31337
+SEED = int(os.environ.get("DMZ_PARITY_SEED", "31337"))
 
 
 def test_1024_frames_against_oracle(ctx, pkg, oracle):
