@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): collects the round's profile summaries into gpurun_out/profiles_$1/
-#   1. rocprofv3 --kernel-trace --stats of bench.py (same command line as the bench, smaller batch)
+#   1. rocprofv3 --kernel-trace --stats of bench.py (the bench.py default command line minus the CPU baseline)
 #   2. PMC passes (separate runs, kernel-trace only): FETCH_SIZE, WRITE_SIZE per kernel
 TAG=${1:-r1}
-B=${BATCH:-16384}
+B=${BATCH:-65536}
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profiles_$TAG

@@ -3,4 +3,4 @@ timeout 900 python bench.py 2>&1 | tail -1 > gpurun_out/bench_r1_v3.json
 cat gpurun_out/bench_r1_v3.json | cut -c1-1500
 bash tools/profile_round.sh r1v3 > /dev/null 2>&1
 ls gpurun_out/profiles_r1v3
-cat gpurun_out/profiles_r1v3/r1v3_pmc_FETCH_SIZE_batch4096.txt gpurun_out/profiles_r1v3/r1v3_pmc_WRITE_SIZE_batch4096.txt
+true
