@@ -77,7 +77,7 @@ class RootGatherer:
                 work = dist.gather(local, gather_list, dst=self.dst, group=self.group, async_op=True)
                 self._pending.append(work)
                 return out
-            except (RuntimeError, NotImplementedError):
+            except NotImplementedError:
                 # a backend without gather: every rank takes the same exit on its first call, so the
                 # ranks stay in step; from here on use the blocking all-gather
                 self._all_gather = True
