@@ -303,6 +303,9 @@ int run_detect(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int 
   int rc = ensure(ctx, ctx->hits, sizeof(DmzBoxHit) * 4 * (size_t)n * 3);
   if (rc) return rc;
   DmzBoxHit *hits = (DmzBoxHit *)ctx->hits.p;
+  // detection starts a frame's record: every byte no later stage writes (reserved, expiry_month/year, the
+  // scan fields of frames that fail a gate) is zero, so that records are reproducible byte for byte
+  HIP_TRY(ctx, hipMemsetAsync(results, 0, sizeof(dmz_hip_frame_result) * (size_t)n, ctx->stream));
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_DETECT);
     if (dmz_launch_detect(ctx->stream, y, frame_stride, row_stride, n, ctx->h_params[0], hits, nullptr))

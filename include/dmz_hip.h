@@ -127,7 +127,7 @@ const char *dmz_hip_last_error(const dmz_hip_context *ctx);
 /* Batched dmz_detect_edges (dmz.h:82-83, dmz.cpp:371-439) on n luma planes.
  * y: n planes of height x width bytes, plane i at y + i*frame_stride, rows
  * row_stride bytes apart.  cb/cr (half-size planes, chroma fallback of
- * dmz.cpp:346-369) may be NULL.  Writes found/rho/theta/corners/found_all. */
+ * dmz.cpp:346-369) may be NULL.  Resets each record to zero, then writes found/rho/theta/corners/found_all. */
 int dmz_hip_detect_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride,
                          int row_stride, int width, int height,
                          const uint8_t *cb, const uint8_t *cr, size_t chroma_frame_stride,

@@ -284,3 +284,30 @@ def test_contexts_are_independent(pkg, oracle):
         assert r == want_res.tobytes() and e == want_exp.tobytes(), key
     y.free()
     ref_ctx.close()
+
+
+def test_records_do_not_depend_on_previous_buffer_contents(ctx, pkg):
+    """every byte of the result and expiry records is defined by the call: poisoned output buffers give the
+    same bytes as zeroed ones (device and host destinations)"""
+    n = 96
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 4000, n, y.ptr)
+    outs = []
+    for fill in (0x00, 0xA5, 0xFF):
+        res = ctx.alloc(n * 1024)
+        exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
+        res.upload(np.full(n * 1024, fill, np.uint8))
+        exp.upload(np.full(n * pkg.EXPIRY_DTYPE.itemsize, fill, np.uint8))
+        ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr)
+        ctx.synchronize()
+        outs.append((res.download(np.uint8).tobytes(), exp.download(np.uint8).tobytes()))
+        res.free()
+        exp.free()
+        hres = np.full(n, 0, pkg.RESULT_DTYPE)
+        hexp = np.zeros(n, pkg.EXPIRY_DTYPE)
+        hres.view(np.uint8)[:] = fill
+        hexp.view(np.uint8)[:] = fill
+        ctx.pipeline_expiry(y.ptr, n, hres, hexp)
+        outs.append((hres.tobytes(), hexp.tobytes()))
+    assert all(o == outs[0] for o in outs)
+    y.free()
