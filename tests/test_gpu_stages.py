@@ -292,22 +292,32 @@ def test_records_do_not_depend_on_previous_buffer_contents(ctx, pkg):
     n = 96
     y = ctx.alloc(n * pkg.FRAME_BYTES)
     ctx.synth_frames(SEED, 4000, n, y.ptr)
+    # two frames without a card: their rectified "cards" must come back as zeros, not as buffer leftovers
+    blank = np.full(pkg.FRAME_BYTES, 90, np.uint8)
+    for i in (5, 77):
+        ctx._check(ctx.lib.dmz_hip_memcpy_h2d(ctx.h, y.ptr + i * pkg.FRAME_BYTES, blank.ctypes.data, blank.nbytes))
     outs = []
     for fill in (0x00, 0xA5, 0xFF):
         res = ctx.alloc(n * 1024)
         exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
+        cards = ctx.alloc(n * pkg.CARD_BYTES)
         res.upload(np.full(n * 1024, fill, np.uint8))
         exp.upload(np.full(n * pkg.EXPIRY_DTYPE.itemsize, fill, np.uint8))
-        ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr)
+        cards.upload(np.full(n * pkg.CARD_BYTES, fill, np.uint8))
+        ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
         ctx.synchronize()
-        outs.append((res.download(np.uint8).tobytes(), exp.download(np.uint8).tobytes()))
+        c = cards.download(np.uint8).reshape(n, -1)
+        assert not c[5].any() and not c[77].any()
+        outs.append((res.download(np.uint8).tobytes(), exp.download(np.uint8).tobytes(), c.tobytes()))
+        cards.free()
         res.free()
         exp.free()
         hres = np.full(n, 0, pkg.RESULT_DTYPE)
         hexp = np.zeros(n, pkg.EXPIRY_DTYPE)
         hres.view(np.uint8)[:] = fill
         hexp.view(np.uint8)[:] = fill
-        ctx.pipeline_expiry(y.ptr, n, hres, hexp)
-        outs.append((hres.tobytes(), hexp.tobytes()))
+        hcards = np.full((n, pkg.CARD_BYTES), fill, np.uint8)
+        ctx.pipeline_expiry(y.ptr, n, hres, hexp, hcards)
+        outs.append((hres.tobytes(), hexp.tobytes(), hcards.tobytes()))
     assert all(o == outs[0] for o in outs)
     y.free()
