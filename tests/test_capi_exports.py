@@ -47,3 +47,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".c")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "import orc" not in text and "dmz_oracle.h" not in text, f
+
+
+def test_bench_tables_cover_every_stage(pkg):
+    """bench.py's algorithmic-bytes and PMC-traffic tables name exactly the stages the C-ABI times"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.ALGO) == set(pkg.STAGES) == set(bench.PMC_TRAFFIC)
+    header = open(os.path.join(ROOT, "include", "dmz_hip.h")).read()
+    assert "#define DMZ_HIP_STAGE_COUNT %d" % len(pkg.STAGES) in header
+    assert bench.PIPELINE_BYTES == 307200 + 115560 + 1024 + pkg.EXPIRY_DTYPE.itemsize
