@@ -204,7 +204,7 @@ def test_expiry_on_random_text_cards(ctx, pkg, oracle):
     # open the gates on every card so that the segmentation always runs; vary the row it starts from
     forced = res.copy()
     forced["flags"] = pkg.FLAG_VSEG_OK | pkg.FLAG_USABLE
-    forced["vseg_y_offset"] = 130 + (np.arange(n) % 40)
+    forced["vseg_y_offset"] = 121 + (np.arange(n) * 2) % 120  # 121 .. 239: down to no room for a stripe
     ctx.scan_expiry(cards, n, forced, exp)
     found = many = 0
     for i in range(n):
