@@ -15,21 +15,28 @@
 
 namespace {
 
-dmz_hip_context *g_default_ctx = nullptr;  // for the entry points that take no dmz_context
-bool g_warned = false;
+// For the entry points that take no dmz_context (dmz_detect_edges, the plumbing and score functions):
+// one lazily created context per host thread -- a HIP context is driven by one thread at a time, like
+// the reference's single-threaded state -- destroyed when the thread ends.
+struct DefaultContext {
+  dmz_hip_context *ctx = nullptr;
+  bool tried = false;
+  ~DefaultContext() {
+    if (ctx) dmz_hip_context_destroy(ctx);
+  }
+};
+thread_local DefaultContext g_default;
 
 dmz_hip_context *hip_of(dmz_context *dmz) {
   if (dmz && dmz->mz) return (dmz_hip_context *)dmz->mz;
-  if (!g_default_ctx) {
-    if (dmz_hip_context_create(0, &g_default_ctx) != DMZ_HIP_OK) {
-      g_default_ctx = nullptr;
-      if (!g_warned) {
-        fprintf(stderr, "dmz (HIP): no usable MI355X context; there is no CPU fallback\n");
-        g_warned = true;
-      }
+  if (!g_default.tried) {
+    g_default.tried = true;
+    if (dmz_hip_context_create(0, &g_default.ctx) != DMZ_HIP_OK) {
+      g_default.ctx = nullptr;
+      fprintf(stderr, "dmz (HIP): no usable MI355X context; there is no CPU fallback\n");
     }
   }
-  return g_default_ctx;
+  return g_default.ctx;
 }
 
 const uint8_t *image_origin(const IplImage *im, int *w, int *h) {
