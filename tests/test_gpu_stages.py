@@ -321,3 +321,50 @@ def test_records_do_not_depend_on_previous_buffer_contents(ctx, pkg):
         outs.append((hres.tobytes(), hexp.tobytes(), hcards.tobytes()))
     assert all(o == outs[0] for o in outs)
     y.free()
+
+
+def test_chroma_fallback_batch(ctx, pkg, oracle):
+    """a batch where random edges are wiped from Y (and some from Cb too): each of the four edges of each
+    frame must come from the first plane that shows it -- Y, then Cb, then Cr -- exactly as in the oracle"""
+    import os
+    n = int(os.environ.get("DMZ_CHROMA_FRAMES", "40"))
+    rng = np.random.default_rng(99)
+    ys, cbs, crs = [], [], []
+    for i in range(n):
+        y, _ = oracle.synth_frame(SEED, 700 + i)
+        cb = np.ascontiguousarray(y[::2, ::2])
+        cr = np.ascontiguousarray(y[1::2, 1::2])
+        y = y.copy()
+        wipes = [(slice(80, 130), slice(None)), (slice(350, 400), slice(None)),
+                 (slice(None), slice(80, 135)), (slice(None), slice(505, 560))]
+        for e, (rs, cs) in enumerate(wipes):
+            r = rng.random()
+            if r < 0.35:  # not on Y
+                y[rs, cs] = 60
+                if r < 0.15:  # not on Cb either
+                    cb[(slice(rs.start // 2, rs.stop // 2) if rs.start is not None else rs,
+                        slice(cs.start // 2, cs.stop // 2) if cs.start is not None else cs)] = 60
+                    if r < 0.05:  # nowhere
+                        cr[(slice(rs.start // 2, rs.stop // 2) if rs.start is not None else rs,
+                            slice(cs.start // 2, cs.stop // 2) if cs.start is not None else cs)] = 60
+        ys.append(y)
+        cbs.append(cb)
+        crs.append(cr)
+    ys, cbs, crs = (np.ascontiguousarray(np.stack(v)) for v in (ys, cbs, crs))
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    ctx.detect(ys, n, res, cb=cbs, cr=crs)
+    from_chroma = missing = 0
+    for i in range(n):
+        w = oracle.detect_edges(ys[i], cb=cbs[i], cr=crs[i])
+        assert np.array_equal(res[i]["found"], w["found"]), i
+        m = w["found"] != 0
+        assert np.array_equal(res[i]["rho"][m].view(np.uint32), w["rho"][m].view(np.uint32)), i
+        assert np.array_equal(res[i]["theta"][m].view(np.uint32), w["theta"][m].view(np.uint32)), i
+        assert res[i]["found_all"] == w["found_all"], i
+        if w["found_all"]:
+            assert np.array_equal(res[i]["corners"].view(np.uint32), w["corners"].view(np.uint32)), i
+        only_y = oracle.detect_edges(ys[i])
+        from_chroma += int((w["found"] != only_y["found"]).sum())
+        missing += int((w["found"] == 0).sum())
+    assert from_chroma >= n // 4  # the batch does exercise the fallback
+    print("edges recovered from chroma: %d, edges found nowhere: %d" % (from_chroma, missing))
