@@ -135,8 +135,8 @@ def main():
     def step():
         k = step_no[0] % nbuf
         step_no[0] += 1
-        if world > 1 and step_no[0] > nbuf:
-            gatherer.wait()  # the gathers that read this pair of buffers (two steps ago) are done
+        if world > 1:
+            gatherer.wait(slots=(2 * k, 2 * k + 1))  # only the gathers that still read this pair of buffers
         ctx.pipeline_expiry(frames, B, results_b[k], expiry_b[k], cards)
         if world > 1:
             gatherer.submit(results_b[k], slot=2 * k)

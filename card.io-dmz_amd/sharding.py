@@ -49,7 +49,7 @@ class RootGatherer:
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = dist.get_rank(group) if (dist.is_initialized() and self.world > 1) else 0
         self.dst = dst
-        self._pending = []
+        self._pending = {}  # slot -> outstanding work handles
         self._bufs = {}
         self._all_gather = False
 
@@ -75,7 +75,7 @@ class RootGatherer:
                 gather_list = list(out.chunk(self.world, dim=0))
             try:
                 work = dist.gather(local, gather_list, dst=self.dst, group=self.group, async_op=True)
-                self._pending.append(work)
+                self._pending.setdefault(slot, []).append(work)
                 return out
             except NotImplementedError:
                 # a backend without gather: every rank takes the same exit on its first call, so the
@@ -84,8 +84,9 @@ class RootGatherer:
         out = gather_results(local, self.world, self.group, out=self._root_buffer(local, slot))
         return out if self.rank == self.dst else None
 
-    def wait(self):
-        """Block the current stream (GPU) / the caller (CPU) until every submitted gather is done."""
-        for w in self._pending:
-            w.wait()
-        self._pending = []
+    def wait(self, slots=None):
+        """Block the current stream (GPU) / the caller (CPU) until the gathers submitted on `slots` (default:
+        all of them) are done -- e.g. the slots whose `local` buffers are about to be overwritten."""
+        for slot in (list(self._pending) if slots is None else slots):
+            for w in self._pending.pop(slot, []):
+                w.wait()

@@ -43,6 +43,7 @@ def _worker(rank, world, port, q):
     a = g.submit(local, slot=0)
     second = local.flip(0).contiguous()
     b = g.submit(second, slot=1)
+    g.wait(slots=(0,))
     g.wait()
     if rank == 0:
         assert torch.equal(a, out)

@@ -24,8 +24,7 @@ bufs = [torch.full((1000, 1024), 10 * rank + k, dtype=torch.uint8, device=dev) f
 outs = []
 for step in range(4):
     k = step % 2
-    if step >= 2:
-        g.wait()
+    g.wait(slots=(k,))
     bufs[k].fill_(10 * rank + step)
     outs.append(g.submit(bufs[k], slot=k))
 g.wait()
