@@ -131,16 +131,42 @@ __global__ __launch_bounds__(256) void k_scores(const uint8_t *__restrict__ y, s
   const uint8_t *roi = y + (size_t)f * frame_stride + (size_t)ry * row_stride + rx;
   unsigned s_abs = 0u, s_px = 0u;
   unsigned long long s_sq = 0ull;
-  for (int i = tid; i < rw * rh; i += 256) {
-    const int r = i / rw, c = i - r * rw;
-    const uint8_t *r1 = roi + (size_t)(r == 0 ? 0 : r - 1) * row_stride;
-    const uint8_t *r2 = roi + (size_t)(r == rh - 1 ? rh - 1 : r + 1) * row_stride;
+  // d(r, c) = e(r-1, c) - e(r+1, c) with e(r, c) = p[r][c-1] - p[r][c+1] (indices clamped): wave w walks a
+  // quarter of the rows, lanes run along the row; the e values of eight rows are fetched together (the
+  // loads are the latency that matters here), each row is read once for its e and once for the mean
+  const int lane = tid & 63, wave = tid >> 6;
+  const int rows_per = (rh + 3) >> 2, rbeg = wave * rows_per, rend = rbeg + rows_per < rh ? rbeg + rows_per : rh;
+  for (int c = lane; c < rw; c += 64) {
     const int cl = c == 0 ? 0 : c - 1, cr = c == rw - 1 ? rw - 1 : c + 1;
-    int d = (int)r1[cl] - (int)r1[cr] - (int)r2[cl] + (int)r2[cr];
-    d = d < 0 ? -d : d;
-    s_abs += (unsigned)d;
-    s_sq += (unsigned long long)(d * d);
-    s_px += roi[(size_t)r * row_stride + c];
+    // e of the row above the block (clamped) and of its first row
+    int e_prev, e_cur;
+    {
+      const uint8_t *ra = roi + (size_t)(rbeg == 0 ? 0 : rbeg - 1) * row_stride, *rb = roi + (size_t)rbeg * row_stride;
+      e_prev = (int)ra[cl] - (int)ra[cr];
+      e_cur = (int)rb[cl] - (int)rb[cr];
+    }
+    for (int r0 = rbeg; r0 < rend; r0 += 8) {
+      int e_next[8], px[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {  // rows r0+u+1 (clamped) for e, r0+u for the mean
+        const int rn = r0 + u + 1 < rh ? r0 + u + 1 : rh - 1, rc = r0 + u < rh ? r0 + u : rh - 1;
+        const uint8_t *pn = roi + (size_t)rn * row_stride;
+        e_next[u] = (int)pn[cl] - (int)pn[cr];
+        px[u] = roi[(size_t)rc * row_stride + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (r0 + u < rend) {
+          int d = e_prev - e_next[u];
+          d = d < 0 ? -d : d;
+          s_abs += (unsigned)d;
+          s_sq += (unsigned long long)(d * d);
+          s_px += (unsigned)px[u];
+        }
+        e_prev = e_cur;
+        e_cur = e_next[u];
+      }
+    }
   }
   __shared__ unsigned sh_abs[256], sh_px[256];
   __shared__ unsigned long long sh_sq[256];
