@@ -8,39 +8,43 @@
 // source.  Every fp64 operation is a single IEEE operation in that order
 // (-ffp-contract=off), so the card is byte-exact.
 //
-// CDNA4 mapping: one workgroup per 64 x 32 destination tile (two of OpenCV's 64 x 16
-// blocks; the x block origin -- the only one that enters the fp64 association -- is the
-// same).  The kernel is fp64-VALU bound, so the work per pixel is trimmed to what
-// exactness needs:
+// CDNA4 mapping: one workgroup per 64 x 90 destination strip (x origin = OpenCV's 64-px block
+// origin, the only one that enters the fp64 association; 428 x 270 = 7 x 3 strips).  A lane owns
+// one destination column and walks down the strip's rows, so everything that depends on the
+// column only (M0*x1, M3*x1, M6*x1) is computed once per lane, and everything that depends on
+// the row only (M0*x + M1*y + M2, ...) is computed once per workgroup and broadcast from LDS.
+// What is left per pixel is what exactness needs -- the kernel is VALU-issue bound (fp64 and
+// integer instructions issue at the same rate on gfx950):
 //   * 32/W: the IEEE-exact v_rcp_f64 + fma sequence the compiler itself emits for an f64
 //     division, without its v_div_scale / v_div_fixup wrapper (quarter-rate instructions
 //     that are the identity for |W| in [2^-500, 2^500]; anything else takes the full `/`).
 //   * cvRound: one fp64 add of 1.5*2^52 (round-to-nearest-even by the adder) instead of
-//     v_rndne_f64 + v_cvt_i32_f64; |f| >= 2^31 takes the saturating conversion.
-//   * the tile's source window comes from its four corner pixels (a projective map with W
+//     v_rndne_f64 + v_cvt_i32_f64, with the (even) window origin folded into the constant so
+//     the low dword is already window-relative; |f| >= 2^31 takes the saturating conversion.
+//   * the strip's source window comes from its four corner pixels (a projective map with W
 //     of constant sign is monotone along lines, +-1 px for rounding) and is staged into LDS
-//     with aligned 32-bit row loads (zeros outside the image = BORDER_CONSTANT 0); the
-//     bilinear taps are an aligned dword pair + v_alignbyte + v_dot4_u32_u8 per row.
-// Tiles whose window exceeds the LDS buffer or whose W changes sign (extreme caller-supplied
-// matrices) take the direct global path.  Blocks are renumbered so that all tiles of a
+//     with aligned 32-bit row loads (zeros outside the image = BORDER_CONSTANT 0); the four
+//     taps are single-byte LDS reads (lanes are adjacent columns: conflict-free).
+// Strips whose window exceeds the LDS buffer or whose W changes sign (extreme caller-supplied
+// matrices) take the direct global path.  Blocks are renumbered so that all strips of a
 // frame run on one XCD (block b is dispatched to XCD b % 8) and share its L2.
 #include "dmz_hip_internal.h"
 
 namespace {
 
-// developer ablation (tools/ablate.sh): 1 = cheap coordinates, 2 = no staging, 3 = no blend
+// developer ablation (tools/ablate.sh): 1 = cheap coordinates, 3 = no blend
 #ifndef DMZ_WARP_ABLATE
 #define DMZ_WARP_ABLATE 0
 #endif
 
-constexpr int TW = 64, TH = 32;
+constexpr int TW = 64, TH = 90;
 constexpr int kTilesX = (DMZ_CARD_WIDTH + TW - 1) / TW;   // 7
-constexpr int kTilesY = (DMZ_CARD_HEIGHT + TH - 1) / TH;  // 9
-constexpr int kTiles = kTilesX * kTilesY;                 // 63
-constexpr int LW = 192;  // LDS window row stride: 48 dwords = 16 mod 32 banks, so the two rows a 32-lane
-                         // group reads land on disjoint banks; windows up to 112 px wide are staged
-constexpr int LWMAX = 112;
-constexpr int LH = 64;   // rows
+constexpr int kTilesY = (DMZ_CARD_HEIGHT + TH - 1) / TH;  // 3
+constexpr int kTiles = kTilesX * kTilesY;                 // 21
+constexpr int LW = 128;     // LDS window row stride (bytes)
+constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
+constexpr int LH = 144;     // rows: a 90-row strip at 1.5 source px per card px, plus slack
+constexpr int kStagePasses = LH / 8;
 
 __device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -73,32 +77,9 @@ struct SrcXY {
   int X, Y;  // fixed point, 5 fractional bits
 };
 
-// FAST: no range checks -- valid for every pixel of a tile whose four corner pixels have W of
-// one sign with moderate exponents and |X|, |Y| < 2^30 (W is affine and X, Y are monotone
-// along lines, so every pixel of the tile lies between the corner values).
-template <bool FAST>
 __device__ __forceinline__ SrcXY map_pixel(double X0, double Y0, double W0, double M0, double M3,
                                            double M6, int x1) {
   SrcXY r;
-  if (DMZ_WARP_ABLATE == 1) {
-    r.X = (int)(float)X0 * 32 + x1 * 32;
-    r.Y = (int)(float)Y0 * 32;
-    return r;
-  }
-  if (FAST) {
-    const double Wd = W0 + M6 * x1;
-    double y = __builtin_amdgcn_rcp(Wd);
-    double t = __builtin_fma(-Wd, y, 1.0);
-    y = __builtin_fma(y, t, y);
-    t = __builtin_fma(-Wd, y, 1.0);
-    y = __builtin_fma(y, t, y);
-    const double q = 32.0 * y;
-    const double rr = __builtin_fma(-Wd, q, 32.0);
-    const double W = __builtin_fma(rr, y, q);
-    r.X = __double2loint((X0 + M0 * x1) * W + 6755399441055744.0);
-    r.Y = __double2loint((Y0 + M3 * x1) * W + 6755399441055744.0);
-    return r;
-  }
   const double W = div32(W0 + M6 * x1);
   r.X = rne_i32((X0 + M0 * x1) * W);
   r.Y = rne_i32((Y0 + M3 * x1) * W);
@@ -123,11 +104,16 @@ __device__ __forceinline__ void taps_global(const uint8_t *__restrict__ src, int
   }
 }
 
+struct RowXYW {
+  double X0, Y0, W0, W0s;  // W0s = W0 / 32
+};
+
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes, size_t frame_stride,
                                                int row_stride, int sw, int sh, int n, int n_pad,
                                                const DmzWarpMat *__restrict__ mats,
                                                uint8_t *__restrict__ cards, size_t card_stride) {
-  __shared__ __attribute__((aligned(16))) unsigned char win[LW * LH + 8];
+  __shared__ __attribute__((aligned(16))) unsigned char win[LW * LH];
+  __shared__ __attribute__((aligned(16))) RowXYW s_row[TH];
   __shared__ int s_corner[4][4];  // per corner: sx, sy, sign of W, unused
 
   // XCD-aware renumbering: logical id = xcd * (blocks/8) + k
@@ -139,35 +125,42 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   if (frame >= n) return;
   const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
   const int tid = threadIdx.x;
-  const int x = tx * TW;                  // OpenCV block origin in x
-  const int xq = (tid & 15) * 4;          // first of 4 pixels, relative to x
-  const int yr = ty * TH + (tid >> 4);    // rows yr and yr + 16
+  const int lane = tid & 63, wave = tid >> 6;
+  const int x = tx * TW;   // OpenCV block origin in x
+  const int y0 = ty * TH;  // 270 == 3 * TH: every strip is full height
   uint8_t *dbase = cards + (size_t)frame * card_stride;
   const DmzWarpMat &wm = mats[frame];
-  const bool col_ok = x + xq < DMZ_CARD_WIDTH;  // 428 % 4 == 0: a 4-pixel group is all in or all out
   if (!wm.valid) {
-    if (col_ok) {
-      if (yr < DMZ_CARD_HEIGHT) *(uint32_t *)(dbase + (size_t)yr * DMZ_CARD_WIDTH + x + xq) = 0u;
-      if (yr + 16 < DMZ_CARD_HEIGHT) *(uint32_t *)(dbase + (size_t)(yr + 16) * DMZ_CARD_WIDTH + x + xq) = 0u;
-    }
+    const bool col_ok = x + lane < DMZ_CARD_WIDTH;
+    if (col_ok)
+      for (int j = wave; j < TH; j += 4) dbase[(y0 + j) * DMZ_CARD_WIDTH + x + lane] = 0;
     return;
   }
   const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
 
-  // ---- source window from the four corner pixels of the tile ----
-  if (tid < 4) {
-    const int cx1 = (tid & 1) ? imin(TW, DMZ_CARD_WIDTH - x) - 1 : 0;
-    const int cy = ty * TH + ((tid & 2) ? imin(TH, DMZ_CARD_HEIGHT - ty * TH) - 1 : 0);
+  // ---- per-row terms (one thread per row) and the four corner pixels of the strip ----
+  if (tid < TH) {
+    const int y = y0 + tid;
+    RowXYW r;
+    r.X0 = M0 * x + M1 * y + M2;
+    r.Y0 = M3 * x + M4 * y + M5;
+    r.W0 = M6 * x + M7 * y + M8;
+    r.W0s = r.W0 * 0.03125;  // exact: the fast path divides by W / 32
+    s_row[tid] = r;
+  } else if (tid >= 128 && tid < 132) {
+    const int c = tid - 128;
+    const int cx1 = (c & 1) ? imin(TW, DMZ_CARD_WIDTH - x) - 1 : 0;
+    const int cy = y0 + ((c & 2) ? TH - 1 : 0);
     const double W0 = M6 * x + M7 * cy + M8;
     const double Wc = W0 + M6 * cx1;
-    const SrcXY p = map_pixel<false>(M0 * x + M1 * cy + M2, M3 * x + M4 * cy + M5, W0, M0, M3, M6, cx1);
-    s_corner[tid][0] = sat16(p.X >> 5);
-    s_corner[tid][1] = sat16(p.Y >> 5);
+    const SrcXY p = map_pixel(M0 * x + M1 * cy + M2, M3 * x + M4 * cy + M5, W0, M0, M3, M6, cx1);
+    s_corner[c][0] = sat16(p.X >> 5);
+    s_corner[c][1] = sat16(p.Y >> 5);
     const int we = (__double2hiint(Wc) >> 20) & 0x7ff;
     const bool tame = we > 900 && we < 1150 && p.X > -(1 << 30) && p.X < (1 << 30) && p.Y > -(1 << 30) &&
                       p.Y < (1 << 30);
-    s_corner[tid][2] = !tame ? 0 : (Wc > 0. ? 1 : -1);
+    s_corner[c][2] = !tame ? 0 : (Wc > 0. ? 1 : -1);
   }
   __syncthreads();
   const int bx0 = imin(imin(s_corner[0][0], s_corner[1][0]), imin(s_corner[2][0], s_corner[3][0])) - 1;
@@ -181,28 +174,50 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   const int wcols = bx1 + 2 - wx0;   // + the right bilinear tap
   const int wrows = by1 + 2 - wy0;
   const uint8_t *src = planes + (size_t)frame * frame_stride;
-  const bool fastxy = same_sign && wcols <= LWMAX && wrows <= LH;
-  const bool staged = fastxy && DMZ_WARP_ABLATE != 4;
+  const bool staged = same_sign && wcols <= LWMAX && wrows <= LH;
+
+  if (!staged) {
+    // ---- generic path: range-checked coordinates, taps straight from global memory ----
+    for (int i = tid; i < TW * TH; i += 256) {
+      const int x1 = i & (TW - 1), j = i >> 6;
+      if (x + x1 >= DMZ_CARD_WIDTH) continue;
+      const RowXYW r = s_row[j];
+      const SrcXY p = map_pixel(r.X0, r.Y0, r.W0, M0, M3, M6, x1);
+      const int sx = sat16(p.X >> 5), sy = sat16(p.Y >> 5);
+      const int ax = p.X & 31, ay = p.Y & 31;
+      int v0, v1, v2, v3;
+      taps_global(src, row_stride, sw, sh, sx, sy, v0, v1, v2, v3);
+      const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
+      int v = (v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10;
+      v = v > 255 ? 255 : v;
+      dbase[(y0 + j) * DMZ_CARD_WIDTH + x + x1] = (uint8_t)v;
+    }
+    return;
+  }
 
   // ---- stage the window: thread (tid & 31) owns one dword column, 8 rows per pass.  For a
   // window that lies inside the image (every card that is inside the frame) the loads are
-  // plain predicated dword loads, all issued here and landing in registers while the fp64
-  // coordinate math below runs; they are written to LDS after it.  Windows that cross the
-  // image border are staged by the generic byte-checked loop.
-  uint32_t stg[LH / 8];
+  // plain predicated dword loads, all in flight together; windows that cross the image border
+  // are staged by the byte-checked loop.
   const int sq = tid & 31, sj = tid >> 5;
-  const int wdw = (wcols + 3) >> 2;  // <= 28
+  const int wdw = (wcols + 3) >> 2;  // <= 30
   const bool interior = ((((uintptr_t)src) | (uintptr_t)row_stride) & 3) == 0 && wx0 >= 0 &&
                         wx0 + 4 * wdw <= sw && wy0 >= 0 && wy0 + wrows <= sh;
-  const bool do_stage = staged && DMZ_WARP_ABLATE != 2;
-  if (do_stage && interior) {
+  if (DMZ_WARP_ABLATE == 7) {
+  } else if (interior) {
+    uint32_t stg[kStagePasses];
     const uint8_t *g = src + (size_t)(wy0 + sj) * row_stride + wx0 + 4 * sq;
 #pragma unroll
-    for (int it = 0; it < LH / 8; it++) {
+    for (int it = 0; it < kStagePasses; it++) {
       stg[it] = 0u;
       if (sq < wdw && sj + 8 * it < wrows) stg[it] = *(const uint32_t *)(g + (size_t)(8 * it) * row_stride);
     }
-  } else if (do_stage) {
+    if (sq < wdw) {
+#pragma unroll
+      for (int it = 0; it < kStagePasses; it++)
+        if (sj + 8 * it < wrows) *(uint32_t *)(win + (sj + 8 * it) * LW + 4 * sq) = stg[it];
+    }
+  } else {
     for (int i = tid; i < wdw * wrows; i += 256) {
       const int j = i / wdw, q = i - j * wdw;
       const int gy = wy0 + j, gx = wx0 + 4 * q;
@@ -216,74 +231,78 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
     }
   }
 
-  // ---- fixed-point source coordinates of this thread's 2 x 4 pixels (overlaps the loads) ----
-  SrcXY P[2][4];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int y = yr + 16 * h;
-    const double X0 = M0 * x + M1 * y + M2;
-    const double Y0 = M3 * x + M4 * y + M5;
-    const double W0 = M6 * x + M7 * y + M8;
-    if (fastxy) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) P[h][k] = map_pixel<true>(X0, Y0, W0, M0, M3, M6, xq + k);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) P[h][k] = map_pixel<false>(X0, Y0, W0, M0, M3, M6, xq + k);
-    }
-  }
-  if (do_stage && interior && sq < wdw) {
-#pragma unroll
-    for (int it = 0; it < LH / 8; it++)
-      if (sj + 8 * it < wrows) *(uint32_t *)(win + (sj + 8 * it) * LW + 4 * sq) = stg[it];
-  }
+  // column terms of this lane, and the rounding constants with the window origin folded in:
+  // 1.5 * 2^52 - 32 * origin is an even integer, so the adder still rounds the product to the
+  // nearest-even integer and the low dword is the window-relative fixed-point coordinate.
+  // The W terms carry a factor 2^-5 (exact), so that 32 / W is the reciprocal of their sum.
+  // Lanes beyond column 427 repeat column 427 (same value to the same byte), which keeps the
+  // loop free of predication.
+  const int x1 = imin(lane, DMZ_CARD_WIDTH - 1 - x);
+  const double A = M0 * x1, B = M3 * x1, C = (M6 * x1) * 0.03125;
+  const double magicX = 6755399441055744.0 - (double)(32 * wx0);
+  const double magicY = 6755399441055744.0 - (double)(32 * wy0);
   __syncthreads();
 
-  // ---- bilinear blend, 4 px -> one 32-bit store ----
-  // (sum p*w*32 + 2^14) >> 15 == (sum p*wx*wy + 512) >> 10 with 5-bit fractions; the two
-  // horizontal taps of a row are one v_dot4_u32_u8 on an aligned-dword pair (v_alignbyte).
-  const int obase = wy0 * LW + wx0;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int y = yr + 16 * h;
-    if (!col_ok || y >= DMZ_CARD_HEIGHT) continue;
-    uint32_t packed = 0;
-    if (staged) {
-      // every pixel of a tile whose W keeps its sign lies inside the corner window (see the
-      // file header); the clamp only keeps the LDS address in range
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int Xv = P[h][k].X, Yv = P[h][k].Y;
-        if (DMZ_WARP_ABLATE == 3) { packed |= (uint32_t)((Xv + Yv) & 255) << (8 * k); continue; }
-        int o = (Yv >> 5) * LW + (Xv >> 5) - obase;
-        o = imin(imax(o, 0), LW * (LH - 1) - 2);
-        const unsigned char *p = win + (o & ~3);
-        const uint32_t a0 = *(const uint32_t *)p, a1 = *(const uint32_t *)(p + 4);
-        const uint32_t b0 = *(const uint32_t *)(p + LW), b1 = *(const uint32_t *)(p + LW + 4);
-        const uint32_t top = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)o);  // uses o & 3
-        const uint32_t bot = __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)o);
-        const uint32_t ax = (uint32_t)Xv & 31u, ay = (uint32_t)Yv & 31u;
-        const uint32_t wx = (32u - ax) | (ax << 8);
-        const uint32_t t_top = __builtin_amdgcn_udot4(top, wx, 0u, false);
-        const uint32_t t_bot = __builtin_amdgcn_udot4(bot, wx, 0u, false);
-        const uint32_t v = (t_top * (32u - ay) + t_bot * ay + 512u) >> 10;  // <= 255
-        packed |= v << (8 * k);
-      }
+  // every pixel of a strip whose W keeps its sign lies inside the corner window (file header);
+  // the clamp only keeps the LDS address in range
+  auto pixel = [&](int j) -> uint32_t {
+    RowXYW r = s_row[DMZ_WARP_ABLATE == 8 ? 0 : j];
+    if (DMZ_WARP_ABLATE == 8) r.X0 += j, r.Y0 += j;
+    int Xv, Yv;
+    if (DMZ_WARP_ABLATE == 1) {
+      Xv = ((int)(float)r.X0 + x1 - wx0) * 32;
+      Yv = ((int)(float)r.Y0 - wy0) * 32;
     } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int Xv = P[h][k].X, Yv = P[h][k].Y;
-        const int sx = sat16(Xv >> 5), sy = sat16(Yv >> 5);
-        const int ax = Xv & 31, ay = Yv & 31;
-        int v0, v1, v2, v3;
-        taps_global(src, row_stride, sw, sh, sx, sy, v0, v1, v2, v3);
-        const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
-        int v = (v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10;
-        v = v > 255 ? 255 : v;
-        packed |= (uint32_t)v << (8 * k);
-      }
+      // 1 / Wd, correctly rounded: v_rcp_f64 and three Newton steps, the last one in the
+      // residual form (the sequence the compiler emits for 1.0 / x between its v_div_scale /
+      // v_div_fixup wrapper, which is the identity for these exponents)
+      const double Wd = r.W0s + C;
+      double yv = __builtin_amdgcn_rcp(Wd);
+      double t = __builtin_fma(-Wd, yv, 1.0);
+      yv = __builtin_fma(yv, t, yv);
+      t = __builtin_fma(-Wd, yv, 1.0);
+      yv = __builtin_fma(yv, t, yv);
+      t = __builtin_fma(-Wd, yv, 1.0);
+      const double W = __builtin_fma(t, yv, yv);
+      Xv = __double2loint((r.X0 + A) * W + magicX);
+      Yv = __double2loint((r.Y0 + B) * W + magicY);
     }
-    *(uint32_t *)(dbase + (size_t)y * DMZ_CARD_WIDTH + x + xq) = packed;
+    if (DMZ_WARP_ABLATE == 3) return (uint32_t)(Xv + Yv) & 255u;
+    int o = ((Yv << 2) & ~(LW - 1)) | (Xv >> 5);  // (Yv >> 5) * LW + (Xv >> 5) inside the window
+    o = imin(imax(o, 0), LW * (LH - 1) - 2);
+    // four single-byte LDS reads: odd-address ds_read_u16 is several times slower than the
+    // aligned form on gfx950, and a byte read costs no more than a wider one here
+    // (the right-hand taps are volatile reads only to keep the compiler from re-merging them)
+    typedef const volatile __attribute__((address_space(3))) unsigned char *lds_vu8;
+    const unsigned char *p = win + o;
+    const lds_vu8 pr = (lds_vu8)win + o;
+    const int p00 = p[0], p01 = pr[1], p10 = p[LW], p11 = pr[LW + 1];
+    const int ax = Xv & 31, ay = Yv & 31, bx = 32 - ax;
+    // (sum p*w*32 + 2^14) >> 15 == (sum p*wx*wy + 512) >> 10 with 5-bit fractions
+    const int t_top = __mul24(p01, ax) + __mul24(p00, bx);
+    const int t_bot = __mul24(p11, ax) + __mul24(p10, bx);
+    return (uint32_t)((t_top << 5) + (__mul24(t_bot - t_top, ay) + 512)) >> 10;  // <= 255
+  };
+
+  // ---- the strip: wave w takes rows w, w + 4, ..., two at a time (independent chains) ----
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  // buffer stores: card descriptor + scalar row offset + lane column, no per-pixel address math
+  const __amdgpu_buffer_rsrc_t card =
+      __builtin_amdgcn_make_buffer_rsrc(dbase, 0, DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT, 0x00020000);
+  const int tile_off = y0 * DMZ_CARD_WIDTH + x;
+  constexpr int kPairs = TH / 8;  // 11 pairs = rows w .. w + 84; rows 88, 89 are the tail
+#pragma unroll
+  for (int m = 0; m < kPairs; m++) {
+    const int j0 = wave_s + 8 * m, j1 = j0 + 4;
+    const uint32_t v0 = pixel(j0), v1 = pixel(j1);
+    if (DMZ_WARP_ABLATE == 6 && v0 + v1 != 0x12345u) continue;
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v0, card, x1, tile_off + j0 * DMZ_CARD_WIDTH, 0);
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v1, card, x1, tile_off + j1 * DMZ_CARD_WIDTH, 0);
+  }
+  static_assert(TH == 8 * kPairs + 2, "tail rows");
+  if (wave_s < 2) {
+    const int j = wave_s + 8 * kPairs;
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pixel(j), card, x1, tile_off + j * DMZ_CARD_WIDTH, 0);
   }
 }
 

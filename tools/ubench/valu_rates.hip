@@ -5,6 +5,7 @@
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(double *out, double a, double b, int iters) {
+  const int m = (int)(a * 1000.0) + (int)threadIdx.x;
   double x[8];
   float f[8];
   int n[8];
@@ -20,6 +21,16 @@ __global__ __launch_bounds__(256) void k(double *out, double a, double b, int it
       if (OP == 5) n[i] = n[i] * 3 + (int)b;
       if (OP == 6) n[i] = (int)__builtin_amdgcn_udot4((unsigned)n[i], 0x01020304u, (unsigned)it, false);
       if (OP == 7) x[i] = __builtin_amdgcn_fract(x[i]) + b;
+      if (OP == 8) n[i] = n[i] * m;                                              // v_mul_lo_u32
+      if (OP == 9) n[i] = (int)__umul24((unsigned)n[i], (unsigned)m);  // v_mul_u32_u24
+      if (OP == 10) n[i] = (int)(__umul24((unsigned)n[i], (unsigned)m) + (unsigned)it);  // v_mad_u32_u24
+      if (OP == 11) n[i] = n[i] * m + it;                                        // v_mad_u64_u32 / mul_lo + add
+      if (OP == 12) n[i] = (int)__builtin_amdgcn_alignbyte((unsigned)n[i], (unsigned)m, (unsigned)it);
+      if (OP == 13) n[i] = (int)__builtin_amdgcn_perm((unsigned)n[i], (unsigned)m, 0x05010400u + (unsigned)it);
+      if (OP == 14) n[i] = (int)__builtin_amdgcn_sad_u8((unsigned)n[i], (unsigned)m, (unsigned)it);
+      if (OP == 15) n[i] = max(min(n[i], m), it);                                // v_med3_i32
+      if (OP == 16) x[i] = (double)(n[i] + it) + x[i];                           // v_cvt_f64_i32 + add
+      if (OP == 17) n[i] = __double2loint(x[i] = x[i] + 6755399441055744.0) + n[i];
     }
   }
   double s = 0;
@@ -57,5 +68,15 @@ int main() {
   run<5>("v_mad_u32 (mul+add)");
   run<6>("v_dot4_u32_u8");
   run<7>("v_fract_f64 + add");
+  run<8>("v_mul_lo_u32");
+  run<9>("v_mul_u32_u24");
+  run<10>("v_mad_u32_u24");
+  run<11>("i32 mul + add");
+  run<12>("v_alignbyte_b32");
+  run<13>("v_perm_b32");
+  run<14>("v_sad_u8");
+  run<15>("v_med3_i32");
+  run<16>("cvt_f64_i32 + add_f64");
+  run<17>("add_f64 + add_u32");
   return 0;
 }
