@@ -352,7 +352,7 @@ int run_transform(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_strid
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_WARP);
     dmz_launch_warp(ctx->stream, plane, frame_stride, row_stride, width, height, n,
-                    (const DmzWarpMat *)ctx->mats.p, cards, card_stride);
+                    (DmzWarpMat *)ctx->mats.p, cards, card_stride);
   }
   HIP_TRY(ctx, hipGetLastError());
   return DMZ_HIP_OK;
@@ -942,7 +942,7 @@ int dmz_hip_warp_perspective_batch(dmz_hip_context *ctx, const uint8_t *plane, s
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_WARP);
     dmz_launch_warp(ctx->stream, (const uint8_t *)dp, frame_stride, row_stride, width, height, n,
-                    (const DmzWarpMat *)ctx->mats.p, dcards, card_stride);
+                    (DmzWarpMat *)ctx->mats.p, dcards, card_stride);
   }
   HIP_TRY(ctx, hipGetLastError());
   if (!cards_dev) {

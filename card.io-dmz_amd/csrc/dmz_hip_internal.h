@@ -74,10 +74,18 @@ struct DmzBoxHit {
 };
 
 // Inverse homography (dst -> src) of one frame, double, as cv::invert leaves it.
+// win[]: per destination strip of k_warp, the source window k_warp_windows derived from the
+// strip's four corner pixels (wdw: dword columns; > 0 staged with aligned dword loads, < 0 staged
+// with the border-checked loop, 0 = generic path)
+struct DmzWarpWin {
+  int wx0, wy0, wdw, wrows;
+};
+constexpr int DMZ_WARP_STRIPS = 21;
 struct DmzWarpMat {
   double m[9];
   int valid;
   int pad_;
+  DmzWarpWin win[DMZ_WARP_STRIPS];
 };
 
 // Expiry path.  Per (frame, stripe) staging written by k_expiry_seg and merged, in stripe order,
@@ -122,7 +130,7 @@ void dmz_launch_homography(hipStream_t s, int n, int orientation, int options,
 void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9);
 void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMat *mats);
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
-                     int width, int height, int n, const DmzWarpMat *mats, uint8_t *cards,
+                     int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride);
 void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
                      int n, int only_warped, dmz_hip_frame_result *results);

@@ -32,7 +32,8 @@
 
 namespace {
 
-// developer ablation (tools/ablate.sh): 1 = cheap coordinates, 3 = no blend
+// developer ablation (tools/ablate.sh): 1 = cheap coordinates, 3 = no blend, 6 = no stores,
+// 8 = one row record, 9 = no address clamp, 10 = one row pair per wave (block overhead)
 #ifndef DMZ_WARP_ABLATE
 #define DMZ_WARP_ABLATE 0
 #endif
@@ -43,7 +44,10 @@ constexpr int kTilesY = (DMZ_CARD_HEIGHT + TH - 1) / TH;  // 3
 constexpr int kTiles = kTilesX * kTilesY;                 // 21
 constexpr int LW = 128;     // LDS window row stride (bytes)
 constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
-constexpr int LH = 144;     // rows: a 90-row strip at 1.5 source px per card px, plus slack
+#ifndef DMZ_WARP_LH
+#define DMZ_WARP_LH 144
+#endif
+constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at 1.5 source px per card px, plus slack
 constexpr int kStagePasses = LH / 8;
 
 __device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
@@ -108,13 +112,55 @@ struct RowXYW {
   double X0, Y0, W0, W0s;  // W0s = W0 / 32
 };
 
+static_assert(kTiles == DMZ_WARP_STRIPS, "strip count");
+
+// One thread per (frame, strip): the strip's source window from its four corner pixels.
+__global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int aligned,
+                                                       DmzWarpMat *__restrict__ mats) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * kTiles) return;
+  const int frame = i / kTiles, tile = i - frame * kTiles;
+  const DmzWarpMat &wm = mats[frame];
+  DmzWarpWin w = {0, 0, 0, 0};
+  if (wm.valid) {
+    const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
+    const int x = tx * TW, y0 = ty * TH;
+    const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
+                 M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
+    int bx0 = 1 << 20, bx1 = -(1 << 20), by0 = 1 << 20, by1 = -(1 << 20), npos = 0, nneg = 0;
+    for (int c = 0; c < 4; c++) {
+      const int cx1 = (c & 1) ? imin(TW, DMZ_CARD_WIDTH - x) - 1 : 0;
+      const int cy = y0 + ((c & 2) ? TH - 1 : 0);
+      const double W0 = M6 * x + M7 * cy + M8;
+      const double Wc = W0 + M6 * cx1;
+      const SrcXY p = map_pixel(M0 * x + M1 * cy + M2, M3 * x + M4 * cy + M5, W0, M0, M3, M6, cx1);
+      const int sx = sat16(p.X >> 5), sy = sat16(p.Y >> 5);
+      bx0 = imin(bx0, sx), bx1 = imax(bx1, sx), by0 = imin(by0, sy), by1 = imax(by1, sy);
+      const int we = (__double2hiint(Wc) >> 20) & 0x7ff;
+      const bool tame = we > 900 && we < 1150 && p.X > -(1 << 30) && p.X < (1 << 30) && p.Y > -(1 << 30) &&
+                        p.Y < (1 << 30);
+      if (tame) (Wc > 0. ? npos : nneg)++;
+    }
+    bx0 -= 1, bx1 += 1, by0 -= 1, by1 += 1;  // rounding of the interior pixels
+    w.wx0 = bx0 & ~3;                         // window origin, 4-aligned in x
+    w.wy0 = by0;
+    const int wcols = bx1 + 2 - w.wx0;        // + the right bilinear tap
+    w.wrows = by1 + 2 - w.wy0;
+    const int wdw = (wcols + 3) >> 2;
+    if ((npos == 4 || nneg == 4) && wcols <= LWMAX && w.wrows <= LH) {
+      const bool interior = aligned && w.wx0 >= 0 && w.wx0 + 4 * wdw <= sw && w.wy0 >= 0 && w.wy0 + w.wrows <= sh;
+      w.wdw = interior ? wdw : -wdw;
+    }
+  }
+  mats[frame].win[tile] = w;
+}
+
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes, size_t frame_stride,
                                                int row_stride, int sw, int sh, int n, int n_pad,
                                                const DmzWarpMat *__restrict__ mats,
                                                uint8_t *__restrict__ cards, size_t card_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char win[LW * LH];
   __shared__ __attribute__((aligned(16))) RowXYW s_row[TH];
-  __shared__ int s_corner[4][4];  // per corner: sx, sy, sign of W, unused
 
   // XCD-aware renumbering: logical id = xcd * (blocks/8) + k
   const unsigned int nblk = (unsigned int)n_pad * kTiles;
@@ -138,8 +184,11 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   }
   const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
+  const DmzWarpWin ww = wm.win[tile];  // uniform: scalar loads
+  const int wx0 = ww.wx0, wy0 = ww.wy0, wrows = ww.wrows;
+  const uint8_t *src = planes + (size_t)frame * frame_stride;
 
-  // ---- per-row terms (one thread per row) and the four corner pixels of the strip ----
+  // ---- per-row terms, one thread per row ----
   if (tid < TH) {
     const int y = y0 + tid;
     RowXYW r;
@@ -148,36 +197,11 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
     r.W0 = M6 * x + M7 * y + M8;
     r.W0s = r.W0 * 0.03125;  // exact: the fast path divides by W / 32
     s_row[tid] = r;
-  } else if (tid >= 128 && tid < 132) {
-    const int c = tid - 128;
-    const int cx1 = (c & 1) ? imin(TW, DMZ_CARD_WIDTH - x) - 1 : 0;
-    const int cy = y0 + ((c & 2) ? TH - 1 : 0);
-    const double W0 = M6 * x + M7 * cy + M8;
-    const double Wc = W0 + M6 * cx1;
-    const SrcXY p = map_pixel(M0 * x + M1 * cy + M2, M3 * x + M4 * cy + M5, W0, M0, M3, M6, cx1);
-    s_corner[c][0] = sat16(p.X >> 5);
-    s_corner[c][1] = sat16(p.Y >> 5);
-    const int we = (__double2hiint(Wc) >> 20) & 0x7ff;
-    const bool tame = we > 900 && we < 1150 && p.X > -(1 << 30) && p.X < (1 << 30) && p.Y > -(1 << 30) &&
-                      p.Y < (1 << 30);
-    s_corner[c][2] = !tame ? 0 : (Wc > 0. ? 1 : -1);
   }
-  __syncthreads();
-  const int bx0 = imin(imin(s_corner[0][0], s_corner[1][0]), imin(s_corner[2][0], s_corner[3][0])) - 1;
-  const int bx1 = imax(imax(s_corner[0][0], s_corner[1][0]), imax(s_corner[2][0], s_corner[3][0])) + 1;
-  const int by0 = imin(imin(s_corner[0][1], s_corner[1][1]), imin(s_corner[2][1], s_corner[3][1])) - 1;
-  const int by1 = imax(imax(s_corner[0][1], s_corner[1][1]), imax(s_corner[2][1], s_corner[3][1])) + 1;
-  const int sgn = s_corner[0][2];
-  const bool same_sign = sgn != 0 && s_corner[1][2] == sgn && s_corner[2][2] == sgn && s_corner[3][2] == sgn;
-  const int wx0 = bx0 & ~3;          // window origin, 4-aligned in x
-  const int wy0 = by0;
-  const int wcols = bx1 + 2 - wx0;   // + the right bilinear tap
-  const int wrows = by1 + 2 - wy0;
-  const uint8_t *src = planes + (size_t)frame * frame_stride;
-  const bool staged = same_sign && wcols <= LWMAX && wrows <= LH;
 
-  if (!staged) {
+  if (ww.wdw == 0) {
     // ---- generic path: range-checked coordinates, taps straight from global memory ----
+    __syncthreads();
     for (int i = tid; i < TW * TH; i += 256) {
       const int x1 = i & (TW - 1), j = i >> 6;
       if (x + x1 >= DMZ_CARD_WIDTH) continue;
@@ -196,28 +220,38 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   }
 
   // ---- stage the window: thread (tid & 31) owns one dword column, 8 rows per pass.  For a
-  // window that lies inside the image (every card that is inside the frame) the loads are
-  // plain predicated dword loads, all in flight together; windows that cross the image border
-  // are staged by the byte-checked loop.
+  // window that lies inside the image (every card that is inside the frame) these are buffer
+  // loads -- frame descriptor + per-thread offset + scalar row offset, no address arithmetic,
+  // rows past the frame read as zero -- all in flight together: twelve passes cover the 96 rows
+  // of a strip at scale 1, taller windows take six more.  Rows between the window and the pass
+  // boundary are staged too (never read).  Windows that cross the image border are staged by
+  // the byte-checked loop.
   const int sq = tid & 31, sj = tid >> 5;
-  const int wdw = (wcols + 3) >> 2;  // <= 30
-  const bool interior = ((((uintptr_t)src) | (uintptr_t)row_stride) & 3) == 0 && wx0 >= 0 &&
-                        wx0 + 4 * wdw <= sw && wy0 >= 0 && wy0 + wrows <= sh;
-  if (DMZ_WARP_ABLATE == 7) {
-  } else if (interior) {
-    uint32_t stg[kStagePasses];
-    const uint8_t *g = src + (size_t)(wy0 + sj) * row_stride + wx0 + 4 * sq;
+  if (ww.wdw > 0) {
+    if (sq < ww.wdw) {
+      const size_t fbytes = (size_t)row_stride * sh;
+      const __amdgpu_buffer_rsrc_t frame_rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)src, 0, fbytes > 0xfffffffcu ? 0xfffffffcu : (unsigned)fbytes, 0x00020000);
+      const int voff = (wy0 + sj) * row_stride + wx0 + 4 * sq;
+      unsigned char *lp = win + sj * LW + 4 * sq;
+      constexpr int kA = 12;
+      uint32_t sa[kA], sb[kStagePasses - kA];
 #pragma unroll
-    for (int it = 0; it < kStagePasses; it++) {
-      stg[it] = 0u;
-      if (sq < wdw && sj + 8 * it < wrows) stg[it] = *(const uint32_t *)(g + (size_t)(8 * it) * row_stride);
-    }
-    if (sq < wdw) {
+      for (int it = 0; it < kA; it++) sa[it] = __builtin_amdgcn_raw_buffer_load_b32(frame_rs, voff, 8 * it * row_stride, 0);
+      if (wrows > 8 * kA) {
 #pragma unroll
-      for (int it = 0; it < kStagePasses; it++)
-        if (sj + 8 * it < wrows) *(uint32_t *)(win + (sj + 8 * it) * LW + 4 * sq) = stg[it];
+        for (int it = kA; it < kStagePasses; it++)
+          sb[it - kA] = __builtin_amdgcn_raw_buffer_load_b32(frame_rs, voff, 8 * it * row_stride, 0);
+      }
+#pragma unroll
+      for (int it = 0; it < kA; it++) *(uint32_t *)(lp + 8 * it * LW) = sa[it];
+      if (wrows > 8 * kA) {
+#pragma unroll
+        for (int it = kA; it < kStagePasses; it++) *(uint32_t *)(lp + 8 * it * LW) = sb[it - kA];
+      }
     }
   } else {
+    const int wdw = -ww.wdw;
     for (int i = tid; i < wdw * wrows; i += 256) {
       const int j = i / wdw, q = i - j * wdw;
       const int gy = wy0 + j, gx = wx0 + 4 * q;
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
     }
     if (DMZ_WARP_ABLATE == 3) return (uint32_t)(Xv + Yv) & 255u;
     int o = ((Yv << 2) & ~(LW - 1)) | (Xv >> 5);  // (Yv >> 5) * LW + (Xv >> 5) inside the window
-    o = imin(imax(o, 0), LW * (LH - 1) - 2);
+    if (DMZ_WARP_ABLATE == 9) o = imin(imax(o, 0), LW * (LH - 1) - 2);
     // four single-byte LDS reads: odd-address ds_read_u16 is several times slower than the
     // aligned form on gfx950, and a byte read costs no more than a wider one here
     // (the right-hand taps are volatile reads only to keep the compiler from re-merging them)
@@ -292,7 +326,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   const int tile_off = y0 * DMZ_CARD_WIDTH + x;
   constexpr int kPairs = TH / 8;  // 11 pairs = rows w .. w + 84; rows 88, 89 are the tail
 #pragma unroll
-  for (int m = 0; m < kPairs; m++) {
+  for (int m = 0; m < (DMZ_WARP_ABLATE == 10 ? 1 : kPairs); m++) {
     const int j0 = wave_s + 8 * m, j1 = j0 + 4;
     const uint32_t v0 = pixel(j0), v1 = pixel(j1);
     if (DMZ_WARP_ABLATE == 6 && v0 + v1 != 0x12345u) continue;
@@ -309,9 +343,12 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
 }  // namespace
 
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
-                     int width, int height, int n, const DmzWarpMat *mats, uint8_t *cards,
+                     int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride) {
   const int n_pad = (n + 7) & ~7;
+  const int aligned = ((((uintptr_t)planes) | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
+  hipLaunchKernelGGL(k_warp_windows, dim3((unsigned)((n * kTiles + 255) / 256)), dim3(256), 0, s, n, width,
+                     height, aligned, mats);
   hipLaunchKernelGGL(k_warp, dim3((unsigned)n_pad * kTiles), dim3(256), 0, s, planes, frame_stride,
                      row_stride, width, height, n, n_pad, mats, cards, card_stride);
 }
