@@ -182,38 +182,68 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   unsigned long long *s_best = (unsigned long long *)(lds + bp.lds_red + 128);  // 16 x 8 B
   int *s_int = (int *)(lds + bp.lds_red + 256);                          // low, high, ncand, overflow
 
-  // ---- A. ROI -> LDS tile in walk space (aligned 32-bit global words), replicate 3 lanes ----
+  // ---- A. ROI -> LDS tile in walk space (32-bit global words), replicate 3 lanes ----
+  // Buffer loads: frame descriptor + per-lane byte offset + scalar row offset, so the only
+  // per-word work is the LDS store.  Top/bottom boxes: a wave per image row, lanes across the
+  // row's words.  Left/right boxes: a lane per image row (= walk lane), the row's words held in
+  // registers and stored a byte at a time (tile step = image column): consecutive lanes write
+  // consecutive bytes.
   {
     const int wpr = ((bp.x + w - 1) >> 2) - (bp.x >> 2) + 1;  // global words per image row
     const uint8_t *plane = planes + (size_t)frame * frame_stride;
-    for (int i = tid; i < wpr * h; i += NT) {
-      const int r = i / wpr, j = i - r * wpr;
-      const uint8_t *g = plane + (size_t)(bp.y + r) * row_stride + ((bp.x >> 2) + j) * 4;
-      uint32_t v;
-      if ((((uintptr_t)g) & 3) == 0) {
-        v = *(const uint32_t *)g;
-      } else {  // plane base / row stride not 4-byte aligned: assemble from bytes
-        v = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
-      }
-      if (!VERT) {
-        *(uint32_t *)(tile + r * sp + 4 + j * 4) = v;  // off = 4 + (x & 3) keeps the alignment
-      } else {
-        // transpose: image (row r, col x) -> tile (step = x - box.x, lane = r)
+    // the descriptor covers the rows of the box; cvSetImageROI clipped the box to the image
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(plane + (size_t)bp.y * row_stride), 0, (unsigned)(h * row_stride), 0x00020000);
+    const bool aligned = ((((uintptr_t)plane) | (uintptr_t)row_stride) & 3) == 0;
+    if (!aligned) {
+      // plane base / row stride not 4-byte aligned: words assembled from bytes, one word per thread
+      for (int i = tid; i < wpr * h; i += NT) {
+        const int r = i / wpr, j = i - r * wpr;
+        const uint8_t *g = plane + (size_t)(bp.y + r) * row_stride + ((bp.x >> 2) + j) * 4;
+        const uint32_t v = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
         const int c0 = j * 4 - (bp.x & 3);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const int cc = c0 + k;
-          if (cc >= 0 && cc < w) tile[cc * sp + off + r] = (unsigned char)(v >> (8 * k));
+          const int cc = c0 + k;  // image column - box.x
+          if (cc >= 0 && cc < w) tile[VERT ? cc * sp + off + r : r * sp + off + cc] = (unsigned char)(v >> (8 * k));
+        }
+      }
+    } else if (!VERT) {
+      for (int r = wave; r < h; r += NT / 64) {
+        const int soff = r * row_stride;
+        unsigned char *trow = tile + r * sp + 4;  // off = 4 + (x & 3) keeps the word alignment
+        for (int j = lane; j < wpr; j += 64)
+          *(uint32_t *)(trow + 4 * j) = __builtin_amdgcn_raw_buffer_load_b32(rs, ((bp.x >> 2) + j) * 4, soff, 0);
+      }
+    } else {
+      constexpr int kChunk = 12;  // words per pass: one pass for boxes up to 44 px wide
+      for (int r = tid; r < h; r += NT) {
+        const int voff = r * row_stride + (bp.x >> 2) * 4;
+        unsigned char *tcol = tile + off + r - (bp.x & 3) * sp;
+        for (int j0 = 0; j0 < wpr; j0 += kChunk) {
+          uint32_t v[kChunk];
+#pragma unroll
+          for (int j = 0; j < kChunk; j++)
+            v[j] = j0 + j < wpr ? __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 4 * (j0 + j), 0) : 0u;
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const int cc = 4 * (j0 + j) + k - (bp.x & 3);  // tile step = image column - box.x
+              if (j0 + j < wpr && cc >= 0 && cc < w)
+                tcol[(4 * (j0 + j) + k) * sp] = (unsigned char)(v[j] >> (8 * k));
+            }
+          }
         }
       }
     }
     if (tid < 4) s_int[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < S * 6; i += NT) {
-      const int a = i / 6, k = i - a * 6;
+    for (int i = tid; i < S * 8; i += NT) {
+      const int a = i >> 3, k = i & 7;
       unsigned char *row = tile + a * sp;
       if (k < 3) row[off - 1 - k] = row[off];
-      else row[off + L + (k - 3)] = row[off + L - 1];
+      else if (k < 6) row[off + L + (k - 3)] = row[off + L - 1];
     }
     __syncthreads();
   }
