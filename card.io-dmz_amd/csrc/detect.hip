@@ -407,26 +407,31 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
         const int r = VERT ? l : a, col = VERT ? a : l;  // image coordinates inside the ROI
 #pragma unroll
         for (int n = 0; n < kNumAngle; n++) {
-          const int rr = ((col * bp.tab_cos[n] + r * bp.tab_sin[n]) >> 10) + half;
-          const int cell = n * numrho + rr;
-          atomicAdd(&acc32[cell >> 1], 1u << ((cell & 1) * 16));  // counts < 65536: no carry
+          // counter of (n, rr): half n & 1 of word (n >> 1) * numrho + rr -- the half is a
+          // compile-time constant per angle; counts < 65536, so no carry between the halves
+          const int t = col * bp.tab_cos[n] + r * bp.tab_sin[n];
+          atomicAdd(&acc32[(n >> 1) * numrho + half + (t >> 10)], (n & 1) ? 0x10000u : 1u);
         }
       }
     }
   }
   __syncthreads();
   DMZ_STOP_AFTER(5, acc32[0] + acc32[numrho])
+  static_assert(kNumAngle % 2 == 0, "vote counters are packed in angle pairs");
 
   // ---- F. arg-max with the reference's scan order (hough.cpp:163-176) ----
   unsigned long long best = 0;
   {
-    const unsigned short *acc16 = (const unsigned short *)acc32;
-    for (int n = 0; n < kNumAngle; n++)
+    for (int p = 0; p < kNumAngle / 2; p++)
       for (int rr = tid; rr < numrho; rr += NT) {
-        const unsigned int val = acc16[n * numrho + rr];
-        const unsigned int order = (unsigned int)(rr * kNumAngle + n);  // scan position
-        const unsigned long long key = ((unsigned long long)val << 32) | (0xffffffffu - order);
-        best = key > best ? key : best;
+        const unsigned int w2 = acc32[p * numrho + rr];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const unsigned int val = k ? w2 >> 16 : w2 & 0xffffu;
+          const unsigned int order = (unsigned int)(rr * kNumAngle + 2 * p + k);  // scan position
+          const unsigned long long key = ((unsigned long long)val << 32) | (0xffffffffu - order);
+          best = key > best ? key : best;
+        }
       }
   }
   for (int o = 32; o > 0; o >>= 1) {
