@@ -232,7 +232,10 @@ __global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restric
     for (int i = tid; i < nd * 40; i += DG_THREADS) {
       const int d = i / 40, pos = i - d * 40;
       const int pr = pos / 5, pc = pos - pr * 5;
-      const unsigned char *xp = eq + d * DG_ESTRIDE + (pr * 3) * 19 + pc * 3;
+      // single-byte LDS reads (volatile only so that the compiler does not merge them into 16-bit
+      // reads: at odd addresses those stall the LDS pipe -- SQ_LDS_UNALIGNED_STALL)
+      typedef const volatile __attribute__((address_space(3))) unsigned char *lds_vu8;
+      const lds_vu8 xp = (lds_vu8)eq + d * DG_ESTRIDE + (pr * 3) * 19 + pc * 3;
       float in[5][5];
 #pragma unroll
       for (int a = 0; a < 5; a++)
