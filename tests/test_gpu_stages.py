@@ -63,6 +63,41 @@ def test_warp_with_given_matrices_byte_exact(ctx, pkg, oracle):
         assert np.array_equal(cards[i], want), (i, int((cards[i] != want).sum()))
 
 
+def test_warp_generic_path_matrices_byte_exact(ctx, pkg, oracle):
+    """Quads whose strips do not fit the staged window (rotation, zoom, a side collapsed towards a
+    point, a self-crossing quad whose W changes sign inside the card) take k_warp's generic path;
+    tiny far-away quads leave the card mostly outside the frame (BORDER_CONSTANT 0)."""
+    frame = oracle.synth_frame(SEED, 3)[0]
+    dst = np.array([0, 0, 427, 0, 0, 269, 427, 269], np.float32)
+    cx, cy = 320.0, 240.0
+
+    def quad(angle_deg, sx, sy, skew=(0, 0, 0, 0, 0, 0, 0, 0)):
+        a = np.deg2rad(angle_deg)
+        pts = []
+        for ux, uy in ((-1, -1), (1, -1), (-1, 1), (1, 1)):  # tl, tr, bl, br
+            x, y = ux * sx, uy * sy
+            pts += [cx + x * np.cos(a) - y * np.sin(a), cy + x * np.sin(a) + y * np.cos(a)]
+        return (np.array(pts) + np.array(skew)).astype(np.float32)
+
+    quads = [
+        quad(30, 213, 134), quad(90, 213, 134), quad(-135, 150, 100), quad(7, 213, 134),
+        quad(0, 330, 250),                       # zoom out: 1.55 source px per card px
+        quad(0, 600, 400),                       # card far larger than the frame
+        quad(0, 20, 12),                         # strong zoom in
+        quad(0, 213, 134, (0, 0, -400, 0, 0, 0, 0, 0)),      # top edge collapsed towards its left end
+        quad(0, 213, 134, (430, 0, -430, 0, 0, 0, 0, 0)),    # tl/tr swapped: self-crossing quad
+        quad(15, 213, 134, (-300, -260, -300, -260, -300, -260, -300, -260)),  # rotated and mostly outside
+    ]
+    mats = np.stack([oracle.calc_persp_transform(q, dst) for q in quads])
+    n = len(quads)
+    frames = np.repeat(frame[None], n, axis=0)
+    cards = np.full((n, 270, 428), 0xA5, np.uint8)
+    ctx.warp_perspective(frames, n, mats, cards)
+    for i in range(n):
+        want = oracle.warp_perspective(frame, mats[i])
+        assert np.array_equal(cards[i], want), (i, int((cards[i] != want).sum()))
+
+
 def test_scan_prewarped_cards(ctx, pkg, oracle):
     """BASELINE configs[2]: vseg/hseg/categorise on pre-warped 428x270 crops."""
     n = 40
