@@ -45,9 +45,10 @@ constexpr int kTiles = kTilesX * kTilesY;                 // 21
 constexpr int LW = 128;     // LDS window row stride (bytes)
 constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
 #ifndef DMZ_WARP_LH
-#define DMZ_WARP_LH 144
+#define DMZ_WARP_LH 136
 #endif
-constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at 1.5 source px per card px, plus slack
+constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at up to 1.47 source px per card px; with the row
+                                 // records the workgroup uses 20,288 B of LDS: eight per CU
 constexpr int kStagePasses = LH / 8;
 
 __device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
