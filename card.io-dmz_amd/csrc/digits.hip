@@ -26,6 +26,11 @@
 
 #include "dmz_hip_internal.h"
 
+// developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
+#ifndef DMZ_LDS_PAD
+#define DMZ_LDS_PAD 0
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restr
 
 void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw, const uint8_t *cards,
                        size_t card_stride, int n, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_digits, dim3(n), dim3(DG_THREADS), 0, s, weights, hidw, cards, card_stride, n,
+  hipLaunchKernelGGL(k_digits, dim3(n), dim3(DG_THREADS), DMZ_LDS_PAD, s, weights, hidw, cards, card_stride, n,
                      results);
 }
 

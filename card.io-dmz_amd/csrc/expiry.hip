@@ -27,6 +27,11 @@
 
 #include "dmz_hip_internal.h"
 
+// developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
+#ifndef DMZ_LDS_PAD
+#define DMZ_LDS_PAD 0
+#endif
+
 namespace {
 
 constexpr int CW = DMZ_CARD_WIDTH, CH = DMZ_CARD_HEIGHT;
@@ -180,6 +185,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 // the int16 samples, which is what buys the occupancy for this latency-bound list logic.
 // ---------------------------------------------------------------------------------------------
 // developer ablation (tools/ablate.sh): -DDMZ_XSEG_STOP=k returns after phase k
+#ifndef DMZ_XSEG_WAVES
+#define DMZ_XSEG_WAVES 3
+#endif
 #ifndef DMZ_XSEG_STOP
 #define DMZ_XSEG_STOP 99
 #endif
@@ -201,14 +209,17 @@ struct SegLds {
       int gstart[66];
     } a;
     struct {                             // per group
-      int tile[3 * 21 * 19];             // thresholded tiles of optimize_character_rects
+      unsigned char tile[3 * 21 * 19 + 3];  // thresholded tiles of optimize_character_rects
     } b;
   } u;
-  int gL[64], gW[64];                    // surviving local groups
-  int rL[64], rS[64];                    // regridded rects of the current group
-  int cLeft[64], cTop[64];               // optimised character rects of the current group
-  int okeep[64], oLeft[64], oTop[64];
-  int cmax[64], csum[64];
+  // 16-bit: positions and widths < 432, sums of at most 21 bytes (the workgroup's LDS decides how
+  // many stripes a CU holds, and the kernel is latency-bound)
+  short gL[64], gW[64];                  // surviving local groups
+  int rS[64];                            // sums of the regridded rects of the current group
+  short rL[64];                          // their left edges
+  short cLeft[64], cTop[64];             // optimised character rects of the current group
+  short okeep[64], oLeft[64], oTop[64];
+  short cmax[64], csum[64];
 };
 
 // four |p[c+1] - p[c-1]| of dword d of a row (prev / cur / next = dwords d-1, d, d+1), column index
@@ -263,7 +274,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-__global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
+__global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
                                                       const uint8_t *__restrict__ cards, size_t card_stride, int n,
                                                       const dmz_hip_frame_result *__restrict__ results,
                                                       const dmz_hip_expiry_result *__restrict__ er,
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(64, 2) void k_expiry_seg(const float *__restrict__ 
     const int ciw = cw + 4, cih = 17 + 4;
     {
       const int sl = lane / 21, c = lane - sl * 21;
-      int *tile = L.u.b.tile;  // [3][21][19]
+      unsigned char *tile = L.u.b.tile;  // [3][21][19]
       for (int b0 = rs; b0 < re; b0 += 3) {
         const int k = b0 + sl;
         const bool have = sl < 3 && k < re;
@@ -1106,8 +1117,11 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_model(const float *__r
 }  // namespace
 
 int dmz_configure_expiry(void) {
+#ifndef DMZ_XCAT_PAD  /* developer ablation: extra dynamic LDS = fewer workgroups per CU */
+#define DMZ_XCAT_PAD 0
+#endif
   hipError_t e = hipFuncSetAttribute((const void *)k_expiry_cat, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(CatLds));
+                                     (int)sizeof(CatLds) + DMZ_XCAT_PAD);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute((const void *)k_expiry_model, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CatLds));
   return (int)e;
@@ -1117,10 +1131,10 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
                        const uint8_t *cards, size_t card_stride, int n, const dmz_hip_frame_result *results,
                        DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid) {
   hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
-  hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), 0, s, weights, xw, cards, card_stride, n, results,
+  hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
                      out, stage);
   if (mid) (void)hipEventRecord(mid, s);
-  hipLaunchKernelGGL(k_expiry_cat, dim3((unsigned)n), dim3(XC_THREADS), sizeof(CatLds), s, weights, xw, tables, cards,
+  hipLaunchKernelGGL(k_expiry_cat, dim3((unsigned)n), dim3(XC_THREADS), sizeof(CatLds) + DMZ_XCAT_PAD, s, weights, xw, tables, cards,
                      card_stride, n, results, stage, out);
 }
 

@@ -30,6 +30,11 @@
 
 #include "dmz_hip_internal.h"
 
+// developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
+#ifndef DMZ_LDS_PAD
+#define DMZ_LDS_PAD 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
 
 void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
                      int n, int only_warped, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), 0, s, weights, cards, card_stride, n,
+  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, cards, card_stride, n,
                      only_warped, results);
 }
 
