@@ -15,9 +15,10 @@
 // the row only (M0*x + M1*y + M2, ...) is computed once per workgroup and broadcast from LDS.
 // What is left per pixel is what exactness needs -- the kernel is VALU-issue bound (fp64 and
 // integer instructions issue at the same rate on gfx950):
-//   * 32/W: the IEEE-exact v_rcp_f64 + fma sequence the compiler itself emits for an f64
-//     division, without its v_div_scale / v_div_fixup wrapper (quarter-rate instructions
-//     that are the identity for |W| in [2^-500, 2^500]; anything else takes the full `/`).
+//   * 32/W = 1/(W/32) (the 2^-5 rides, exactly, in the row and column terms): the IEEE-exact
+//     v_rcp_f64 + fma sequence the compiler itself emits for 1.0/x, without its v_div_scale /
+//     v_div_fixup wrapper (quarter-rate instructions that are the identity for the exponents
+//     k_warp_windows admits to the fast path; anything else takes the full `/`).
 //   * cvRound: one fp64 add of 1.5*2^52 (round-to-nearest-even by the adder) instead of
 //     v_rndne_f64 + v_cvt_i32_f64, with the (even) window origin folded into the constant so
 //     the low dword is already window-relative; |f| >= 2^31 takes the saturating conversion.
@@ -33,7 +34,7 @@
 namespace {
 
 // developer ablation (tools/ablate.sh): 1 = cheap coordinates, 3 = no blend, 6 = no stores,
-// 8 = one row record, 9 = no address clamp, 10 = one row pair per wave (block overhead)
+// 8 = one row record, 9 = with an LDS address clamp, 10 = one row pair per wave (block overhead)
 #ifndef DMZ_WARP_ABLATE
 #define DMZ_WARP_ABLATE 0
 #endif
