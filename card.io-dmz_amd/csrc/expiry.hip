@@ -921,29 +921,54 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   }
   __syncthreads();
   if (DMZ_XCAT_STOP == 3) return;
-  // FC 120 -> 176, ReLU
+  // FC 120 -> 176, ReLU and FC 176 -> 10, softmax -- on the matrix core, not for its throughput
+  // (four rows of sixteen are real) but because every lane's weight loads are then independent:
+  // the VALU version walked each output's 120 (176) weights as one dependent fmaf chain fed from L2.
+  // The accumulation order is unchanged: v_mfma_f32_16x16x4_f32 adds its four k in order.
   {
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
     const float *fc1t = xw + dmzx::FC1_T;
-    for (int idx = tid; idx < nd * 176; idx += XC_THREADS) {
-      const int d = idx / 176, j = idx - d * 176;
-      const float *l2 = S.l2 + d * 120;
-      float s = 0.0f;
-#pragma unroll 8
-      for (int i = 0; i < 120; i++) s = fmaf(fc1t[i * 176 + j], l2[i], s);
-      const float v = s + xm[dmzw::X_HB + j];
-      S.l3[idx] = v > 0.0f ? v : 0.0f;
+    float a1[30];
+#pragma unroll
+    for (int ks = 0; ks < 30; ks++) a1[ks] = m16 < nd ? S.l2[m16 * 120 + 4 * ks + kk] : 0.0f;
+    for (int nt = wave; nt < 11; nt += XC_THREADS / 64) {
+      float b1[30];
+#pragma unroll
+      for (int ks = 0; ks < 30; ks++) b1[ks] = fc1t[(4 * ks + kk) * 176 + 16 * nt + m16];
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < 30; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], b1[ks], acc, 0, 0, 0);
+      // D: row (digit) = 4 * kk + v, column (unit) = m16: the digits sit in the lanes with kk == 0
+      if (kk == 0) {
+        const int j = 16 * nt + m16;
+        const float hb = xm[dmzw::X_HB + j];
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          if (v < nd) {
+            const float t = acc[v] + hb;
+            S.l3[v * 176 + j] = t > 0.0f ? t : 0.0f;
+          }
+      }
     }
   }
   __syncthreads();
-  // FC 176 -> 10, softmax
-  if (tid < nd * 10) {
-    const int d = tid / 10, k = tid - d * 10;
-    const float *lw = xm + dmzw::X_LW + k * 176;
-    const float *l3 = S.l3 + d * 176;
-    float s = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < 176; i++) s = fmaf(lw[i], l3[i], s);
-    S.es[d * 16 + k] = expf(s + xm[dmzw::X_LB + k]);
+  if (tid < 64) {
+    const int m16 = tid & 15, kk = tid >> 4;
+    float a2[44], b2[44];
+#pragma unroll
+    for (int ks = 0; ks < 44; ks++) {
+      a2[ks] = m16 < nd ? S.l3[m16 * 176 + 4 * ks + kk] : 0.0f;
+      b2[ks] = m16 < 10 ? xm[dmzw::X_LW + m16 * 176 + 4 * ks + kk] : 0.0f;
+    }
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < 44; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ks], b2[ks], acc, 0, 0, 0);
+    if (kk == 0 && m16 < 10) {
+      const float lb = xm[dmzw::X_LB + m16];
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+        if (v < nd) S.es[v * 16 + m16] = expf(acc[v] + lb);
+    }
   }
   __syncthreads();
   if (tid < nd * 10) {
