@@ -224,44 +224,62 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
   }
 }
 
-// n_vseg.cpp:49-92 on one lane.  The reference's ring buffer entry read at step y is
-// the score of row y - 26, so the window is fed from the score arrays directly; the float
-// add / compare / subtract sequence is literal.  Scores live in arrays padded to 288.
-__device__ void vseg_best_segmentation(const float *__restrict__ vis, const float *__restrict__ amx,
-                                       float *score, int *y_off, int *pattern) {
-  float vsum = 0.0f, asum = 0.0f;
-  float best = 0.0f;
-  int bp = 0, by = 0;
+// n_vseg.cpp:49-92, called by one wave.  The reference's ring buffer entry read at step y is the
+// score of row y - 26, so the window is fed from the score arrays directly.  The two running
+// sums (visa / amex) are literal float add / subtract chains -- one lane each (even lanes replay
+// the visa chain, odd lanes the amex chain, writing the same values) -- and the reference's
+// scan "first strict maximum of v(26), a(26), v(27), a(27), ..." is an arg-max over the 488
+// window sums with ties to the smallest scan position: exact, and parallel over the wave.
+// Scores live in arrays padded to 288; `wsum` is 2 x 256 floats of scratch.
+__device__ __forceinline__ void vseg_best_segmentation(const float *__restrict__ vis,
+                                                       const float *__restrict__ amx, float *wsum,
+                                                       int lane, float *score, int *y_off, int *pattern) {
+  const int p = lane & 1;
+  const float *src = p ? amx : vis;
+  float *w = wsum + p * 256;
+  float sum = 0.0f;
   // rows 0..25: the window is not full yet
   for (int y0 = 0; y0 < 26; y0 += 13) {
-    float v[13], a[13];
+    float v[13];
 #pragma unroll
-    for (int k = 0; k < 13; k++) { v[k] = vis[y0 + k]; a[k] = amx[y0 + k]; }
+    for (int k = 0; k < 13; k++) v[k] = src[y0 + k];
 #pragma unroll
-    for (int k = 0; k < 13; k++) { vsum = vsum + v[k]; asum = asum + a[k]; }
+    for (int k = 0; k < 13; k++) sum = sum + v[k];
   }
-  // rows 26..269 (244 = 4 * 61 steps... processed 4 at a time with the loads up front)
-  for (int y0 = 26; y0 < 270; y0 += 4) {
-    float v[4], a[4], ov[4], oa[4];
+  // rows 26..269, eight at a time with the loads up front
+  for (int y0 = 26; y0 < 270; y0 += 8) {
+    float v[8], ov[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      v[k] = vis[y0 + k]; a[k] = amx[y0 + k];
-      ov[k] = vis[y0 + k - 26]; oa[k] = amx[y0 + k - 26];
+    for (int k = 0; k < 8; k++) {
+      v[k] = src[imin(y0 + k, 287)];
+      ov[k] = src[y0 + k - 26];
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int y = y0 + k;
-      vsum = vsum + v[k];
-      asum = asum + a[k];
-      if (vsum > best) { best = vsum; bp = 1; by = y - 26; }
-      if (asum > best) { best = asum; bp = 2; by = y - 26; }
-      vsum = vsum - ov[k];
-      asum = asum - oa[k];
+    for (int k = 0; k < 8; k++) {
+      sum = sum + v[k];
+      if (y0 + k < 270) w[y0 + k - 26] = sum;
+      sum = sum - ov[k];
     }
   }
-  *score = best;
-  *y_off = by;
-  *pattern = bp;
+  __builtin_amdgcn_wave_barrier();
+  float best = 0.0f;
+  int bo = 0x7fffffff;  // scan position 2 * (y - 26) + (0 visa, 1 amex)
+  for (int o = lane; o < 2 * 244; o += 64) {
+    const float x = wsum[(o & 1) * 256 + (o >> 1)];
+    if (x > best) { best = x; bo = o; }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float ob = __shfl_down(best, d, 64);
+    const int oo = __shfl_down(bo, d, 64);
+    if (ob > best || (ob == best && oo < bo)) { best = ob; bo = oo; }
+  }
+  best = __shfl(best, 0, 64);
+  bo = __shfl(bo, 0, 64);
+  const bool any = bo != 0x7fffffff;
+  *score = any ? best : 0.0f;
+  *y_off = any ? bo >> 1 : 0;
+  *pattern = any ? (bo & 1) + 1 : 0;
 }
 
 // logistic bias + softmax of the rows just evaluated (modelm_befe75da.cpp:1781-1784)
@@ -345,18 +363,19 @@ __global__ __launch_bounds__(VS_THREADS, 7) void k_vseg(const float *__restrict_
   VS_STOP(2, part[0] + part[100])
   vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
   __syncthreads();
-  if (tid == 0) {
+  if (tid < 64) {
     float score;
     int y_off, pattern;
-    vseg_best_segmentation(vis, amx, &score, &y_off, &pattern);
-    // fine pass rows (n_vseg.cpp:140-152)
+    vseg_best_segmentation(vis, amx, part, lane, &score, &y_off, &pattern);  // part is dead here
+    // fine pass rows (n_vseg.cpp:140-152): at most 27 + 16 rows, one lane each
     int ymin = y_off < 8 ? 0 : y_off - 8;
     ymin = imin(270, ymin);
     const int ymax = imin(270, y_off + 27 + 8);
-    int cnt = 0;
-    for (int y = ymin; y < ymax; y++)
-      if (vis[y] == 0.0f && amx[y] == 0.0f) row_y[cnt++] = (unsigned short)y;
-    s_int[0] = cnt;
+    const int y = ymin + lane;
+    const bool fresh = y < ymax && vis[imin(y, 287)] == 0.0f && amx[imin(y, 287)] == 0.0f;
+    const unsigned long long m = __ballot(fresh);
+    if (fresh) row_y[__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)y;
+    if (lane == 0) s_int[0] = __popcll(m);
   }
   __syncthreads();
   VS_STOP(3, s_int[0] + vis[100])
@@ -370,10 +389,11 @@ __global__ __launch_bounds__(VS_THREADS, 7) void k_vseg(const float *__restrict_
     __syncthreads();
   }
   VS_STOP(4, vis[150] + amx[3])
-  if (tid == 0) {
+  if (tid < 64) {
     float score;
     int y_off, pattern;
-    vseg_best_segmentation(vis, amx, &score, &y_off, &pattern);
+    vseg_best_segmentation(vis, amx, part, lane, &score, &y_off, &pattern);
+  if (tid == 0) {
     int flags = in_flags & DMZ_HIP_FLAG_WARPED;
     if (y_off < (DMZ_CARD_HEIGHT - 27) / 2) flags |= DMZ_HIP_FLAG_UPSIDE_DOWN;  // frame.cpp:38
     else if (score > 15.0f) flags |= DMZ_HIP_FLAG_VSEG_OK;                       // frame.cpp:43
@@ -387,6 +407,7 @@ __global__ __launch_bounds__(VS_THREADS, 7) void k_vseg(const float *__restrict_
     res->number_width = 0.0f;
     res->pattern_offset = 0;
     res->number_score = 0.0f;
+  }
   }
   // clear the per-digit outputs (NumberScores::Zero(), n_categorize.cpp:93)
   for (int i = tid; i < 160; i += VS_THREADS) (&res->scores[0][0])[i] = 0.0f;
