@@ -60,6 +60,12 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 // developer ablation (tools/ablate.sh): return after phase k
+#ifndef DMZ_VSEG_BLOCKS  /* workgroups per CU the register allocation aims at */
+#define DMZ_VSEG_BLOCKS 7
+#endif
+#ifndef VS_SCAN_BATCH
+#define VS_SCAN_BATCH 4
+#endif
 #ifndef DMZ_VSEG_STOP
 #define DMZ_VSEG_STOP 99
 #endif
@@ -246,16 +252,16 @@ __device__ __forceinline__ void vseg_best_segmentation(const float *__restrict__
 #pragma unroll
     for (int k = 0; k < 13; k++) sum = sum + v[k];
   }
-  // rows 26..269, eight at a time with the loads up front
-  for (int y0 = 26; y0 < 270; y0 += 8) {
-    float v[8], ov[8];
+  // rows 26..269, VS_SCAN_BATCH at a time with the loads up front
+  for (int y0 = 26; y0 < 270; y0 += VS_SCAN_BATCH) {
+    float v[VS_SCAN_BATCH], ov[VS_SCAN_BATCH];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < VS_SCAN_BATCH; k++) {
       v[k] = src[imin(y0 + k, 287)];
       ov[k] = src[y0 + k - 26];
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < VS_SCAN_BATCH; k++) {
       sum = sum + v[k];
       if (y0 + k < 270) w[y0 + k - 26] = sum;
       sum = sum - ov[k];
@@ -323,7 +329,7 @@ __device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts,
   w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
 }
 
-__global__ __launch_bounds__(VS_THREADS, 7) void k_vseg(const float *__restrict__ wts,
+__global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const float *__restrict__ wts,
                                                       const uint8_t *__restrict__ cards,
                                                       size_t card_stride, int n, int only_warped,
                                                       dmz_hip_frame_result *__restrict__ results) {
