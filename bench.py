@@ -56,14 +56,14 @@ PIPELINE_BYTES = 307200 + 115560 + 1024 + 1592
 # streams, these kernels load 4 B/lane ("uncalibrated" there); WRITE_SIZE matched known byte
 # counts exactly (k_synth_frames: 307,200 B/frame; k_warp: 112.9 KB vs 115,560 B written).
 PMC_TRAFFIC = {
-    "detect": (72062.6 + 124243.3 + 256 + 256) * 1024 / 4096,
-    "geometry": (166.5 + 559.2 + 384 + 1536) * 1024 / 4096,
-    "warp": (362862.6 + 441.5 + 462308.7 + 1413.0) * 1024 / 4096,  # k_warp + k_warp_windows
-    "vseg": (248548.3 + 169313.8) * 1024 / 4096,  # includes the register-spill traffic of the 7-workgroup build
-    "hseg": (32725.1 + 256.0) * 1024 / 4096,
+    "detect": (72059.0 + 124234.8 + 256 + 256) * 1024 / 4096,
+    "geometry": (166.5 + 596.4 + 384 + 1536) * 1024 / 4096,
+    "warp": (361754.3 + 441.5 + 462312.4 + 1413.0) * 1024 / 4096,  # k_warp + k_warp_windows
+    "vseg": (258900.1 + 159331.5) * 1024 / 4096,  # includes the register-spill traffic of the 7-workgroup build
+    "hseg": (32657.4 + 256.0) * 1024 / 4096,
     "digits": (24702.0 + 2902.4) * 1024 / 4096,
-    "expiry_seg": (81034.8 + 60864.8 + 7104.2 + 459.7) * 1024 / 4096,  # k_expiry_stripes + k_expiry_seg
-    "expiry_cat": (5369.0 + 564.5) * 1024 / 4096,
+    "expiry_seg": (81005.4 + 62114.3 + 7104.4 + 7748.8) * 1024 / 4096,  # k_expiry_stripes + k_expiry_seg
+    "expiry_cat": (5400.2 + 564.5) * 1024 / 4096,
 }
 # kernels of comparable size per stage timer: the detect stage is two launches (top/bottom boxes,
 # left/right boxes); the other stages are one kernel (plus helpers below 1 % of the stage).  The
