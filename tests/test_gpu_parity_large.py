@@ -10,20 +10,22 @@ pytestmark = pytest.mark.gpu
 SEED = int(os.environ.get("DMZ_PARITY_SEED", "31337"))
 
 
-def test_1024_frames_against_oracle(ctx, pkg, oracle):
-    n = int(os.environ.get("DMZ_PARITY_FRAMES", "1024"))  # raise for a one-off sweep (the oracle does ~215 frames/s)
-    y = ctx.alloc(n * pkg.FRAME_BYTES)
+def compare_with_oracle(ctx, pkg, oracle, y, n):
+    """Full pipeline on the n frames resident in `y` against the oracle, frame by frame; returns the counters."""
     res = ctx.alloc(n * 1024)
     cards = ctx.alloc(n * pkg.CARD_BYTES)
     exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
-    ctx.synth_frames(SEED, 1000, n, y.ptr)
     ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
     ctx.synchronize()
     got = res.download(pkg.RESULT_DTYPE, n)
     gexp = exp.download(pkg.EXPIRY_DTYPE, n)
     gcards = cards.download(np.uint8).reshape(n, 270, 428)
     frames = y.download(np.uint8).reshape(n, 480, 640)
-    stats = dict(card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
+    for b in (res, cards, exp):
+        b.free()
+    stats = dict(found_all=int(got["found_all"].astype(bool).sum()),
+                 vseg_ok=int(((got["flags"] & pkg.FLAG_VSEG_OK) != 0).sum()) if hasattr(pkg, "FLAG_VSEG_OK") else -1,
+                 card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
                  label_diff=0, flag_diff=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
                  expiry_slash_flips=0, max_expiry_err=0.0)
     for i in range(n):
@@ -72,6 +74,15 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
             continue
         if k:
             stats["max_expiry_err"] = max(stats["max_expiry_err"], float(np.abs(a["scores"] - b["scores"]).max()))
+    return stats
+
+
+def test_1024_frames_against_oracle(ctx, pkg, oracle):
+    n = int(os.environ.get("DMZ_PARITY_FRAMES", "1024"))  # raise for a one-off sweep (the oracle does ~215 frames/s)
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 1000, n, y.ptr)
+    stats = compare_with_oracle(ctx, pkg, oracle, y, n)
+    y.free()
     print("parity stats over %d frames: %s" % (n, stats))
     assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
     assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
@@ -80,5 +91,56 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
     assert stats["label_diff"] <= 2 + n // 4096
     assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 + n // 8192 and stats["max_expiry_err"] <= 1e-4
     assert stats["expiry_frames"] >= n // 4
-    for b in (y, res, cards, exp):
-        b.free()
+
+
+def _fuzz_frame(rng, kind, oracle):
+    """Frames the synthetic corpus never produces: no clean card, or a card in the wrong place."""
+    yy, xx = np.mgrid[0:480, 0:640]
+    if kind >= 5:    # a synthetic card frame shifted off the guide frame, dimmed, with heavy noise
+        f = oracle.synth_frame(SEED + 99, int(rng.integers(0, 1 << 20)))[0].astype(np.int64)
+        f = np.roll(f, (int(rng.integers(-14, 15)), int(rng.integers(-14, 15))), axis=(0, 1))
+        if kind == 6:
+            f = f * rng.uniform(0.35, 0.9) + rng.integers(0, int(rng.integers(2, 60)), (480, 640))
+        return np.clip(f, 0, 255).astype(np.uint8)
+    if kind == 0:    # uniform noise
+        f = rng.integers(0, 256, (480, 640))
+    elif kind == 1:  # low-contrast noise on a ramp
+        f = (xx * rng.uniform(0, 0.3) + yy * rng.uniform(0, 0.3) + rng.integers(0, 40, (480, 640))) % 256
+    elif kind == 2:  # a bright rotated quadrilateral anywhere, noisy background
+        f = rng.integers(0, 60, (480, 640))
+        a = rng.uniform(-0.5, 0.5)
+        cx, cy = rng.uniform(200, 440), rng.uniform(150, 330)
+        u = (xx - cx) * np.cos(a) + (yy - cy) * np.sin(a)
+        v = -(xx - cx) * np.sin(a) + (yy - cy) * np.cos(a)
+        inside = (np.abs(u) < rng.uniform(120, 260)) & (np.abs(v) < rng.uniform(80, 170))
+        f = np.where(inside, 150 + rng.integers(0, 100, (480, 640)), f)
+    elif kind == 3:  # bars and a grid: many strong collinear edges, saturated Sobel responses
+        p = int(rng.integers(6, 40))
+        f = np.where(((xx // p) + (yy // int(rng.integers(6, 40)))) % 2 == 0, 255, 0)
+    else:            # the guide-frame rectangle drawn as thin lines, plus clutter lines
+        f = rng.integers(0, 30, (480, 640))
+        for _ in range(int(rng.integers(3, 12))):
+            if rng.integers(0, 2):
+                f[int(rng.integers(0, 480)), :] = 255
+            else:
+                f[:, int(rng.integers(0, 640))] = 255
+        f[105:375, 106] = 255; f[105:375, 533] = 255; f[105, 106:534] = 255; f[374, 106:534] = 255
+    return f.astype(np.uint8)
+
+
+def test_fuzz_frames_against_oracle(ctx, pkg, oracle):
+    """Noise, ramps, stray quadrilaterals, bar patterns and line clutter through the whole pipeline:
+    detect with thousands of NMS survivors, edges that do not meet, quads that leave the frame, garbage
+    for the scan stages -- every record must still equal the oracle's."""
+    n = int(os.environ.get("DMZ_FUZZ_FRAMES", "210"))
+    rng = np.random.default_rng(int(os.environ.get("DMZ_PARITY_SEED", "31337")) + 7)
+    frames = np.stack([_fuzz_frame(rng, i % 7, oracle) for i in range(n)])
+    y = ctx.alloc(frames.nbytes).upload(frames)
+    stats = compare_with_oracle(ctx, pkg, oracle, y, n)
+    y.free()
+    print("fuzz parity stats over %d frames: %s" % (n, stats))
+    assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
+    assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
+    # garbage cards have flat vseg scores: near-ties (each one asserted to be within 1e-4) are more frequent here
+    assert stats["ties"] <= 2 + n // 100 and stats["flag_diff"] <= 2 and stats["label_diff"] <= 2
+    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 and stats["max_expiry_err"] <= 1e-4
