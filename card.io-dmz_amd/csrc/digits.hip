@@ -181,18 +181,27 @@ __global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restric
   for (int i = tid; i < 16 * 128; i += DG_THREADS) hist32[i] = 0u;
   __syncthreads();
   // ---- per digit: cross gradient clamped at the 19x27 ROI edge, histogram ----
-  for (int i = tid; i < nd * 513; i += DG_THREADS) {
-    const int d = i / 513, p = i - d * 513;
-    const int r = p / 19, c = p - r * 19;
-    const unsigned char *roi = strip_l + res->offsets[d];
-    const int ru = r > 0 ? r - 1 : r, rd = r < 26 ? r + 1 : r;
-    const int cl = c > 0 ? c - 1 : c, cr = c < 18 ? c + 1 : c;
-    const int nn = roi[ru * DMZ_CARD_WIDTH + c], ww = roi[r * DMZ_CARD_WIDTH + cl],
-              cc = roi[r * DMZ_CARD_WIDTH + c], ee = roi[r * DMZ_CARD_WIDTH + cr],
-              ss = roi[rd * DMZ_CARD_WIDTH + c];
-    const int gv = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
-    eq[d * DG_ESTRIDE + p] = (unsigned char)gv;
-    atomicAdd(&hist32[d * 128 + (gv >> 1)], 1u << ((gv & 1) * 16));  // counts <= 513: no carry
+  // A wave per digit; lane l < 57 owns column l % 19 of rows l / 19, l / 19 + 3, ...: pixel index
+  // p = 57 k + l in step k, so nine steps cover the 513 pixels with no per-pixel division and the
+  // five taps at constant offsets from one address.
+  if (lane < 57) {
+    const int rr = lane / 19, c = lane - 19 * rr;
+    const int cl = c > 0 ? -1 : 0, cr = c < 18 ? 1 : 0;
+    for (int d = wave; d < nd; d += DG_THREADS / 64) {
+      const unsigned char *px = strip_l + res->offsets[d] + rr * DMZ_CARD_WIDTH + c;
+      unsigned char *eqd = eq + d * DG_ESTRIDE + lane;
+      unsigned int *hd = hist32 + d * 128;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int r = 3 * k + rr;
+        const unsigned char *q = px + 3 * k * DMZ_CARD_WIDTH;
+        const int nn = q[r > 0 ? -DMZ_CARD_WIDTH : 0], ww = q[cl], cc = q[0], ee = q[cr],
+                  ss = q[r < 26 ? DMZ_CARD_WIDTH : 0];
+        const int gv = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
+        eqd[57 * k] = (unsigned char)gv;
+        atomicAdd(&hd[gv >> 1], 1u << ((gv & 1) * 16));  // counts <= 513: no carry
+      }
+    }
   }
   __syncthreads();
   DG_STOP(1, eq[0] + hist32[3])
@@ -218,10 +227,12 @@ __global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restric
     h[lane * 4 + 2] = (unsigned short)l2; h[lane * 4 + 3] = (unsigned short)l3;
   }
   __syncthreads();
-  for (int i = tid; i < nd * 513; i += DG_THREADS) {
-    const int d = i / 513, p = i - d * 513;
-    eq[d * DG_ESTRIDE + p] = (unsigned char)hist16[d * 256 + eq[d * DG_ESTRIDE + p]];
-  }
+  if (lane < 57)
+    for (int d = wave; d < nd; d += DG_THREADS / 64) {
+      unsigned char *eqd = eq + d * DG_ESTRIDE + lane;
+#pragma unroll
+      for (int k = 0; k < 9; k++) eqd[57 * k] = (unsigned char)hist16[d * 256 + eqd[57 * k]];
+    }
   __syncthreads();
   DG_STOP(2, eq[0] + eq[512])
   // rows of unused digits (nd = 15) must be finite for the matrix core
