@@ -100,12 +100,10 @@ __device__ float hseg_score(const float *__restrict__ g, int pt, float width, in
     const int cn = nxt < plen ? slot_center(off, nxt, width) : 428;
     const int len = live ? cn - c : 0;
     const float *gp = g + (live ? c : 0);
-    // the first 16 taps are inside every live lane's segment (digit spacing >= 16)
+    // the first 16 taps are inside every live lane's segment (digit spacing >= 16); the sum of a
+    // lane that is not live is discarded below, so it needs no masking here
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const float a = fabsf(gp[j] - HSEG_T(j));
-      s = s + (live ? a : 0.0f);
-    }
+    for (int j = 0; j < 16; j++) s = s + fabsf(gp[j] - HSEG_T(j));
 #pragma unroll
     for (int j = 16; j < 19; j++) {
       const float a = fabsf(gp[j] - HSEG_T(j));
