@@ -312,12 +312,14 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
 #pragma unroll
     for (int t = 0; t < IROWS; t++) {
-      const uint32_t p0 = (uint32_t)__shfl_up((int)c0[t], 1, 64);      // dword d0 - 1 (lane 0: unused)
-      const uint32_t n0s = (uint32_t)__shfl_down((int)c0[t], 1, 64);   // dword d0 + 1 for lanes < 63
-      const uint32_t first1 = (uint32_t)__shfl((int)c1[t], 0, 64);     // dword 64
-      const uint32_t last0 = (uint32_t)__shfl((int)c0[t], 63, 64);     // dword 63
-      const uint32_t p1s = (uint32_t)__shfl_up((int)c1[t], 1, 64);
-      const uint32_t n1 = (uint32_t)__shfl_down((int)c1[t], 1, 64);    // dword d1 + 1 (lane 42: unused)
+      // neighbours by DPP wave shifts (wave_shr:1 = lane - 1, wave_shl:1 = lane + 1) and readlane
+      const int i0 = (int)c0[t], i1 = (int)c1[t];
+      const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(i0, i0, 0x138, 0xf, 0xf, false);   // dword d0 - 1 (lane 0: unused)
+      const uint32_t n0s = (uint32_t)__builtin_amdgcn_update_dpp(i0, i0, 0x130, 0xf, 0xf, false);  // dword d0 + 1 for lanes < 63
+      const uint32_t first1 = (uint32_t)__builtin_amdgcn_readlane(i1, 0);                          // dword 64
+      const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane(i0, 63);                          // dword 63
+      const uint32_t p1s = (uint32_t)__builtin_amdgcn_update_dpp(i1, i1, 0x138, 0xf, 0xf, false);
+      const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(i1, i1, 0x130, 0xf, 0xf, false);   // dword d1 + 1 (lane 42: unused)
       const uint32_t n0 = lane == 63 ? first1 : n0s;
       const uint32_t p1 = lane == 0 ? last0 : p1s;
       *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d0) = scharr_inter4(p0, c0[t], n0, d0);
