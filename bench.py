@@ -1,24 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the card.io-dmz scan hot path on MI355X.
 
-A "step" = one pass of the full per-frame pipeline (detect edges -> rectify card
--> number-row search -> digit segmentation -> digit categorisation -> expiry
-segmentation + categorisation) over one HBM-resident batch of synthetic 640x480
-luma frames (BASELINE.json configs[3]).  `value` = frames/s of the whole job (all ranks), inputs resident
-in HBM when the timed region starts.
+A "step" = one pass of the hot path over one HBM-resident batch of synthetic input.  The default
+workload is BASELINE.json configs[3] (`--config 4` in SURVEY 8(d)'s numbering): the full per-frame
+pipeline (detect edges -> rectify card -> number-row search -> digit segmentation -> digit
+categorisation -> expiry segmentation + categorisation) over 65 536 synthetic 640x480 luma frames.
+`value` = frames/s of the whole job (all ranks), inputs resident in HBM when the timed region starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4}] [--batch B]
 
-N > 1 is launched by the driver as
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-one rank per GPU; frames are sharded (weak scaling: B frames per GPU) and the fixed-size
-result and expiry records of each step are gathered on rank 0 (RCCL sends over xGMI),
-asynchronously: the exchange of step k overlaps the kernels of step k+1 (two alternating
-record buffers), and the timed region ends only when the last gather has completed.
+  --config 2   BASELINE configs[1]: card-edge detection only, 4 096 frames        (dmz_hip_detect_batch)
+  --config 3   BASELINE configs[2]: 65 536 pre-warped 428x270 crops, vseg + hseg + digit CNNs
+                                                                                (dmz_hip_scan_cards_batch)
+  --config 4   BASELINE configs[3]: full pipeline incl. expiry, 65 536 frames    (dmz_hip_pipeline_expiry_batch)
+
+--gpus N > 1 (BASELINE configs[4]): one process per GPU.  Under torch.distributed.run (WORLD_SIZE set)
+the script is a rank; run plainly it starts the N ranks itself -- as a CHILD `python -m
+torch.distributed.run ...` created before this process has touched the GPU -- and exits with the
+child's code.  Frames are sharded by contiguous ranges (weak scaling: B frames per GPU; at N > 1 the
+default B is 131 072, i.e. the 1 048 576-frame corpus of configs[4] at N = 8) and the fixed-size
+result / expiry records of each step are gathered on rank 0 (RCCL sends over xGMI), asynchronously:
+the exchange of step k overlaps the kernels of step k+1 (two alternating record buffers), and the
+timed region ends only when the last gather has completed.
+
+--dry-run: no device; the ranks run the same shard / step / gather / timing code on CPU tensors
+over gloo with records filled by a rank-and-step pattern, and rank 0 checks what it gathered.  It
+exists so that the N > 1 launch and exchange logic is covered by the CPU test suite.
 """
 import argparse
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +46,7 @@ import __graft_entry__ as entry  # noqa: E402
 SEED = 0xCA4D10
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # vector == f32-MFMA peak
-# ALGORITHMIC bytes / flops per frame and per kernel (DESIGN.md "Kernels and rooflines").
-# The pipeline total is SURVEY 8(d)'s 423,784 B/frame: 307,200 read + 115,560 card written
-# + 1,024 result record.
+# ALGORITHMIC bytes / flops per frame and per kernel.
 ALGO = {
     #            bytes/frame                flop/frame
     "detect":   (307200 + 64,               2 * 2.2e6 + 1.2e6),
@@ -49,44 +62,161 @@ ALGO = {
     "expiry_seg": (92 * 428 + 3 * 23 * 428 + 1592, 1.5e5),
     "expiry_cat": (4 * 176 + 160,           0.6 * 4 * 2 * 1.27e6),
 }
-PIPELINE_BYTES = 307200 + 115560 + 1024 + 1592
-# HBM traffic per frame (bytes) from the committed PMC passes profiles/r1_v4_pmc_{FETCH,WRITE}_SIZE_*.txt
-# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, KB per dispatch / 4096 frames).
-# FETCH_SIZE is NOT doubled: the guide's x2 gfx950 correction is calibrated for 16 B/lane
-# streams, these kernels load 4 B/lane ("uncalibrated" there); WRITE_SIZE matched known byte
-# counts exactly (k_synth_frames: 307,200 B/frame; k_warp: 112.9 KB vs 115,560 B written).
-PMC_TRAFFIC = {
-    "detect": (72059.0 + 124234.8 + 256 + 256) * 1024 / 4096,
-    "geometry": (166.5 + 596.4 + 384 + 1536) * 1024 / 4096,
-    "warp": (361754.3 + 441.5 + 462312.4 + 1413.0) * 1024 / 4096,  # k_warp + k_warp_windows
-    "vseg": (258900.1 + 159331.5) * 1024 / 4096,  # includes the register-spill traffic of the 7-workgroup build
-    "hseg": (32657.4 + 256.0) * 1024 / 4096,
-    "digits": (24702.0 + 2902.4) * 1024 / 4096,
-    "expiry_seg": (81005.4 + 62114.3 + 7104.4 + 7748.8) * 1024 / 4096,  # k_expiry_stripes + k_expiry_seg
-    "expiry_cat": (5400.2 + 564.5) * 1024 / 4096,
+# kernels behind each stage timer (rocprofv3 names, template arguments stripped); the first one is
+# the stage's main kernel, the others are helpers below 1 % of the stage
+STAGE_KERNELS = {
+    "detect": ("k_detect_walk",), "geometry": ("k_homography", "k_geometry"),
+    "warp": ("k_warp", "k_warp_windows"), "vseg": ("k_vseg",), "hseg": ("k_hseg",),
+    "digits": ("k_digits",), "expiry_seg": ("k_expiry_seg", "k_expiry_stripes", "k_expiry_slash"),
+    "expiry_cat": ("k_expiry_cat",),
 }
-# kernels of comparable size per stage timer: the detect stage is two launches (top/bottom boxes,
-# left/right boxes); the other stages are one kernel (plus helpers below 1 % of the stage).  The
-# roofline object is for the largest single kernel, so stages are ranked by time per launch.
-LAUNCHES = {"detect": 2}
+# algorithmic bytes per unit of each configuration
+CONFIGS = {
+    2: dict(name="configs[1]", unit="frames", batch=4096, bytes=307200 + 80,
+            metric="frames/sec card-edge detection only (640x480)",
+            workload="detect only (Sobel-7 + adaptive Canny + gated Hough + corner geometry), BASELINE configs[1]",
+            stages=("detect", "geometry")),
+    3: dict(name="configs[2]", unit="crops", batch=65536, bytes=115560 + 1024,
+            metric="crops/sec digit pass on pre-warped 428x270 cards",
+            workload="vseg + hseg + 3 digit CNNs on pre-warped 428x270 crops, BASELINE configs[2]",
+            stages=("vseg", "hseg", "digits")),
+    4: dict(name="configs[3]", unit="frames", batch=65536, bytes=307200 + 115560 + 1024,
+            metric="frames/sec full scan pipeline (640x480)",
+            workload="full pipeline detect->warp->vseg->hseg->digits->expiry, BASELINE configs[3]",
+            stages=tuple(ALGO)),
+}
+FRAMES_PER_GPU_MULTI = 131072  # 8 GPUs x 131 072 = the 1 048 576-frame corpus of BASELINE configs[4]
 
 
-def cpu_baseline(orc_mod, frames, budget_s=12.0):
-    """The CPU oracle (a port of the reference algorithm, oracle/*.c) timed on ONE host
-    core over a bounded sample of the same frames."""
-    o = orc_mod.Oracle()
+# ---------------------------------------------------------------------------------------------
+# measured HBM traffic per kernel, from the committed PMC passes in profiles/
+# ---------------------------------------------------------------------------------------------
+def load_pmc_traffic():
+    """{kernel base name: (fetch bytes, write bytes) per frame} from the PMC summaries named by
+    profiles/CURRENT (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB per dispatch over
+    a batch given in the file name).  FETCH_SIZE is doubled: on gfx950 it tallies 128-byte requests
+    at 64 bytes (MI355X_MICROARCH.md, HBM section); k_detect_walk, whose reads are known exactly
+    (rows x boxes x 128-byte lines), calibrates the doubled figure to 0.2 %.  WRITE_SIZE matches
+    known byte counts as reported (k_synth_frames: 307 200 B per frame)."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        tag = open(os.path.join(pdir, "CURRENT")).read().split()[0]
+    except OSError:
+        return None, None
+    out = {}
+    for counter, slot, mul in (("FETCH_SIZE", 0, 2.0), ("WRITE_SIZE", 1, 1.0)):
+        files = glob.glob(os.path.join(pdir, "%s_pmc_%s_batch*.txt" % (tag, counter)))
+        if not files:
+            return None, tag
+        m = re.search(r"batch(\d+)\.txt$", files[0])
+        b0 = int(m.group(1))
+        for line in open(files[0]):
+            if line.startswith("#") or "dispatches=" not in line:
+                continue
+            name = line[:line.index("dispatches=")].strip().split("<")[0].split("(")[0]
+            mean_kb = float(re.search(r"mean=([0-9.]+)", line).group(1))
+            ent = out.setdefault(name, [0.0, 0.0])
+            ent[slot] += mul * mean_kb * 1024.0 / b0  # template instances of one kernel add up
+    return out, tag
+
+
+def stage_traffic(pmc, stage):
+    """(fetch, write) bytes per frame of all kernels behind a stage timer, or None."""
+    if not pmc:
+        return None
+    f = w = 0.0
+    hit = False
+    for k in STAGE_KERNELS[stage]:
+        if k in pmc:
+            hit = True
+            f += pmc[k][0]
+            w += pmc[k][1]
+    return (f, w) if hit else None
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a port of the reference algorithm, oracle/*.c), one process per core
+# ---------------------------------------------------------------------------------------------
+_cpu_barrier = None
+
+
+def _cpu_init(barrier):
+    global _cpu_barrier
+    _cpu_barrier = barrier
+
+
+def _cpu_worker(job):
+    wid, config, first, nframes, budget_s = job
+    orc = entry.load_oracle()
+    o = orc.Oracle()
+    if config == 3:
+        items = [o.synth_card(SEED, first + i)[0] for i in range(nframes)]
+    else:
+        items = [o.synth_frame(SEED, first + i)[0] for i in range(nframes)]
+    _cpu_barrier.wait()
     t0 = time.perf_counter()
     done = 0
-    for f in frames:
-        res, card = o.scan_frame(f, want_card=True)
-        o.scan_card_expiry(card, res)
+    while True:
+        it = items[done % nframes]
+        if config == 2:
+            o.detect_edges(it)
+        elif config == 3:
+            o.scan_card_image(it)
+        else:
+            res, card = o.scan_frame(it, want_card=True)
+            o.scan_card_expiry(card, res)
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the benchmark's synthetic 640x480 frames, full pipeline incl. expiry, 1 thread, %.1f s"
-                      % (done, dt)}
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(config, budget_s=3.0, frames_per_worker=48):
+    """Runs BEFORE this process touches the GPU (the workers are forked)."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0))
+    ctx = mp.get_context("fork")
+    barrier = ctx.Barrier(cores)
+    with ctx.Pool(cores, initializer=_cpu_init, initargs=(barrier,)) as pool:
+        res = pool.map(_cpu_worker, [(w, config, w * frames_per_worker, frames_per_worker, budget_s)
+                                     for w in range(cores)], chunksize=1)
+    total = sum(d for d, _ in res)
+    wall = max(t for _, t in res)
+    per_core = float(np.mean([d / t for d, t in res]))
+    unit = CONFIGS[config]["unit"]
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(total / wall, 1), "unit": unit + "/s", "cores": cores, "kind": "port",
+            "per_core": round(per_core, 1), "cpu": model,
+            "sample": "%d %s of the benchmark corpus per process (indices [%d w, %d w + %d), cycled), "
+                      "%s, one process per host core (%d), %.1f s wall, %.0f s of CPU work"
+                      % (frames_per_worker, unit, frames_per_worker, frames_per_worker, frames_per_worker,
+                         CONFIGS[config]["workload"], cores, wall, sum(t for _, t in res))}
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 run plainly: start the ranks as a child process before anything here touches the GPU
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -94,74 +224,123 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="units (frames / crops) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no device: shard / gather / timing logic on CPU over gloo")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing above has initialised the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; run `python bench.py --gpus %d` (it starts its own ranks) or "
+                 "`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py "
+                 "--gpus %d ...`" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+
+    cfg = CONFIGS[args.config]
+    B = args.batch or (cfg["batch"] if world == 1 or args.config != 4 else FRAMES_PER_GPU_MULTI)
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not args.dry_run:
+        cpu = cpu_baseline(args.config)  # forks: must precede the first GPU call of this process
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL on ROCm
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl")  # RCCL on ROCm
     pkg = entry.load_package()
     from dmz_amd import sharding
-    ctx = pkg.Context(dev.index)  # raises without the HIP library / a GPU: no fallback
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
 
-    B = args.batch
-    frames = torch.empty((B, pkg.FRAME_H, pkg.FRAME_W), dtype=torch.uint8, device=dev)
-    cards = torch.empty((B, pkg.CARD_H, pkg.CARD_W), dtype=torch.uint8, device=dev)
     XB = pkg.EXPIRY_DTYPE.itemsize
+    with_expiry = args.config == 4
+    if args.dry_run:
+        dev = torch.device("cpu")
+        ctx = None
+    else:
+        torch.cuda.set_device(local_rank if world > 1 else 0)
+        dev = torch.device("cuda", local_rank if world > 1 else 0)
+        ctx = pkg.Context(dev.index)  # raises without the HIP library / a GPU: no fallback
+        stream = torch.cuda.current_stream(dev)
+        ctx.set_stream(stream.cuda_stream)
+
     nbuf = 2 if world > 1 else 1  # alternate record buffers so that a gather can overlap the next step
     results_b = [torch.zeros((B, 1024), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    expiry_b = [torch.zeros((B, XB), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    results, expiry = results_b[0], expiry_b[0]
+    expiry_b = [torch.zeros((B, XB), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if with_expiry else None
     gatherer = sharding.RootGatherer(world) if world > 1 else None
     # every rank scans its own contiguous slice of the synthetic corpus (weak scaling:
-    # the corpus is world*B frames, rank g owns [g*B, (g+1)*B))
+    # the corpus is world*B units, rank g owns [g*B, (g+1)*B))
     lo, hi = sharding.shard_range(world * B, rank, world)
     assert hi - lo == B
-    ctx.synth_frames(SEED, lo, B, frames)
-    torch.cuda.synchronize(dev)
+    frames = cards = None
+    if ctx is not None:
+        if args.config != 3:
+            frames = torch.empty((B, pkg.FRAME_H, pkg.FRAME_W), dtype=torch.uint8, device=dev)
+            ctx.synth_frames(SEED, lo, B, frames)
+        if args.config != 2:
+            cards = torch.empty((B, pkg.CARD_H, pkg.CARD_W), dtype=torch.uint8, device=dev)
+        if args.config == 3:
+            ctx.synth_cards(SEED, lo, B, cards)
+        torch.cuda.synchronize(dev)
+
+    def hot_path(k):
+        if ctx is None:  # dry run: a pattern rank 0 can verify after the gather
+            results_b[k].fill_((rank * 16 + step_no[0]) & 255)
+            if with_expiry:
+                expiry_b[k].fill_((rank * 16 + step_no[0] + 7) & 255)
+        elif args.config == 2:
+            ctx.detect(frames, B, results_b[k])
+        elif args.config == 3:
+            ctx.scan_cards(cards, B, results_b[k], only_warped=False)
+        else:
+            ctx.pipeline_expiry(frames, B, results_b[k], expiry_b[k], cards)
 
     step_no = [0]
+    gathered = [None] * (2 * nbuf)
 
     def step():
         k = step_no[0] % nbuf
         step_no[0] += 1
         if world > 1:
             gatherer.wait(slots=(2 * k, 2 * k + 1))  # only the gathers that still read this pair of buffers
-        ctx.pipeline_expiry(frames, B, results_b[k], expiry_b[k], cards)
+        hot_path(k)
         if world > 1:
-            gatherer.submit(results_b[k], slot=2 * k)
-            gatherer.submit(expiry_b[k], slot=2 * k + 1)
+            gathered[2 * k] = gatherer.submit(results_b[k], slot=2 * k)
+            if with_expiry:
+                gathered[2 * k + 1] = gatherer.submit(expiry_b[k], slot=2 * k + 1)
+
+    def sync():
+        if ctx is not None:
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         gatherer.wait()
-    torch.cuda.synchronize(dev)
+    sync()
     if world > 1:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
+    if ctx is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
     for _ in range(args.steps):
         step()
     if world > 1:
         gatherer.wait()  # the timed region includes the last exchange
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
+    if ctx is not None:
+        ev1.record(stream)
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -169,40 +348,66 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = ev0.elapsed_time(ev1) if ctx is not None else elapsed * 1e3
+
+    if args.dry_run:
+        ok = True
+        if rank == 0 and world > 1:
+            last = (step_no[0] - 1) % nbuf
+            got = gathered[2 * last].view(world, B, 1024)
+            for g in range(world):
+                ok = ok and bool((got[g] == ((g * 16 + step_no[0]) & 255)).all())
+            if with_expiry:
+                gx = gathered[2 * last + 1].view(world, B, XB)
+                for g in range(world):
+                    ok = ok and bool((gx[g] == ((g * 16 + step_no[0] + 7) & 255)).all())
+        if rank == 0:
+            print(json.dumps({"metric": cfg["metric"], "dry_run": True, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "frames_per_gpu": B, "gather_ok": ok,
+                              "shard": [lo, hi], "backend": "gloo" if world > 1 else "none"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
 
     # per-kernel durations with hipEvents on the launch stream (untimed extra steps)
     ctx.set_profiling(True)
     ctx.stage_times(reset=True)
     prof_steps = 2
     for _ in range(prof_steps):
-        ctx.pipeline_expiry(frames, B, results, expiry, cards)
+        hot_path(0)
     stage = ctx.stage_times(reset=True)
     ctx.set_profiling(False)
 
     if rank == 0:
+        results = results_b[0]
         res = results.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
-        gates = {
-            "found_all": float((res["found_all"] != 0).mean()),
-            "vseg_ok": float(((res["flags"] & pkg.FLAG_VSEG_OK) != 0).mean()),
-            "usable": float(((res["flags"] & pkg.FLAG_USABLE) != 0).mean()),
-        }
-        ex = expiry.cpu().numpy().view(pkg.EXPIRY_DTYPE).reshape(-1)
-        gates["expiry_group_found"] = float((ex["n_found"] > 0).mean())
-        gates["expiry_categorised"] = float(((ex["categorised"] != 0) & (ex["n_groups"] > 0)).mean())
-        gates["expiry_groups_per_frame"] = float(ex["n_groups"].mean())
+        gates = {"found_all": float((res["found_all"] != 0).mean())} if args.config != 3 else {}
+        if args.config != 2:
+            gates["vseg_ok"] = float(((res["flags"] & pkg.FLAG_VSEG_OK) != 0).mean())
+            gates["usable"] = float(((res["flags"] & pkg.FLAG_USABLE) != 0).mean())
+        if with_expiry:
+            ex = expiry_b[0].cpu().numpy().view(pkg.EXPIRY_DTYPE).reshape(-1)
+            gates["expiry_group_found"] = float((ex["n_found"] > 0).mean())
+            gates["expiry_categorised"] = float(((ex["categorised"] != 0) & (ex["n_groups"] > 0)).mean())
+            gates["expiry_groups_per_frame"] = float(ex["n_groups"].mean())
+        pmc, pmc_tag = load_pmc_traffic()
         per_stage = {}
         for name, (ms, cnt) in stage.items():
             if cnt == 0:
                 continue
             avg_ms = ms / prof_steps  # all launches of the stage in one step
             by, fl = ALGO[name]
-            per_stage[name] = {
-                "ms_per_step": round(avg_ms, 4),
-                "GBps": round(by * B / (avg_ms * 1e-3) / 1e9, 2),
-                "TFLOPs": round(fl * B / (avg_ms * 1e-3) / 1e12, 3),
-            }
-        dom = max(per_stage, key=lambda k: per_stage[k]["ms_per_step"] / LAUNCHES.get(k, 1))
+            ent = {"ms_per_step": round(avg_ms, 4),
+                   "GBps": round(by * B / (avg_ms * 1e-3) / 1e9, 2),
+                   "TFLOPs": round(fl * B / (avg_ms * 1e-3) / 1e12, 3)}
+            tr = stage_traffic(pmc, name)
+            if tr is not None:
+                ent["hbm_fetch_B_per_unit"] = round(tr[0])
+                ent["hbm_write_B_per_unit"] = round(tr[1])
+                ent["traffic_over_algorithmic"] = round((tr[0] + tr[1]) / by, 3)
+            per_stage[name] = ent
+        dom = max(per_stage, key=lambda k: per_stage[k]["ms_per_step"])
         hbm_frac = per_stage[dom]["GBps"] / HBM_PEAK_GBPS
         fl_frac = per_stage[dom]["TFLOPs"] / FP32_PEAK_TFLOPS
         if hbm_frac >= fl_frac:
@@ -211,18 +416,28 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": per_stage[dom]["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(fl_frac, 5), "traffic": None}
-        roof["kernel"] = dom
-        roof["launch_ms"] = round(per_stage[dom]["ms_per_step"] / LAUNCHES.get(dom, 1), 4)
-        # bytes per launch, from profiles/ (see PMC_TRAFFIC)
-        roof["traffic"] = round(PMC_TRAFFIC[dom] * B / LAUNCHES.get(dom, 1)) if PMC_TRAFFIC[dom] is not None else None
+        roof["kernel"] = STAGE_KERNELS[dom][0]
+        roof["launch_ms"] = per_stage[dom]["ms_per_step"]
+        roof["algorithmic_bytes_per_launch"] = ALGO[dom][0] * B
+        tr = stage_traffic(pmc, dom)
+        if tr is not None:
+            # HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes, scaled to this batch
+            roof["traffic"] = round((tr[0] + tr[1]) * B)
+            roof["traffic_over_algorithmic"] = round((tr[0] + tr[1]) / ALGO[dom][0], 3)
+            roof["traffic_source"] = "profiles/%s_pmc_{FETCH,WRITE}_SIZE_*.txt (FETCH_SIZE doubled: gfx950 correction)" % pmc_tag
         value = world * B * args.steps / elapsed
-        roof["pipeline_GBps"] = round(value / world * PIPELINE_BYTES / 1e9, 2)
-        roof["pipeline_frac_of_hbm"] = round(value / world * PIPELINE_BYTES / 1e9 / HBM_PEAK_GBPS, 5)
+        roof["pipeline_GBps"] = round(value / world * cfg["bytes"] / 1e9, 2)
+        roof["pipeline_frac_of_hbm"] = round(value / world * cfg["bytes"] / 1e9 / HBM_PEAK_GBPS, 5)
+        if pmc:
+            tot = [stage_traffic(pmc, s) for s in per_stage]
+            if all(t is not None for t in tot):
+                roof["pipeline_traffic_B_per_unit"] = round(sum(t[0] + t[1] for t in tot))
+                roof["pipeline_traffic_over_algorithmic"] = round(sum(t[0] + t[1] for t in tot) / cfg["bytes"], 3)
 
         out = {
-            "metric": "frames/sec full scan pipeline (640x480)",
+            "metric": cfg["metric"],
             "value": round(value, 1),
-            "unit": "frames/s",
+            "unit": cfg["unit"] + "/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -233,19 +448,21 @@ def main():
             "dtype": "u8 (int32 accumulators; f32 model scores; f64 warp coordinates)",
             "data": "synthetic",
             "config": {
-                "workload": "full pipeline detect->warp->vseg->hseg->digits->expiry (BASELINE configs[3]), "
-                            "%d synthetic 640x480 Y frames per GPU resident in HBM" % B,
-                "frames_per_gpu": B,
-                "parallelism": "frame-sharded x%d, asynchronous gather of the 1 KiB result + 1.6 KiB expiry records on rank 0" % world,
+                "workload": "%s, %d synthetic %s per GPU resident in HBM"
+                            % (cfg["workload"], B, "640x480 Y frames" if args.config != 3 else "428x270 card crops"),
+                "baseline_config": cfg["name"],
+                "units_per_gpu": B,
+                "algorithmic_bytes_per_unit": cfg["bytes"],
+                "parallelism": "frame-sharded x%d, asynchronous gather of the 1 KiB result%s records on rank 0"
+                               % (world, " + 1.6 KiB expiry" if with_expiry else ""),
                 "gate_pass_rates": gates,
                 "device_ms_per_step": round(dev_ms / args.steps, 3),
             },
             "roofline": roof,
             "stages": per_stage,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            sample = frames[:2048].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), sample)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

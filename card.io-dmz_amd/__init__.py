@@ -29,6 +29,7 @@ ORIENTATION_LANDSCAPE_RIGHT = 3
 ORIENTATION_LANDSCAPE_LEFT = 4
 
 FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
+SCAN_ONLY_WARPED, SCAN_SKIP_NUMBER = 1, 2
 OPT_TRUNCATE_CORNERS = 1
 OPT_UPSAMPLE = 2
 STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
@@ -248,9 +249,9 @@ class Context:
             self.h, _ptr(plane), frame_stride, row_stride, width, height, n, orientation, options,
             _ptr(results), _ptr(cards), CARD_BYTES))
 
-    def scan_cards(self, cards, n, results, only_warped=False):
-        self._check(self.lib.dmz_hip_scan_cards_batch(self.h, _ptr(cards), CARD_BYTES, n, int(only_warped),
-                                                      _ptr(results)))
+    def scan_cards(self, cards, n, results, only_warped=False, skip_number=False):
+        mode = (SCAN_ONLY_WARPED if only_warped else 0) | (SCAN_SKIP_NUMBER if skip_number else 0)
+        self._check(self.lib.dmz_hip_scan_cards_batch(self.h, _ptr(cards), CARD_BYTES, n, mode, _ptr(results)))
 
     def pipeline(self, y, n, results, cards=None, width=FRAME_W, height=FRAME_H,
                  orientation=ORIENTATION_LANDSCAPE_RIGHT, options=0):
@@ -286,7 +287,12 @@ class Context:
         self._check(self.lib.dmz_hip_ycbcr_to_rgb(self.h, _ptr(y), _ptr(cb), _ptr(cr), n_pixels, channels, _ptr(rgb)))
 
     def scan_sessions(self, results, expiry, n_sessions, frames_per_session, out, scan_expiry=True,
-                      frame_interval_ms=33, now_year=2026, now_month=10, allow_past_expiry=False):
+                      frame_interval_ms=33, now_year=None, now_month=None, allow_past_expiry=False):
+        if now_year is None or now_month is None:  # the reference reads localtime (expiry_categorize.cpp:262-270)
+            import datetime
+            today = datetime.date.today()
+            now_year = today.year if now_year is None else now_year
+            now_month = today.month if now_month is None else now_month
         self._check(self.lib.dmz_hip_scan_sessions_batch(
             self.h, _ptr(results), _ptr(expiry), n_sessions, frames_per_session, int(scan_expiry),
             frame_interval_ms, now_year, now_month, int(allow_past_expiry), _ptr(out)))

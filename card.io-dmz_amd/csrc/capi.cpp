@@ -291,6 +291,9 @@ int stage_in(dmz_hip_context *ctx, dmz_hip_context::Buf &buf, const void *src, s
   int rc = ensure(ctx, buf, bytes);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // a pinned host source is copied truly asynchronously: wait, so that the caller may reuse its buffer as
+  // soon as the call returns (host staging is the PCIe-bound slow path anyway)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *dev = buf.p;
   return DMZ_HIP_OK;
 }
@@ -358,11 +361,15 @@ int run_transform(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_strid
   return DMZ_HIP_OK;
 }
 
-int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n, int only_warped,
+int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n, int mode,
              dmz_hip_frame_result *results) {
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_VSEG);
-    dmz_launch_vseg(ctx->stream, ctx->d_weights, cards, card_stride, n, only_warped, results);
+    dmz_launch_vseg(ctx->stream, ctx->d_weights, cards, card_stride, n, mode, results);
+  }
+  if (mode & DMZ_HIP_SCAN_SKIP_NUMBER) {  // scan_card_image(collect_card_number = false), frame.cpp:49
+    HIP_TRY(ctx, hipGetLastError());
+    return DMZ_HIP_OK;
   }
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_HSEG);
@@ -396,6 +403,12 @@ int run_expiry(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, i
   }
   HIP_TRY(ctx, hipGetLastError());
   return DMZ_HIP_OK;
+}
+
+// bytes spanned by n planes: the last plane ends with its last pixel, not with a whole stride (a host image
+// with an ROI starts inside its buffer: widthStep * height from there would run past the end)
+size_t planes_span(size_t frame_stride, int row_stride, int width, int height, int n) {
+  return frame_stride * (size_t)(n - 1) + (size_t)row_stride * (size_t)(height - 1) + (size_t)width;
 }
 
 int check_frames(dmz_hip_context *ctx, const void *y, size_t frame_stride, int row_stride, int width,
@@ -536,13 +549,14 @@ int dmz_hip_detect_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
   int rc = check_frames(ctx, y, frame_stride, row_stride, width, height, n);
   if (rc) return rc;
   if (!results || (cb == nullptr) != (cr == nullptr)) return fail(ctx, DMZ_HIP_EINVAL, "bad arguments");
+  if (cb && (rc = check_frames(ctx, cb, chroma_frame_stride, chroma_row_stride, width / 2, height / 2, n))) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if ((rc = configure_detection(ctx, width, height, orientation))) return rc;
   const void *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
-  if ((rc = stage_in(ctx, ctx->stage_in, y, frame_stride * (size_t)n, &dy))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, planes_span(frame_stride, row_stride, width, height, n), &dy))) return rc;
   if (cb) {
-    if ((rc = stage_in(ctx, ctx->stage_cb, cb, chroma_frame_stride * (size_t)n, &dcb))) return rc;
-    if ((rc = stage_in(ctx, ctx->stage_cr, cr, chroma_frame_stride * (size_t)n, &dcr))) return rc;
+    if ((rc = stage_in(ctx, ctx->stage_cb, cb, planes_span(chroma_frame_stride, chroma_row_stride, width / 2, height / 2, n), &dcb))) return rc;
+    if ((rc = stage_in(ctx, ctx->stage_cr, cr, planes_span(chroma_frame_stride, chroma_row_stride, width / 2, height / 2, n), &dcr))) return rc;
   }
   const bool res_dev = is_device_ptr(results);
   dmz_hip_frame_result *dres = results;
@@ -572,7 +586,7 @@ int dmz_hip_transform_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t f
     return fail(ctx, DMZ_HIP_EINVAL, "bad card buffer (stride must be >= 115560 and a multiple of 4)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const void *dp = nullptr;
-  if ((rc = stage_in(ctx, ctx->stage_in, plane, frame_stride * (size_t)n, &dp))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, plane, planes_span(frame_stride, row_stride, width, height, n), &dp))) return rc;
   const bool res_dev = is_device_ptr(results), cards_dev = is_device_ptr(cards);
   dmz_hip_frame_result *dres = results;
   uint8_t *dcards = cards;
@@ -600,8 +614,9 @@ int dmz_hip_transform_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t f
 }
 
 int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
-                             int only_warped, dmz_hip_frame_result *results) {
+                             int mode, dmz_hip_frame_result *results) {
   if (!ctx) return DMZ_HIP_EINVAL;
+  if (mode & ~(DMZ_HIP_SCAN_ONLY_WARPED | DMZ_HIP_SCAN_SKIP_NUMBER)) return fail(ctx, DMZ_HIP_EINVAL, "unknown scan mode bits");
   if (!cards || !results || n <= 0 || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
     return fail(ctx, DMZ_HIP_EINVAL, "bad card buffer (stride must be >= 115560 and a multiple of 4)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -617,7 +632,7 @@ int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t 
     HIP_TRY(ctx, hipMemcpyAsync(dres, results, sizeof(dmz_hip_frame_result) * (size_t)n,
                                 hipMemcpyHostToDevice, ctx->stream));
   }
-  if ((rc = run_scan(ctx, (const uint8_t *)dc, card_stride, n, only_warped, dres))) return rc;
+  if ((rc = run_scan(ctx, (const uint8_t *)dc, card_stride, n, mode, dres))) return rc;
   if (!res_dev) {
     HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -640,7 +655,7 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if ((rc = configure_detection(ctx, width, height, orientation))) return rc;
   const void *dy = nullptr;
-  if ((rc = stage_in(ctx, ctx->stage_in, y, frame_stride * (size_t)n, &dy))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, planes_span(frame_stride, row_stride, width, height, n), &dy))) return rc;
   const bool res_dev = is_device_ptr(results);
   const bool cards_dev = cards && is_device_ptr(cards);
   dmz_hip_frame_result *dres = results;
@@ -833,7 +848,7 @@ int dmz_hip_scores_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
   if (roi[2] <= 0 || roi[3] <= 0 || roi[0] < 0 || roi[1] < 0) return fail(ctx, DMZ_HIP_EINVAL, "image too small for the scoring ROI");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const void *dy = nullptr;
-  if ((rc = stage_in(ctx, ctx->stage_in, y, frame_stride * (size_t)n, &dy))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, y, planes_span(frame_stride, row_stride, width, height, n), &dy))) return rc;
   const bool fdev = focus && is_device_ptr(focus), bdev = brightness && is_device_ptr(brightness);
   float *df = focus, *db = brightness;
   if ((focus && !fdev) || (brightness && !bdev)) {
@@ -929,7 +944,7 @@ int dmz_hip_warp_perspective_batch(dmz_hip_context *ctx, const uint8_t *plane, s
     return fail(ctx, DMZ_HIP_EINVAL, "bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const void *dp = nullptr, *dm = nullptr;
-  if ((rc = stage_in(ctx, ctx->stage_in, plane, frame_stride * (size_t)n, &dp))) return rc;
+  if ((rc = stage_in(ctx, ctx->stage_in, plane, planes_span(frame_stride, row_stride, width, height, n), &dp))) return rc;
   if ((rc = stage_in(ctx, ctx->misc, matrices, sizeof(float) * 9 * (size_t)n, &dm))) return rc;
   if ((rc = ensure(ctx, ctx->mats, sizeof(DmzWarpMat) * (size_t)n))) return rc;
   const bool cards_dev = is_device_ptr(cards);

@@ -133,7 +133,7 @@ void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, 
                      int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride);
 void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
-                     int n, int only_warped, dmz_hip_frame_result *results);
+                     int n, int mode /* DMZ_HIP_SCAN_* */, dmz_hip_frame_result *results);
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results);
 void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw /* 3 x [32][320] */,

@@ -331,7 +331,7 @@ __device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts,
 
 __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const float *__restrict__ wts,
                                                       const uint8_t *__restrict__ cards,
-                                                      size_t card_stride, int n, int only_warped,
+                                                      size_t card_stride, int n, int mode,
                                                       dmz_hip_frame_result *__restrict__ results) {
   __shared__ __attribute__((aligned(16))) unsigned char grad[VS_MAXROWS * VS_GSTRIDE];  // 14,144 B
   __shared__ float norm[2 * VS_MAXROWS];
@@ -345,12 +345,21 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   dmz_hip_frame_result *res = results + f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int in_flags = res->flags;
-  if (only_warped && !(in_flags & DMZ_HIP_FLAG_WARPED)) {
+  if ((mode & DMZ_HIP_SCAN_ONLY_WARPED) && !(in_flags & DMZ_HIP_FLAG_WARPED)) {
+    // not rectified: no gate can have passed, whatever the caller's record held
     if (tid == 0) {
+      res->flags = 0;
       res->vseg_score = 0.0f;
       res->vseg_y_offset = 0;
       res->pattern_type = 0;
+      res->n_offsets = 0;
+      res->hseg_score = 0.0f;
+      res->number_width = 0.0f;
+      res->pattern_offset = 0;
+      res->number_score = 0.0f;
     }
+    for (int i = tid; i < 160; i += VS_THREADS) (&res->scores[0][0])[i] = 0.0f;
+    if (tid < 16) { res->digits[tid] = 0; res->offsets[tid] = 0; }
     return;
   }
   const uint8_t *card = cards + (size_t)f * card_stride;
@@ -402,7 +411,8 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   if (tid == 0) {
     int flags = in_flags & DMZ_HIP_FLAG_WARPED;
     if (y_off < (DMZ_CARD_HEIGHT - 27) / 2) flags |= DMZ_HIP_FLAG_UPSIDE_DOWN;  // frame.cpp:38
-    else if (score > 15.0f) flags |= DMZ_HIP_FLAG_VSEG_OK;                       // frame.cpp:43
+    else if (score > 15.0f)                                                      // frame.cpp:43-49
+      flags |= DMZ_HIP_FLAG_VSEG_OK | ((mode & DMZ_HIP_SCAN_SKIP_NUMBER) ? DMZ_HIP_FLAG_USABLE : 0);
     res->vseg_score = score;
     res->vseg_y_offset = y_off;
     res->pattern_type = pattern;
@@ -478,9 +488,9 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
 }  // namespace
 
 void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
-                     int n, int only_warped, dmz_hip_frame_result *results) {
+                     int n, int mode, dmz_hip_frame_result *results) {
   hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, cards, card_stride, n,
-                     only_warped, results);
+                     mode, results);
 }
 
 void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *x, int n, float *out) {

@@ -3,13 +3,17 @@
 // scan/n_vseg.h:14-21, scan/n_hseg.h:13-19, cv/warp.h:20-25, mz.h:19-25.
 //
 // Same names, argument meaning, ownership and (lack of) error codes as the reference, so
-// that an SDK call site relinks against libdmz_host.so unchanged; every function is a
-// batch-of-1 wrapper over the C-ABI of include/dmz_hip.h.  `dmz_context.mz` holds the
+// that an SDK call site RECOMPILES against this header and links libdmz_host.so (source
+// compatibility: the structs below keep the reference's field order, but Eigen and OpenCV
+// types are replaced, so object files built against the reference headers do not relink);
+// every function is a batch-of-1 wrapper over the C-ABI of include/dmz_hip.h.  `dmz_context.mz` holds the
 // dmz_hip_context exactly where the Android flavour keeps its GLES warp context
 // (mz_android.cpp:233-240).  Differences, all forced by dropping Eigen/OpenCV types:
 //   * NumberScores / NumberPredictions are plain arrays (reference: Eigen matrices,
-//     n_categorize.h:14, scan.h:17);
-//   * ExpiryGroupScores is a plain 11 x 10 float array (reference: Eigen, expiry_types.h:47);
+//     n_categorize.h:14, scan.h:17) with the accessors call sites use: scores(i, k),
+//     predictions(i, 0), rows(), cols(), sum(), setZero();
+//   * ExpiryGroupScores is a plain 11 x 10 float array with the same accessors (reference:
+//     Eigen, expiry_types.h:47);
 //     CharacterRect.sum of the groups a frame reports is 0 (the device does not return it and
 //     nothing downstream reads it);
 //   * IplImage is declared here with OpenCV 2.4's field layout (types_c.h:462-507) unless
@@ -21,6 +25,8 @@
 
 #include <stdint.h>
 
+#include <map>
+#include <string>
 #include <vector>
 
 #ifndef __OPENCV_CORE_TYPES_H__
@@ -94,8 +100,29 @@ typedef struct {
   float number_width;
   uint16_t pattern_offset;
 } NHorizontalSegmentation;
-typedef struct { float v[16][10]; } NumberScores;        // row-major, n_categorize.h:14
-typedef struct { long v[16]; } NumberPredictions;        // scan.h:17
+// Eigen::Matrix<float, R, C, RowMajor> as a plain array with the Eigen accessors the SDK call sites use
+template <int R, int C>
+struct DmzScoreMatrix {
+  float v[R][C];
+  float &operator()(int r, int c) { return v[r][c]; }
+  const float &operator()(int r, int c) const { return v[r][c]; }
+  static int rows() { return R; }
+  static int cols() { return C; }
+  void setZero() { for (int r = 0; r < R; r++) for (int c = 0; c < C; c++) v[r][c] = 0.0f; }
+  float sum() const {  // plain row-major order (Eigen's redux order differs in the last ulp)
+    float s = 0.0f;
+    for (int r = 0; r < R; r++) for (int c = 0; c < C; c++) s += v[r][c];
+    return s;
+  }
+};
+typedef DmzScoreMatrix<16, 10> NumberScores;             // row-major, n_categorize.h:14
+struct NumberPredictions {                               // Eigen::Matrix<Index, 16, 1>, scan.h:17
+  long v[16];
+  long &operator()(int r, int = 0) { return v[r]; }
+  const long &operator()(int r, int = 0) const { return v[r]; }
+  static int rows() { return 16; }
+  static int cols() { return 1; }
+};
 
 // ---- scan/expiry_types.h:16-79 ----
 #define kSmallCharacterWidth 9
@@ -112,7 +139,7 @@ enum ExpiryPattern {
   ExpiryPatternMMdMMs20YY,
   ExpiryPatternMMsYYdMMsYY,
 };
-typedef struct { float v[kExpiryMaxValidLength][10]; } ExpiryGroupScores;
+typedef DmzScoreMatrix<kExpiryMaxValidLength, 10> ExpiryGroupScores;
 struct CharacterRect {
   int top;
   int left;
@@ -154,6 +181,19 @@ typedef struct {
   bool torch_is_on;
 } FrameScanResult;
 
+// ---- scan/scan_analytics.h:12-33 (the analytics hook is a counter + ring index in the reference too:
+// scan_analytics.cpp:17-20 records no field) ----
+#define kScanSessionNumFramesStored 20
+typedef struct {
+  uint32_t frame_index;
+  std::map<std::string, std::string> frame_values;
+} ScanFrameAnalytics;
+typedef struct {
+  uint32_t num_frames_scanned;
+  uint8_t frames_ring_start;
+  ScanFrameAnalytics frames_ring[kScanSessionNumFramesStored];
+} ScanSessionAnalytics;
+
 // ---- scan/scan.h:19-48 ----
 typedef struct {
   bool complete;
@@ -166,6 +206,7 @@ typedef struct {
 typedef struct ScannerState {
   uint16_t count15, count16;
   NumberScores aggregated15, aggregated16;
+  ScanSessionAnalytics session_analytics;  // same position as scan/scan.h:38
   ScannerResult successfulCardNumberResult;
   NHorizontalSegmentation mostRecentUsableHSeg;
   NVerticalSegmentation mostRecentUsableVSeg;
@@ -174,7 +215,8 @@ typedef struct ScannerState {
   int expiry_month, expiry_year;
   GroupedRectsList expiry_groups;
   GroupedRectsList name_groups;
-  dmz_context *dmz;  // HIP flavour: the context the frames are scanned on (NULL = process default)
+  // -- end of the reference's fields (scan/scan.h:33-48); appended by the HIP flavour: --
+  dmz_context *dmz;  // the context the frames are scanned on (NULL = the calling thread's default context)
 } ScannerState;
 
 // life cycle (dmz.h:48-57, mz.h:19-25, processor_support.h pattern)
@@ -185,6 +227,17 @@ void *mz_create(void);
 void mz_destroy(void *mz);
 void mz_prepare_for_backgrounding(void *mz);
 int dmz_has_hip_runtime(void);
+// dmz.h:60: "can images be allocated" probe of the reference (cvCreateImage); here of dmz_create_image_8u
+int dmz_has_opencv(void);
+// processor_support.h:59-66.  No NEON / VFP code exists in this flavour (both 0).  The GLES-warp switch
+// of the Android flavour maps onto the HIP warp: dmz_use_gles_warp() reports whether the accelerator
+// rectifies (a HIP device is present and the switch is on); dmz_set_gles_warp(0) is recorded and reported
+// back, but it cannot select a CPU path -- there is none: llcv_unwarp then fails loudly (stderr, output
+// untouched) instead of falling back as mz_android.cpp:8-24 does.
+int dmz_has_neon_runtime(void);
+int dmz_use_vfp3_16(void);
+int dmz_use_gles_warp(void);
+void dmz_set_gles_warp(int newstate);
 
 // detection / transformation (dmz.h:78-96, cv/warp.h:20-25)
 bool dmz_found_all_edges(dmz_edges found_edges);
@@ -231,6 +284,9 @@ void dmz_hip_host_allow_past_expiry(bool allow);
 dmz_point dmz_create_point(float x, float y);
 dmz_rect dmz_create_rect(float x, float y, float w, float h);
 void dmz_rect_get_points(dmz_rect rect, dmz_point points[4]);
+dmz_point dmz_scale_point(const dmz_point src_p, const dmz_rect src_f, const dmz_rect dst_f);
+dmz_rect dmz_guide_frame(FrameOrientation orientation, float preview_width, float preview_height);
+FrameOrientation dmz_opposite_orientation(FrameOrientation orientation);
 bool dmz_passes_luhn_checksum(uint8_t *number_array, uint8_t number_length);
 dmz_card_info dmz_card_info_for_prefix_and_length(uint8_t *number_array, uint8_t number_length,
                                                   bool allow_incomplete_number);

@@ -90,6 +90,22 @@ void mz_prepare_for_backgrounding(void *mz) {
 }
 int dmz_has_hip_runtime(void) { return dmz_hip_device_count() > 0; }
 
+// dmz.cpp:41-47: the reference probes cvCreateImage; this flavour probes its own image allocator
+int dmz_has_opencv(void) {
+  IplImage *probe = dmz_create_image_8u(kCreditCardTargetWidth, kCreditCardTargetHeight, 1);
+  const int rv = probe != NULL;
+  dmz_release_image(&probe);
+  return rv;
+}
+
+// processor_support.cpp:87-118.  No NEON / VFP code paths exist here; the GLES-warp switch of the
+// Android flavour (:95-102) is kept as the "accelerator rectifies" switch of the HIP warp.
+static int g_hip_warp_allowed = 1;
+int dmz_has_neon_runtime(void) { return 0; }
+int dmz_use_vfp3_16(void) { return 0; }
+void dmz_set_gles_warp(int newstate) { g_hip_warp_allowed = 1 & newstate; }
+int dmz_use_gles_warp(void) { return g_hip_warp_allowed && dmz_has_hip_runtime(); }
+
 dmz_context *dmz_context_create(void) {
   dmz_context *dmz = (dmz_context *)calloc(1, sizeof(dmz_context));
   if (!dmz) return NULL;
@@ -119,6 +135,36 @@ void dmz_rect_get_points(dmz_rect rect, dmz_point points[4]) {
   points[1] = dmz_create_point(rect.x + rect.w, rect.y);
   points[2] = dmz_create_point(rect.x, rect.y + rect.h);
   points[3] = dmz_create_point(rect.x + rect.w, rect.y + rect.h);
+}
+// dmz_olm.cpp:20-23
+dmz_point dmz_scale_point(const dmz_point src_p, const dmz_rect src_f, const dmz_rect dst_f) {
+  return dmz_create_point(dst_f.x + (src_p.x - src_f.x) * dst_f.w / src_f.w,
+                          dst_f.y + (src_p.y - src_f.y) * dst_f.h / src_f.h);
+}
+// dmz_olm.cpp:134-164 with dmz_constants.h:10-27: the guide frame is the card-sized hole of the 480 x 640
+// (portrait) / 640 x 480 (landscape) sample, as fractions of the preview
+dmz_rect dmz_guide_frame(FrameOrientation orientation, float preview_width, float preview_height) {
+  const float portrait_h = (float)((480 - kCreditCardTargetWidth) / 2) / (float)480;    // kPortraitHorizontalPercentInset
+  const float portrait_v = (float)((640 - kCreditCardTargetHeight) / 2) / (float)640;   // kPortraitVerticalPercentInset
+  const float landscape_v = (float)((480 - kCreditCardTargetHeight) / 2) / (float)480;  // kLandscapeVerticalPercentInset
+  const float landscape_h = (float)((640 - kCreditCardTargetWidth) / 2) / (float)640;   // kLandscapeHorizontalPercentInset
+  float inset_w = 0.0f, inset_h = 0.0f;
+  if (orientation == FrameOrientationPortrait || orientation == FrameOrientationPortraitUpsideDown) {
+    inset_w = portrait_h * preview_width;
+    inset_h = portrait_v * preview_height;
+  } else if (orientation == FrameOrientationLandscapeLeft || orientation == FrameOrientationLandscapeRight) {
+    inset_w = landscape_v * preview_width;   // sic: the reference pairs the vertical percentage with the width
+    inset_h = landscape_h * preview_height;
+  }
+  return dmz_create_rect(inset_w, inset_h, preview_width - 2.0f * inset_w, preview_height - 2.0f * inset_h);
+}
+// dmz_olm.cpp:166-179
+FrameOrientation dmz_opposite_orientation(FrameOrientation orientation) {
+  // pairs 1 <-> 2 and 3 <-> 4; anything else maps to portrait
+  static const FrameOrientation opposite[5] = {FrameOrientationPortrait, FrameOrientationPortraitUpsideDown,
+                                               FrameOrientationPortrait, FrameOrientationLandscapeLeft,
+                                               FrameOrientationLandscapeRight};
+  return orientation <= 4 ? opposite[orientation] : (FrameOrientation)FrameOrientationPortrait;
 }
 bool dmz_passes_luhn_checksum(uint8_t *number_array, uint8_t number_length) {
   int sum = 0;
@@ -269,6 +315,11 @@ void llcv_unwarp(dmz_context *dmz, IplImage *input, const dmz_point source_point
                  const dmz_rect to_rect, IplImage *output) {
   dmz_hip_context *ctx = hip_of(dmz);
   if (!ctx || !input || !output || !output->imageData) return;
+  if (!g_hip_warp_allowed) {  // dmz_set_gles_warp(0): the reference would fall back to its CPU warp; there is none here
+    fprintf(stderr, "dmz (HIP): llcv_unwarp: the accelerator warp was switched off (dmz_set_gles_warp(0)) and "
+                    "there is no CPU fallback\n");
+    return;
+  }
   if (input->nChannels != 1 || output->nChannels != 1 || output->width != kCreditCardTargetWidth ||
       output->height != kCreditCardTargetHeight || output->widthStep != kCreditCardTargetWidth) {
     fprintf(stderr, "dmz (HIP): llcv_unwarp handles 1-channel 428x270 outputs only\n");
@@ -403,6 +454,8 @@ void scanner_initialize(ScannerState *state) {
 
 void scanner_reset(ScannerState *state) {
   state->count15 = state->count16 = 0;
+  state->session_analytics.num_frames_scanned = 0;  // scan_analytics_init, scan_analytics.cpp:27-30
+  state->session_analytics.frames_ring_start = 0;
   memset(&state->aggregated15, 0, sizeof(NumberScores));
   memset(&state->aggregated16, 0, sizeof(NumberScores));
   state->timeOfCardNumberCompletionInMilliseconds = 0;
@@ -579,7 +632,8 @@ void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_e
   const size_t card_stride = (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight;
   dmz_hip_frame_result r;
   memset(&r, 0, sizeof(r));
-  int rc = dmz_hip_scan_cards_batch(ctx, cards, card_stride, 1, 0, &r);
+  // scan_card_image(y, still_need_to_collect_card_number, ...), scan.cpp:48
+  int rc = dmz_hip_scan_cards_batch(ctx, cards, card_stride, 1, need_number ? 0 : DMZ_HIP_SCAN_SKIP_NUMBER, &r);
   dmz_hip_expiry_result x;
   memset(&x, 0, sizeof(x));
   if (rc == DMZ_HIP_OK && need_expiry) rc = dmz_hip_scan_expiry_batch(ctx, cards, card_stride, 1, &r, &x);  // frame.cpp:71-73
@@ -590,7 +644,15 @@ void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_e
   }
   fill_frame_result(r, result);
   if (need_expiry) fill_expiry_groups(x, &result->expiry_groups);
-  if (result->upside_down || !result->usable) return;  // scan.cpp:51-60
+  if (result->upside_down) return;                     // scan.cpp:49-51
+  {                                                    // scan_analytics_record_frame (scan.cpp:53): frame counter + ring
+    ScanSessionAnalytics *sa = &state->session_analytics;
+    if (sa->num_frames_scanned > kScanSessionNumFramesStored)
+      sa->frames_ring_start = (uint8_t)((sa->num_frames_scanned + 1) % kScanSessionNumFramesStored);
+    sa->frames_ring[sa->num_frames_scanned % kScanSessionNumFramesStored].frame_index = sa->num_frames_scanned;
+    sa->num_frames_scanned += 1;
+  }
+  if (!result->usable) return;                         // scan.cpp:57-59
   if (need_expiry) {                                   // scan.cpp:61-67 + expiry_extract (:332-376)
     state->scan_expiry = true;
     if (!result->expiry_groups.empty()) {

@@ -144,10 +144,16 @@ int dmz_hip_transform_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t f
                             size_t card_stride);
 
 /* Batched scan_card_image number path (frame.h:34, frame.cpp:24-81 as driven by
- * scanner_add_frame_with_expiry scan.cpp:41-50) on n 428x270 cards.
- * only_warped != 0: skip cards whose result lacks DMZ_HIP_FLAG_WARPED. */
+ * scanner_add_frame_with_expiry scan.cpp:41-50) on n 428x270 cards.  `mode` is a bit mask:
+ * DMZ_HIP_SCAN_ONLY_WARPED: skip cards whose result lacks DMZ_HIP_FLAG_WARPED (their scan fields and
+ *   gate flags are cleared);
+ * DMZ_HIP_SCAN_SKIP_NUMBER: scan_card_image(collect_card_number = false), what the reference runs once a
+ *   session's number has been accepted (scan.cpp:43-48): only the vseg search and its gates run, and
+ *   a frame that passes them is usable (frame.cpp:43-49); hseg / digit fields stay zero. */
+#define DMZ_HIP_SCAN_ONLY_WARPED 1
+#define DMZ_HIP_SCAN_SKIP_NUMBER 2
 int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride,
-                             int n, int only_warped, dmz_hip_frame_result *results);
+                             int n, int mode, dmz_hip_frame_result *results);
 
 /* detect -> transform(Y) -> scan for n frames (the cython_dmz/dmz.pyx:379-483
  * call sequence).  cards may be NULL (an internal buffer is used). */

@@ -153,6 +153,7 @@ void orc_best_n_hseg(const uint8_t *strip, int stride, int pattern_type, orc_fra
 void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets, int n,
                        float scores[160]);                                  /* n_categorize.cpp:75-107 */
 void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res); /* frame.cpp:24-81 (number path) */
+void orc_scan_card_image_ex(const uint8_t *card, int stride, int collect_card_number, orc_frame_result *res);
 
 /* ---- expiry path: scan/expiry_seg.cpp, scan/expiry_categorize.cpp.
  * Per-frame part only: segmentation into MM/YY groups and the four digit score rows of each

@@ -281,11 +281,12 @@ class Oracle:
         self.lib.orc_number_scores(_p(strip, _u8p), strip.shape[1], _p(offs, _u16p), int(n), _p(s, _f32p))
         return s
 
-    def scan_card_image(self, card, warped=True):
+    def scan_card_image(self, card, warped=True, collect_card_number=True):
         card = np.ascontiguousarray(card, np.uint8)
         res = np.zeros(1, RESULT_DTYPE)
         res["flags"] = FLAG_WARPED if warped else 0
-        self.lib.orc_scan_card_image(_p(card, _u8p), card.shape[1], res.ctypes.data_as(C.c_void_p))
+        self.lib.orc_scan_card_image_ex(_p(card, _u8p), card.shape[1], int(collect_card_number),
+                                        res.ctypes.data_as(C.c_void_p))
         return res[0]
 
     def scan_frame(self, y, orientation=3, truncate=False, want_card=True):

@@ -424,8 +424,10 @@ void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets
   }
 }
 
-/* frame.cpp:24-81, number path (collect_card_number = true; expiry handled elsewhere) */
-void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res) {
+/* frame.cpp:24-81, number path (expiry handled elsewhere).  collect_card_number = 0 is what
+ * scanner_add_frame_with_expiry passes once the session's number is accepted (scan.cpp:43-48): a frame
+ * that passes the vseg gates is usable as it is (frame.cpp:43-49), hseg and the digit CNNs do not run. */
+void orc_scan_card_image_ex(const uint8_t *card, int stride, int collect_card_number, orc_frame_result *res) {
   float score;
   int y_off, pattern;
   res->flags &= ORC_FLAG_WARPED;
@@ -447,6 +449,10 @@ void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res)
   }
   if (!(score > 15)) return; /* kMinVSegScore */
   res->flags |= ORC_FLAG_VSEG_OK;
+  if (!collect_card_number) {
+    res->flags |= ORC_FLAG_USABLE;
+    return;
+  }
   const uint8_t *strip = card + (size_t)y_off * stride;
   orc_best_n_hseg(strip, stride, pattern, res);
   orc_number_scores(strip, stride, res->offsets, res->n_offsets, &res->scores[0][0]);
@@ -462,6 +468,10 @@ void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res)
       if (res->scores[d][k] > res->scores[d][best]) best = k;
     res->digits[d] = (uint8_t)best;
   }
+}
+
+void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res) {
+  orc_scan_card_image_ex(card, stride, 1, res);
 }
 
 /* detect -> transform (Y plane) -> scan : the sequence of cython_dmz/dmz.pyx:379-483 */

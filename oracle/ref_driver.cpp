@@ -138,6 +138,22 @@ REF_API int ref_card_type(uint8_t *digits, int n, int allow_incomplete, int *num
   return info.card_type;
 }
 
+// ---- dmz_olm.cpp:20-23,134-179 and processor_support.cpp:112-118 (the CYTHON flavour) ----
+REF_API void ref_scale_point(const float *p /* x y */, const float *src /* x y w h */, const float *dst, float *out) {
+  dmz_point q = dmz_scale_point(dmz_create_point(p[0], p[1]), dmz_create_rect(src[0], src[1], src[2], src[3]),
+                                dmz_create_rect(dst[0], dst[1], dst[2], dst[3]));
+  out[0] = q.x;
+  out[1] = q.y;
+}
+REF_API void ref_guide_frame(int orientation, float preview_width, float preview_height, float *out /* x y w h */) {
+  dmz_rect r = dmz_guide_frame((FrameOrientation)orientation, preview_width, preview_height);
+  out[0] = r.x; out[1] = r.y; out[2] = r.w; out[3] = r.h;
+}
+REF_API int ref_opposite_orientation(int orientation) { return dmz_opposite_orientation((FrameOrientation)orientation); }
+REF_API int ref_processor_support(int which) {
+  return which == 0 ? dmz_has_neon_runtime() : which == 1 ? dmz_use_vfp3_16() : dmz_use_gles_warp();
+}
+
 // ---- expiry segmentation list logic (scan/expiry_seg.cpp): the two functions below touch the
 // Scharr image only through the CV_IMAGE_ELEM header macro, so they link without OpenCV ----
 REF_API int ref_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *sums, int top,

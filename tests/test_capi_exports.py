@@ -55,7 +55,10 @@ def test_bench_tables_cover_every_stage(pkg):
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert set(bench.ALGO) == set(pkg.STAGES) == set(bench.PMC_TRAFFIC)
+    assert set(bench.ALGO) == set(pkg.STAGES) == set(bench.STAGE_KERNELS)
     header = open(os.path.join(ROOT, "include", "dmz_hip.h")).read()
     assert "#define DMZ_HIP_STAGE_COUNT %d" % len(pkg.STAGES) in header
-    assert bench.PIPELINE_BYTES == 307200 + 115560 + 1024 + pkg.EXPIRY_DTYPE.itemsize
+    # algorithmic bytes per unit of configs[1..3]
+    assert [bench.CONFIGS[c]["bytes"] for c in (2, 3, 4)] == [307280, 116584, 423784]
+    for c in bench.CONFIGS.values():
+        assert set(c["stages"]) <= set(pkg.STAGES)

@@ -76,3 +76,99 @@ def test_full_batch_properties(ctx, pkg, oracle):
     assert 0.6 < usable < 0.75 and bool((rec["found_all"] != 0).all())
     for b in (y, cards, res, exp, small_res, small_exp):
         b.free()
+
+
+def test_config2_detect_only_at_4096_frames(ctx, pkg, oracle):
+    """BASELINE configs[1]: dmz_hip_detect_batch on 4 096 frames.  Its records equal the detect fields of
+    the full pipeline's records, twice the same bytes, and a 48-frame sample equals the oracle."""
+    n = 4096
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    res = ctx.alloc(n * 1024)
+    pres = ctx.alloc(n * 1024)
+    pexp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
+    ctx.synth_frames(SEED, 70000, n, y.ptr)
+    ctx.detect(y.ptr, n, res.ptr)
+    ctx.synchronize()
+    d1 = res.download(np.uint8)
+    ctx.detect(y.ptr, n, res.ptr)
+    ctx.synchronize()
+    assert np.array_equal(res.download(np.uint8), d1)
+    ctx.pipeline_expiry(y.ptr, n, pres.ptr, pexp.ptr)
+    ctx.synchronize()
+    det, pipe = d1.view(pkg.RESULT_DTYPE), pres.download(pkg.RESULT_DTYPE, n)
+    for f in ("found", "rho", "theta", "corners", "found_all"):
+        assert np.array_equal(det[f].view(np.uint32), pipe[f].view(np.uint32)), f
+    # detect writes nothing else: every other byte of its records is zero
+    blank = det.copy()
+    for f in ("found", "rho", "theta", "corners", "found_all"):
+        blank[f] = 0
+    assert not blank.view(np.uint8).any()
+    assert bool((det["found_all"] != 0).all())
+    rng = np.random.default_rng(8)
+    for i in rng.choice(n, 48, replace=False):
+        frame, _ = oracle.synth_frame(SEED, 70000 + int(i))
+        want = oracle.detect_edges(frame)
+        g = det[int(i)]
+        assert np.array_equal(g["found"], want["found"]) and g["found_all"] == want["found_all"], i
+        for f in ("rho", "theta", "corners"):
+            assert np.array_equal(g[f].view(np.uint32), want[f].view(np.uint32)), (i, f)
+    for b in (y, res, pres, pexp):
+        b.free()
+
+
+def test_config3_digit_pass_on_65536_prewarped_crops(ctx, pkg, oracle):
+    """BASELINE configs[2]: dmz_hip_scan_cards_batch (+ dmz_hip_scan_expiry_batch) on 65 536 pre-warped
+    428 x 270 crops (7.57 GB): determinism, independence from batch size and position, a sample against
+    the oracle, gate rates."""
+    n = N
+    rs, xs = pkg.RESULT_DTYPE.itemsize, pkg.EXPIRY_DTYPE.itemsize
+    cards = ctx.alloc(n * pkg.CARD_BYTES)
+    res = ctx.alloc(n * rs)
+    exp = ctx.alloc(n * xs)
+    ctx.synth_cards(SEED, 0, n, cards.ptr)
+
+    def run():
+        ctx.scan_cards(cards.ptr, n, res.ptr)
+        ctx.scan_expiry(cards.ptr, n, res.ptr, exp.ptr)
+        ctx.synchronize()
+        return res.download(np.uint8), exp.download(np.uint8)
+
+    zero = np.zeros(8192 * rs, np.uint8)
+    for lo in range(0, n, 8192):
+        ctx._check(ctx.lib.dmz_hip_memcpy_h2d(ctx.h, res.ptr + lo * rs, zero.ctypes.data, zero.nbytes))
+    r1, x1 = run()
+    r2, x2 = run()
+    assert hashlib.sha256(r1).hexdigest() == hashlib.sha256(r2).hexdigest()
+    assert hashlib.sha256(x1).hexdigest() == hashlib.sha256(x2).hexdigest()
+    small_res = np.zeros(4099, pkg.RESULT_DTYPE)
+    small_exp = np.zeros(4099, pkg.EXPIRY_DTYPE)
+    for lo, m in ((0, 4096), (4095, 4099), (33333, 515), (65535, 1), (61440, 4096)):
+        small_res[:] = 0
+        ctx.scan_cards(cards.ptr + lo * pkg.CARD_BYTES, m, small_res)
+        ctx.scan_expiry(cards.ptr + lo * pkg.CARD_BYTES, m, small_res, small_exp)
+        assert small_res[:m].tobytes() == r1[lo * rs:(lo + m) * rs].tobytes(), (lo, m)
+        assert small_exp[:m].tobytes() == x1[lo * xs:(lo + m) * xs].tobytes(), (lo, m)
+    rec, xrec = r1.view(pkg.RESULT_DTYPE), x1.view(pkg.EXPIRY_DTYPE)
+    rng = np.random.default_rng(9)
+    for i in rng.choice(n, 48, replace=False):
+        i = int(i)
+        card, _ = oracle.synth_card(SEED, i)
+        want = oracle.scan_card_image(card, warped=False)
+        g = rec[i]
+        assert g["flags"] == want["flags"] and g["vseg_y_offset"] == want["vseg_y_offset"], i
+        assert np.array_equal(g["offsets"], want["offsets"]) and np.array_equal(g["digits"], want["digits"]), i
+        assert g["hseg_score"].view(np.uint32) == want["hseg_score"].view(np.uint32), i
+        assert np.abs(g["scores"] - want["scores"]).max() <= 1e-4, i
+        we, ge = oracle.scan_card_expiry(card, want), xrec[i]
+        assert ge["n_found"] == we["n_found"] and ge["n_stripes"] == we["n_stripes"] and ge["categorised"] == we["categorised"], i
+        k = int(we["n_groups"])
+        assert np.array_equal(ge["groups"]["char_left"][:k], we["groups"]["char_left"][:k]), i
+        assert np.array_equal(ge["groups"]["char_top"][:k], we["groups"]["char_top"][:k]), i
+        if k:
+            assert np.abs(ge["groups"]["scores"][:k] - we["groups"]["scores"][:k]).max() <= 1e-4, i
+    vseg_ok = float(((rec["flags"] & pkg.FLAG_VSEG_OK) != 0).mean())
+    usable = float(((rec["flags"] & pkg.FLAG_USABLE) != 0).mean())
+    print("config 3 gate rates: vseg_ok %.3f usable %.3f" % (vseg_ok, usable))
+    assert vseg_ok > 0.9 and usable > 0.4
+    for b in (cards, res, exp):
+        b.free()

@@ -72,5 +72,10 @@ def test_host_library_exports_reference_names(pkg):
                  "dmz_transform_card(", "dmz_found_all_edges(", "llcv_unwarp(", "llcv_calc_persp_transform(",
                  "scanner_initialize(", "scanner_reset(", "scanner_add_frame(", "scanner_add_frame_with_expiry(",
                  "scanner_result(", "scanner_destroy(", "mz_create()", "mz_destroy(", "mz_prepare_for_backgrounding(",
-                 "dmz_passes_luhn_checksum(", "dmz_card_info_for_prefix_and_length(", "dmz_prepare_for_backgrounding("):
+                 "dmz_passes_luhn_checksum(", "dmz_card_info_for_prefix_and_length(", "dmz_prepare_for_backgrounding(",
+                 # dmz_olm.h:82,101,104, dmz.h:60, processor_support.h:59-66
+                 "dmz_scale_point(", "dmz_guide_frame(", "dmz_opposite_orientation(", "dmz_has_opencv()",
+                 "dmz_has_neon_runtime()", "dmz_use_vfp3_16()", "dmz_use_gles_warp()", "dmz_set_gles_warp(int)",
+                 "dmz_deinterleave_uint8_c2(", "dmz_deinterleave_RGBA_to_R(", "dmz_YCbCr_to_RGB(", "dmz_focus_score(",
+                 "dmz_brightness_score(", "dmz_blur_card(", "dmz_create_point(", "dmz_create_rect(", "dmz_rect_get_points("):
         assert name in syms, name

@@ -1,6 +1,13 @@
 """Parity statistics on a larger seeded corpus (1024 frames): every integer/index output
-must match the oracle; float scores within 1e-4; y_offset may differ only on float near-ties
-of the window sums, and such frames are counted and bounded."""
+must match the oracle; float scores within 1e-4.  An index may differ only where the reference's own
+decision hangs on a float comparison closer than the score tolerance, and every such event must be
+PROVEN from the oracle's values (no blanket allowance):
+  * a digit label: the oracle's top two vote scores of that digit are within 2e-4 (|delta| <= 1e-4 on
+    every class and a different arg-max imply a top-two gap <= 2e-4);
+  * the usable flag: the oracle's number_score is within 1e-3 of the gate value 3 (160 scores summed);
+  * y_offset / pattern: the oracle's window sums of the two (offset, pattern) choices are within 1e-4,
+    or -- when the coarse-pass tie moved the fine-pass rows -- the two winning scores are.
+Anything else counts as `unexplained` and fails the test."""
 import os
 
 import numpy as np
@@ -26,7 +33,7 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
     stats = dict(found_all=int(got["found_all"].astype(bool).sum()),
                  vseg_ok=int(((got["flags"] & pkg.FLAG_VSEG_OK) != 0).sum()) if hasattr(pkg, "FLAG_VSEG_OK") else -1,
                  card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
-                 label_diff=0, flag_diff=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
+                 label_diff=0, flag_diff=0, unexplained=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
                  expiry_slash_flips=0, max_expiry_err=0.0)
     for i in range(n):
         w, wcard = oracle.scan_frame(frames[i])
@@ -37,8 +44,13 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
             continue
         stats["card_bytes_diff"] += int((gcards[i] != wcard).sum())
         if g["vseg_y_offset"] != w["vseg_y_offset"] or g["pattern_type"] != w["pattern_type"]:
-            assert abs(float(g["vseg_score"]) - float(w["vseg_score"])) < 1e-4, i
-            stats["ties"] += 1
+            _, _, _, vis, amx = oracle.best_n_vseg(wcard)
+            def wsum(y, p):
+                return float((vis if p == 1 else amx)[y:y + 27].astype(np.float64).sum()) if p else 0.0
+            near = abs(wsum(int(g["vseg_y_offset"]), int(g["pattern_type"])) -
+                       wsum(int(w["vseg_y_offset"]), int(w["pattern_type"]))) < 1e-4
+            near = near or abs(float(g["vseg_score"]) - float(w["vseg_score"])) < 1e-4
+            stats["ties" if near else "unexplained"] += 1
             continue
         stats["max_vseg_err"] = max(stats["max_vseg_err"], abs(float(g["vseg_score"]) - float(w["vseg_score"])))
         if not (np.array_equal(g["offsets"], w["offsets"]) and g["pattern_offset"] == w["pattern_offset"]
@@ -46,11 +58,13 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
             stats["idx_diff"] += 1
             continue
         stats["max_score_err"] = max(stats["max_score_err"], float(np.abs(g["scores"] - w["scores"]).max()))
-        stats["label_diff"] += int((g["digits"] != w["digits"]).sum())
+        for d in np.nonzero(g["digits"] != w["digits"])[0]:
+            top2 = np.sort(w["scores"][d])[-2:]
+            stats["label_diff" if float(top2[1] - top2[0]) <= 2e-4 else "unexplained"] += 1
         if g["flags"] != w["flags"]:
             # the usable gate compares number_score with 3: only a float near-tie may flip it
-            assert abs(float(w["number_score"]) - 3.0) < 1e-3, i
-            stats["flag_diff"] += 1
+            near = (g["flags"] ^ w["flags"]) == pkg.FLAG_USABLE and abs(float(w["number_score"]) - 3.0) < 1e-3
+            stats["flag_diff" if near else "unexplained"] += 1
             continue
         # ---- expiry: stripes, groups and rects exact; scores 1e-4 ----
         we, ge = oracle.scan_card_expiry(wcard, w), gexp[i]
@@ -86,10 +100,9 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
     print("parity stats over %d frames: %s" % (n, stats))
     assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
     assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
-    assert stats["ties"] <= 2 + n // 4096 and stats["flag_diff"] <= 2 + n // 4096
-    # a label can only flip when two vote scores of a digit are within the float tolerance
-    assert stats["label_diff"] <= 2 + n // 4096
-    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 + n // 8192 and stats["max_expiry_err"] <= 1e-4
+    # near-tie events are proven one by one in compare_with_oracle; anything unproven fails
+    assert stats["unexplained"] == 0
+    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4
     assert stats["expiry_frames"] >= n // 4
 
 
@@ -141,6 +154,6 @@ def test_fuzz_frames_against_oracle(ctx, pkg, oracle):
     print("fuzz parity stats over %d frames: %s" % (n, stats))
     assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
     assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
-    # garbage cards have flat vseg scores: near-ties (each one asserted to be within 1e-4) are more frequent here
-    assert stats["ties"] <= 2 + n // 100 and stats["flag_diff"] <= 2 and stats["label_diff"] <= 2
-    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] <= 1 and stats["max_expiry_err"] <= 1e-4
+    # garbage cards have flat vseg scores: near-ties (each one proven within 1e-4) are more frequent here
+    assert stats["unexplained"] == 0
+    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4

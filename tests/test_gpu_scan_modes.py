@@ -1,0 +1,74 @@
+"""dmz_hip_scan_cards_batch mode bits: DMZ_HIP_SCAN_SKIP_NUMBER = scan_card_image(collect_card_number = false)
+(frame.cpp:43-49, scan.cpp:43-48: what the reference runs once a session's number is accepted) and
+DMZ_HIP_SCAN_ONLY_WARPED on records that carry stale gate flags."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0xCA4D10
+
+
+def test_skip_number_mode_marks_vseg_ok_frames_usable_and_categorises_their_expiry(ctx, pkg, oracle):
+    n = 96
+    cards = ctx.alloc(n * pkg.CARD_BYTES)
+    ctx.synth_cards(SEED, 500, n, cards.ptr)
+    host_cards = cards.download(np.uint8).reshape(n, 270, 428).copy()
+    host_cards[5] = 0                         # fails the vseg gate
+    host_cards[6] = host_cards[6][::-1, ::-1]  # upside down
+    cards.upload(host_cards)
+    full = np.zeros(n, pkg.RESULT_DTYPE)
+    ctx.scan_cards(cards.ptr, n, full)
+    got = np.zeros(n, pkg.RESULT_DTYPE)
+    got["flags"] = 0x7  # stale bits from an earlier use of the buffer must not survive
+    got["n_offsets"] = 9
+    ctx.scan_cards(cards.ptr, n, got, skip_number=True)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_expiry(cards.ptr, n, got, exp)
+    promoted = 0
+    for i in range(n):
+        want = oracle.scan_card_image(host_cards[i], warped=False, collect_card_number=False)
+        g = got[i]
+        assert g["flags"] == want["flags"], i
+        assert g["vseg_y_offset"] == want["vseg_y_offset"] and g["pattern_type"] == want["pattern_type"], i
+        assert abs(float(g["vseg_score"]) - float(want["vseg_score"])) <= 1e-4
+        assert g["n_offsets"] == 0 and not g["offsets"].any() and not g["scores"].any() and g["number_score"] == 0
+        vseg_ok = bool(want["flags"] & pkg.FLAG_VSEG_OK)
+        assert bool(g["flags"] & pkg.FLAG_USABLE) == vseg_ok  # frame.cpp:43-49
+        promoted += int(vseg_ok and not (full[i]["flags"] & pkg.FLAG_USABLE))
+        we = oracle.scan_card_expiry(host_cards[i], want)
+        ge = exp[i]
+        assert ge["n_found"] == we["n_found"] and ge["categorised"] == we["categorised"], i
+        if vseg_ok and want["vseg_y_offset"] < 240:
+            assert ge["categorised"] == 1, i
+        k = int(we["n_groups"])
+        assert np.array_equal(ge["groups"]["char_left"][:k], we["groups"]["char_left"][:k]), i
+        if k:
+            assert np.abs(ge["groups"]["scores"][:k] - we["groups"]["scores"][:k]).max() <= 1e-4
+    # the case the mode exists for: frames whose digit score fails the number gate still count for the expiry
+    assert promoted >= 5
+    assert not (got[5]["flags"] & pkg.FLAG_VSEG_OK) and (got[6]["flags"] & pkg.FLAG_UPSIDE_DOWN)
+    cards.free()
+
+
+def test_only_warped_clears_stale_gate_flags(ctx, pkg):
+    n = 8
+    cards = ctx.alloc(n * pkg.CARD_BYTES)
+    ctx.synth_cards(SEED, 0, n, cards.ptr)
+    rec = np.zeros(n, pkg.RESULT_DTYPE)
+    rec["flags"] = pkg.FLAG_VSEG_OK | pkg.FLAG_USABLE  # stale: not WARPED
+    rec["flags"][::2] |= pkg.FLAG_WARPED
+    rec["n_offsets"] = 16
+    rec["scores"] = 0.5
+    ctx.scan_cards(cards.ptr, n, rec, only_warped=True)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_expiry(cards.ptr, n, rec, exp)
+    for i in range(n):
+        if i % 2 == 0:
+            assert rec[i]["flags"] & pkg.FLAG_WARPED and rec[i]["flags"] & pkg.FLAG_VSEG_OK
+        else:
+            assert rec[i]["flags"] == 0 and rec[i]["n_offsets"] == 0 and not rec[i]["scores"].any()
+            assert exp[i]["n_found"] == 0 and exp[i]["categorised"] == 0
+    with pytest.raises(pkg.DmzHipError):
+        ctx.lib.dmz_hip_scan_cards_batch.restype  # noqa: B018 (attribute exists)
+        ctx._check(ctx.lib.dmz_hip_scan_cards_batch(ctx.h, cards.ptr, pkg.CARD_BYTES, n, 4, rec.ctypes.data))
+    cards.free()

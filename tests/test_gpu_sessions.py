@@ -45,7 +45,7 @@ def test_sessions_on_synthetic_records(ctx, pkg, oracle, orc):
     dres = ctx.alloc(frp.nbytes)
     dres.upload(frp.view(np.uint8))
     dout = ctx.alloc(S * 128)
-    ctx.scan_sessions(dres.ptr, None, S, F, dout.ptr, scan_expiry=True, frame_interval_ms=200)
+    ctx.scan_sessions(dres.ptr, None, S, F, dout.ptr, scan_expiry=True, frame_interval_ms=200, now_year=2026, now_month=10)
     ctx.synchronize()
     out = dout.download(pkg.SESSION_DTYPE, S)
     for s in range(S):
@@ -67,7 +67,7 @@ def test_sessions_end_to_end_from_frames(ctx, pkg, oracle, orc):
     exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
     out = ctx.alloc(S * 128)
     ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr)
-    ctx.scan_sessions(res.ptr, exp.ptr, S, F, out.ptr, scan_expiry=True, frame_interval_ms=33)
+    ctx.scan_sessions(res.ptr, exp.ptr, S, F, out.ptr, scan_expiry=True, frame_interval_ms=33, now_year=2026, now_month=10)
     ctx.synchronize()
     got = out.download(pkg.SESSION_DTYPE, S)
     gres = res.download(pkg.RESULT_DTYPE, n).reshape(S, F)

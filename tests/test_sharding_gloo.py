@@ -84,3 +84,47 @@ def test_two_rank_gloo_gather_equals_single_process(pkg, orc, oracle):
         y, _ = oracle.synth_frame(SEED, idx)
         want, _ = oracle.scan_frame(y, want_card=False)
         assert got[idx].tobytes() == want.tobytes(), idx
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(entry.ROOT, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_starts_its_own_ranks_when_run_plainly():
+    """`python bench.py --gpus 2` without torchrun: the script starts two ranks as a child process and
+    they run bench.py's own shard / step / asynchronous-gather / timing code (--dry-run: CPU tensors over
+    gloo, records filled with a rank-and-step pattern that rank 0 verifies after the gather)."""
+    for config, steps in ((4, 3), (2, 2)):
+        rc, line, err = _run_bench(["--gpus", "2", "--dry-run", "--batch", "48", "--steps", str(steps),
+                                    "--config", str(config)])
+        assert rc == 0, err[-2000:]
+        assert line["n_gpus"] == 2 and line["dry_run"] and line["gather_ok"] and line["steps"] == steps
+        assert line["frames_per_gpu"] == 48 and line["shard"] == [0, 48] and line["backend"] == "gloo"
+
+
+def test_bench_default_corpus_at_8_ranks_is_one_million_frames():
+    import bench
+    assert 8 * bench.FRAMES_PER_GPU_MULTI == 1048576
+    assert bench.CONFIGS[4]["bytes"] == 423784 and bench.CONFIGS[2]["batch"] == 4096 and bench.CONFIGS[3]["batch"] == 65536
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    rc, line, err = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and line is None and "WORLD_SIZE=1" in err
+
+
+def test_bench_reads_traffic_from_the_committed_profiles():
+    import bench
+    pmc, tag = bench.load_pmc_traffic()
+    assert pmc is not None and tag, "profiles/CURRENT must name a PMC pass"
+    for stage in bench.ALGO:
+        tr = bench.stage_traffic(pmc, stage)
+        assert tr is not None and tr[0] > 0, stage
