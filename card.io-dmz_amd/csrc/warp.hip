@@ -51,6 +51,9 @@ constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
 constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at up to 1.47 source px per card px; with the row
                                  // records the workgroup uses 20,288 B of LDS: eight per CU
 constexpr int kStagePasses = LH / 8;
+constexpr int kFastFlag = 1 << 16;  // DmzWarpWin.wrows: the strip admits the extrapolated reciprocal (k_warp)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
     const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                  M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
     int bx0 = 1 << 20, bx1 = -(1 << 20), by0 = 1 << 20, by1 = -(1 << 20), npos = 0, nneg = 0;
+    double wmin = 1e300;  // min |W| over the strip: W is linear, so it is at a corner
     for (int c = 0; c < 4; c++) {
       const int cx1 = (c & 1) ? imin(TW, DMZ_CARD_WIDTH - x) - 1 : 0;
       const int cy = y0 + ((c & 2) ? TH - 1 : 0);
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
       const bool tame = we > 900 && we < 1150 && p.X > -(1 << 30) && p.X < (1 << 30) && p.Y > -(1 << 30) &&
                         p.Y < (1 << 30);
       if (tame) (Wc > 0. ? npos : nneg)++;
+      wmin = fmin(wmin, fabs(Wc));
     }
     bx0 -= 1, bx1 += 1, by0 -= 1, by1 += 1;  // rounding of the interior pixels
     w.wx0 = bx0 & ~3;                         // window origin, 4-aligned in x
@@ -152,6 +157,8 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
     if ((npos == 4 || nneg == 4) && wcols <= LWMAX && w.wrows <= LH) {
       const bool interior = aligned && w.wx0 >= 0 && w.wx0 + 4 * wdw <= sw && w.wy0 >= 0 && w.wy0 + w.wrows <= sh;
       w.wdw = interior ? wdw : -wdw;
+      // relative change of W per card row <= 2^-11: the reciprocal may be extrapolated along rows
+      if (fabs(M7) * 2048.0 <= wmin) w.wrows |= kFastFlag;
     }
   }
   mats[frame].win[tile] = w;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
   const DmzWarpWin ww = wm.win[tile];  // uniform: scalar loads
-  const int wx0 = ww.wx0, wy0 = ww.wy0, wrows = ww.wrows;
+  const int wx0 = ww.wx0, wy0 = ww.wy0, wrows = ww.wrows & (kFastFlag - 1);
   const uint8_t *src = planes + (size_t)frame * frame_stride;
 
   // ---- per-row terms, one thread per row ----
@@ -279,66 +286,214 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   const double magicY = 6755399441055744.0 - (double)(32 * wy0);
   __syncthreads();
 
-  // every pixel of a strip whose W keeps its sign lies inside the corner window (file header);
-  // the clamp only keeps the LDS address in range
-  auto pixel = [&](int j) -> uint32_t {
-    RowXYW r = s_row[DMZ_WARP_ABLATE == 8 ? 0 : j];
-    if (DMZ_WARP_ABLATE == 8) r.X0 += j, r.Y0 += j;
-    int Xv, Yv;
-    if (DMZ_WARP_ABLATE == 1) {
-      Xv = ((int)(float)r.X0 + x1 - wx0) * 32;
-      Yv = ((int)(float)r.Y0 - wy0) * 32;
-    } else {
-      // 1 / Wd, correctly rounded: v_rcp_f64 and three Newton steps, the last one in the
-      // residual form (the sequence the compiler emits for 1.0 / x between its v_div_scale /
-      // v_div_fixup wrapper, which is the identity for these exponents)
-      const double Wd = r.W0s + C;
-      double yv = __builtin_amdgcn_rcp(Wd);
-      double t = __builtin_fma(-Wd, yv, 1.0);
-      yv = __builtin_fma(yv, t, yv);
-      t = __builtin_fma(-Wd, yv, 1.0);
-      yv = __builtin_fma(yv, t, yv);
-      t = __builtin_fma(-Wd, yv, 1.0);
-      const double W = __builtin_fma(t, yv, yv);
-      Xv = __double2loint((r.X0 + A) * W + magicX);
-      Yv = __double2loint((r.Y0 + B) * W + magicY);
-    }
-    if (DMZ_WARP_ABLATE == 3) return (uint32_t)(Xv + Yv) & 255u;
-    int o = ((Yv << 2) & ~(LW - 1)) | (Xv >> 5);  // (Yv >> 5) * LW + (Xv >> 5) inside the window
-    if (DMZ_WARP_ABLATE == 9) o = imin(imax(o, 0), LW * (LH - 1) - 2);
-    // four single-byte LDS reads: odd-address ds_read_u16 is several times slower than the
-    // aligned form on gfx950, and a byte read costs no more than a wider one here
-    // (the right-hand taps are volatile reads only to keep the compiler from re-merging them)
-    typedef const volatile __attribute__((address_space(3))) unsigned char *lds_vu8;
-    const unsigned char *p = win + o;
-    const lds_vu8 pr = (lds_vu8)win + o;
-    const int p00 = p[0], p01 = pr[1], p10 = p[LW], p11 = pr[LW + 1];
-    const int ax = Xv & 31, ay = Yv & 31, bx = 32 - ax;
-    // (sum p*w*32 + 2^14) >> 15 == (sum p*wx*wy + 512) >> 10 with 5-bit fractions
-    const int t_top = __mul24(p01, ax) + __mul24(p00, bx);
-    const int t_bot = __mul24(p11, ax) + __mul24(p10, bx);
-    return (uint32_t)((t_top << 5) + (__mul24(t_bot - t_top, ay) + 512)) >> 10;  // <= 255
+  // Coordinates travel as "l-format" dwords: window-relative fixed point with 16 + 5 fractional
+  // bits (pixel index from bit 21, the 5-bit bilinear fraction in bits 16..20, bits 0..15 below
+  // the rounding position).  The exact path shifts its rounded integer up by 16.
+  //
+  // every pixel of a strip whose W keeps its sign lies inside the corner window (file header)
+  auto exact_xy = [&](const RowXYW &r, uint32_t &Xl, uint32_t &Yl) {
+    // 1 / Wd, correctly rounded: v_rcp_f64 and three Newton steps, the last one in the
+    // residual form (the sequence the compiler emits for 1.0 / x between its v_div_scale /
+    // v_div_fixup wrapper, which is the identity for these exponents)
+    const double Wd = r.W0s + C;
+    double yv = __builtin_amdgcn_rcp(Wd);
+    double t = __builtin_fma(-Wd, yv, 1.0);
+    yv = __builtin_fma(yv, t, yv);
+    t = __builtin_fma(-Wd, yv, 1.0);
+    yv = __builtin_fma(yv, t, yv);
+    t = __builtin_fma(-Wd, yv, 1.0);
+    const double W = __builtin_fma(t, yv, yv);
+    Xl = (uint32_t)__double2loint((r.X0 + A) * W + magicX) << 16;
+    Yl = (uint32_t)__double2loint((r.Y0 + B) * W + magicY) << 16;
   };
 
-  // ---- the strip: wave w takes rows w, w + 4, ..., two at a time (independent chains) ----
+  // bilinear blend of two pixels.  The four taps of a pixel are single-byte LDS reads (odd-address
+  // ds_read_u16 is several times slower than the aligned form on gfx950), packed as the pairs
+  // {p00, p10} and {p01, p11} in two registers: the horizontal
+  // lerp of the top and the bottom row is then ONE 32-bit multiply-add over both halves
+  // (t = 32 p0 + (p1 - p0) ax <= 8160: no carry between the halves), and the vertical lerp with
+  // rounding one v_dot2_u32_u16 against {(32 - ay) 64, ay 64} + 2^15, which leaves
+  // (sum p w + 2^14) >> 15 == (sum p wx wy + 512) >> 10 in bits 16..23: the byte a d16_hi store writes.
+  uint32_t k2048;  // kept in a register: v_mad_u32_u24 can take one literal only
+  asm("v_mov_b32 %0, 0x800" : "=v"(k2048));
+  auto blend2 = [&](uint32_t Xa, uint32_t Ya, uint32_t Xb, uint32_t Yb, uint32_t &va, uint32_t &vb) {
+    const uint32_t oa = ((Ya >> 14) & ~(uint32_t)(LW - 1)) | (Xa >> 21);  // (Y >> 21) * LW + (X >> 21)
+    const uint32_t ob = ((Yb >> 14) & ~(uint32_t)(LW - 1)) | (Xb >> 21);
+    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)win + oa;
+    const uint32_t lb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)win + ob;
+    // (inline asm: the compiler would merge the two horizontally adjacent byte reads into one 16-bit
+    // read at an odd address; the d16 / d16_hi load forms that would deliver the pairs packed zero the
+    // other register half on this chip (SRAM-ECC), so the pairs cost one v_lshl_or_b32 each)
+    uint32_t a00, a01, a10, a11, b00, b01, b10, b11;
+    asm volatile(
+        "ds_read_u8 %0, %8\n\t"
+        "ds_read_u8 %1, %8 offset:1\n\t"
+        "ds_read_u8 %2, %8 offset:%10\n\t"
+        "ds_read_u8 %3, %8 offset:%11\n\t"
+        "ds_read_u8 %4, %9\n\t"
+        "ds_read_u8 %5, %9 offset:1\n\t"
+        "ds_read_u8 %6, %9 offset:%10\n\t"
+        "ds_read_u8 %7, %9 offset:%11"
+        : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "=&v"(b00), "=&v"(b01), "=&v"(b10), "=&v"(b11)
+        : "v"(la), "v"(lb), "n"(LW), "n"(LW + 1));
+    const uint32_t axa = (Xa >> 16) & 31u, aya = (Ya >> 16) & 31u;
+    const uint32_t axb = (Xb >> 16) & 31u, ayb = (Yb >> 16) & 31u;
+    const uint32_t wya = aya * (65535u * 64u) + k2048;  // {(32 - ay) * 64, ay * 64}
+    const uint32_t wyb = ayb * (65535u * 64u) + k2048;
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11));
+    const uint32_t p0a = (a10 << 16) | a00, p1a = (a11 << 16) | a01;  // {p00, p10}, {p01, p11}
+    const uint32_t p0b = (b10 << 16) | b00, p1b = (b11 << 16) | b01;
+    const uint32_t ta = (p0a << 5) + (p1a - p0a) * axa;  // {t_top, t_bot}
+    const uint32_t tb = (p0b << 5) + (p1b - p0b) * axb;
+    va = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, ta), __builtin_bit_cast(u16x2, wya), 32768u, false);
+    vb = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, tb), __builtin_bit_cast(u16x2, wyb), 32768u, false);
+  };
+
+  // stores: card descriptor + scalar row offset + lane column, no per-pixel address math; the d16_hi
+  // form takes bits 16..23 of the blend as they are (the buffer-store builtin has no such form)
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  // buffer stores: card descriptor + scalar row offset + lane column, no per-pixel address math
-  const __amdgpu_buffer_rsrc_t card =
-      __builtin_amdgcn_make_buffer_rsrc(dbase, 0, DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT, 0x00020000);
-  const int tile_off = y0 * DMZ_CARD_WIDTH + x;
-  constexpr int kPairs = TH / 8;  // 11 pairs = rows w .. w + 84; rows 88, 89 are the tail
-#pragma unroll
-  for (int m = 0; m < (DMZ_WARP_ABLATE == 10 ? 1 : kPairs); m++) {
-    const int j0 = wave_s + 8 * m, j1 = j0 + 4;
-    const uint32_t v0 = pixel(j0), v1 = pixel(j1);
-    if (DMZ_WARP_ABLATE == 6 && v0 + v1 != 0x12345u) continue;
-    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v0, card, x1, tile_off + j0 * DMZ_CARD_WIDTH, 0);
-    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v1, card, x1, tile_off + j1 * DMZ_CARD_WIDTH, 0);
+  i32x4 card;
+  {
+    const uint64_t cb = (uint64_t)(uintptr_t)dbase;
+    card.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)cb);
+    card.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(cb >> 32) & 0xffff);
+    card.z = DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT;
+    card.w = 0x00020000;
   }
-  static_assert(TH == 8 * kPairs + 2, "tail rows");
-  if (wave_s < 2) {
-    const int j = wave_s + 8 * kPairs;
-    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pixel(j), card, x1, tile_off + j * DMZ_CARD_WIDTH, 0);
+  const int tile_off = y0 * DMZ_CARD_WIDTH + x;
+  auto store_row = [&](int j, uint32_t v) {
+    const int soff = tile_off + j * DMZ_CARD_WIDTH;
+    asm volatile("buffer_store_byte_d16_hi %0, %1, %2, %3 offen" : : "v"(v), "v"(x1), "s"(card), "s"(soff) : "memory");
+  };
+
+  // ---- the strip: wave w takes the 23 rows from a = min(23 w, 67) (rows 67, 68 are produced twice,
+  // with the same bytes), two rows per iteration as independent chains ----
+  constexpr int kRows = 23;
+  static_assert(4 * kRows >= TH && (kRows & 1) == 1, "rows per wave");
+  const int a = imin(wave_s * kRows, TH - kRows);
+
+  if (!(ww.wrows & kFastFlag)) {
+    // exact coordinates for every pixel (strips whose perspective term is too strong for the
+    // extrapolated reciprocal below)
+#pragma unroll 2
+    for (int m = 0; m < kRows / 2; m++) {
+      const int j0 = a + 2 * m, j1 = j0 + 1;
+      uint32_t Xa, Ya, Xb, Yb, va, vb;
+      exact_xy(s_row[j0], Xa, Ya);
+      exact_xy(s_row[j1], Xb, Yb);
+      blend2(Xa, Ya, Xb, Yb, va, vb);
+      store_row(j0, va);
+      store_row(j1, vb);
+    }
+    {
+      const int j = a + kRows - 1;
+      uint32_t Xa, Ya, va, vb;
+      exact_xy(s_row[j], Xa, Ya);
+      blend2(Xa, Ya, Xa, Ya, va, vb);
+      store_row(j, va);
+    }
+    return;
+  }
+
+  // ---- filtered-exact coordinates.  The card byte depends on cvRound(fX) only, so a cheap fX is
+  // enough wherever it is provably on the same side of every rounding boundary as the exact one.
+  //   * 1 / Wd: Wd is linear in the row, so along a lane's rows (step 2 per chain) the linear
+  //     extrapolation 2 y[k-1] - y[k-2] of the previous reciprocals has relative error ~ (2 rho)^2
+  //     (rho = |M7| / |W|, the relative change of W per row) and ONE Newton step against the true Wd
+  //     squares that; k_warp_windows admits a strip only if rho <= 2^-11, which with the start-up
+  //     errors (see below) bounds the relative error of y by 2^-36: 3 fp64 operations instead of
+  //     v_rcp_f64 (quarter rate) + 6.
+  //   * fX = fma(Xn, y, magic'): magic' = 1.5 * 2^36 + 0.5 - 32 * origin puts the rounding position
+  //     of the adder 16 bits BELOW the integer, so the low dword holds round((fX + 0.5) * 2^16):
+  //     |fX| < 2^16 (window-relative) => absolute error of the cheap fX < 2^16 * 2^-36 * 2^16 = 2^-4
+  //     units of the last kept bit, plus 1/2 unit of rounding.  floor() of that dword >> 16 equals
+  //     cvRound(exact fX) unless its low 16 bits are exactly 0 (a multiple of 2^16 within 3/4 unit:
+  //     the only place where floor, the half-way case of round-to-even included, can differ).
+  //   * lanes whose dword has zero low bits (2^-16 per coordinate) take the exact sequence; the test
+  //     is one v_min3_u16 + v_min_u16 + compare per pixel pair, the branch is wave-uniform.
+  // (uniform: kept in scalar registers, so that the fma needs no copy of its addend)
+  auto uniform = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  const double magicXf = uniform(103079215104.0 + 0.5 - (double)(32 * wx0));  // 1.5 * 2^36
+  const double magicYf = uniform(103079215104.0 + 0.5 - (double)(32 * wy0));
+  const double sW = M7 * 0.03125;  // Wd(row + 1) - Wd(row)
+  auto newton = [](double Wd, double g) {
+    const double t = __builtin_fma(-Wd, g, 1.0);
+    return __builtin_fma(g, t, g);
+  };
+  // reciprocals at the virtual rows a-1 (full Newton sequence) and a-2, a-3, a-4 (one step from
+  // y[a-1]: relative error (k rho)^2); the first extrapolations then start with <= 15 rho^2 and
+  // the Newton step leaves <= 225 rho^4 <= 2^-36
+  const double Wa = s_row[a].W0s + C;
+  double y1;
+  {
+    const double Wd = Wa - sW;
+    y1 = __builtin_amdgcn_rcp(Wd);
+    y1 = newton(Wd, y1);
+    y1 = newton(Wd, y1);
+  }
+  double yA1 = newton(Wa - 2.0 * sW, y1), yA2 = newton(Wa - 4.0 * sW, y1);  // chain A: rows a, a+2, ...
+  double yB1 = y1, yB2 = newton(Wa - 3.0 * sW, y1);                          // chain B: rows a+1, a+3, ...
+  // the numerators and Wd of a chain advance by recurrence (two rows per step): the cheap path needs
+  // them to ~2^-40 only, so the rounding of a dozen additions is irrelevant, and the per-row LDS
+  // records (three broadcast reads per pixel pair: the LDS pipe was the next limit) are left to
+  // the exact path
+  struct Chain {
+    double Xn, Yn, Wd, y1, y2;
+  };
+  const double dX2 = uniform(2.0 * M1), dY2 = uniform(2.0 * M4), dW2 = uniform(2.0 * sW);
+  auto fast_xy = [&](Chain &c, uint32_t &Xl, uint32_t &Yl) {
+    const double yn = newton(c.Wd, __builtin_fma(2.0, c.y1, -c.y2));
+    c.y2 = c.y1;
+    c.y1 = yn;
+    // (v_fma_f64 spelled out: the compiler picks the two-address v_fmac_f64 here and pays a 64-bit
+    // register copy of the addend per pixel)
+    double fx, fy;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fx) : "v"(c.Xn), "v"(yn), "s"(magicXf));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fy) : "v"(c.Yn), "v"(yn), "s"(magicYf));
+    Xl = (uint32_t)__double2loint(fx);
+    Yl = (uint32_t)__double2loint(fy);
+    c.Xn += dX2;
+    c.Yn += dY2;
+    c.Wd += dW2;
+  };
+  Chain cA, cB;
+  {
+    const RowXYW ra = s_row[a], rb = s_row[a + 1];
+    cA.Xn = ra.X0 + A, cA.Yn = ra.Y0 + B, cA.Wd = Wa, cA.y1 = yA1, cA.y2 = yA2;
+    cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C, cB.y1 = yB1, cB.y2 = yB2;
+  }
+#pragma unroll
+  for (int m = 0; m < kRows / 2; m++) {
+    const int j0 = a + 2 * m, j1 = j0 + 1;
+    uint32_t Xa, Ya, Xb, Yb, va, vb;
+    fast_xy(cA, Xa, Ya);
+    fast_xy(cB, Xb, Yb);
+    uint32_t lo16;
+    unsigned long long amb;
+    asm("v_min3_u16 %0, %2, %3, %4\n\t"
+        "v_min_u16 %0, %0, %5\n\t"
+        "v_cmp_eq_u16 %1, 0, %0"
+        : "=&v"(lo16), "=s"(amb)
+        : "v"(Xa), "v"(Ya), "v"(Xb), "v"(Yb));
+    if (__builtin_expect(amb != 0, 0)) {
+      exact_xy(s_row[j0], Xa, Ya);
+      exact_xy(s_row[j1], Xb, Yb);
+    }
+    blend2(Xa, Ya, Xb, Yb, va, vb);
+    store_row(j0, va);
+    store_row(j1, vb);
+  }
+  {
+    const int j = a + kRows - 1;
+    uint32_t Xa, Ya, va, vb;
+    fast_xy(cA, Xa, Ya);
+    if (__builtin_amdgcn_ballot_w64((Xa & 0xffffu) == 0u || (Ya & 0xffffu) == 0u)) exact_xy(s_row[j], Xa, Ya);
+    blend2(Xa, Ya, Xa, Ya, va, vb);
+    store_row(j, va);
   }
 }
 
