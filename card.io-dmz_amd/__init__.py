@@ -30,6 +30,7 @@ ORIENTATION_LANDSCAPE_LEFT = 4
 
 FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
 SCAN_ONLY_WARPED, SCAN_SKIP_NUMBER = 1, 2
+EXPIRY_CONV_F32, EXPIRY_CONV_BF16X3, EXPIRY_CONV_BF16 = 0, 1, 2
 OPT_TRUNCATE_CORNERS = 1
 OPT_UPSAMPLE = 2
 STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
@@ -83,7 +84,7 @@ EXPORTS = (
     "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
     "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
     "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
-    "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch",
+    "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv",
 )
 
 
@@ -117,6 +118,7 @@ def load_library():
     lib.dmz_hip_context_destroy.restype = None
     lib.dmz_hip_synchronize.argtypes = [vp]
     lib.dmz_hip_set_stream.argtypes = [vp, vp]
+    lib.dmz_hip_set_expiry_conv.argtypes = [vp, i]
     lib.dmz_hip_last_error.argtypes = [vp]
     lib.dmz_hip_last_error.restype = C.c_char_p
     lib.dmz_hip_detect_batch.argtypes = [vp, vp, sz, i, i, i, vp, vp, sz, i, i, i, vp]
@@ -222,6 +224,10 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._check(self.lib.dmz_hip_set_stream(self.h, stream_handle))
+
+    def set_expiry_conv(self, mode):
+        """arithmetic of the expiry CNN's conv2: EXPIRY_CONV_F32 / _BF16X3 (default) / _BF16"""
+        self._check(self.lib.dmz_hip_set_expiry_conv(self.h, mode))
 
     def set_profiling(self, on):
         self._check(self.lib.dmz_hip_set_profiling(self.h, int(on)))

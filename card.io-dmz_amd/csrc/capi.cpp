@@ -44,6 +44,8 @@ struct dmz_hip_context {
   };
   Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc, xstage, stage_exp, stage_sess;
 
+  int expiry_conv = DMZ_HIP_EXPIRY_CONV_BF16X3;
+
   // profiling
   bool profiling = false;
   struct Span {
@@ -98,6 +100,20 @@ bool is_device_ptr(const void *p) {
     return false;
   }
   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// float <-> bfloat16 (round to nearest even; the weights are finite)
+uint16_t bf16_rne(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_to_float(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float v;
+  memcpy(&v, &u, 4);
+  return v;
 }
 
 // ---- dmz.cpp:279-341 -------------------------------------------------------
@@ -390,13 +406,13 @@ int run_expiry(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, i
   if (rc) return rc;
   if (!ctx->profiling) {
     dmz_launch_expiry(ctx->stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, cards, card_stride, n, results,
-                      (DmzExpiryStage *)ctx->xstage.p, out, nullptr);
+                      (DmzExpiryStage *)ctx->xstage.p, out, nullptr, ctx->expiry_conv);
   } else {
     // two spans (segmentation kernels | categorisation kernel) sharing the middle event
     StageTimer a(ctx, DMZ_HIP_STAGE_EXPIRY_SEG);
     hipEvent_t mid = a.take(), mid2 = a.take();
     dmz_launch_expiry(ctx->stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, cards, card_stride, n, results,
-                      (DmzExpiryStage *)ctx->xstage.p, out, mid);
+                      (DmzExpiryStage *)ctx->xstage.p, out, mid, ctx->expiry_conv);
     (void)hipEventRecord(mid2, ctx->stream);
     ctx->spans.push_back({DMZ_HIP_STAGE_EXPIRY_CAT, mid, mid2});
     a.b_override = mid;
@@ -471,6 +487,20 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     const float *hw = w + dmzw::EXPIRY + dmzw::X_HW;
     for (int j = 0; j < 176; j++)
       for (int i = 0; i < 120; i++) xw[dmzx::FC1_T + i * 176 + j] = hw[j * 120 + i];
+    // conv2 B fragments of v_mfma_f32_16x16x32_bf16: lane (n = lane & 15, run = lane >> 4) of k-step ks
+    // holds the eight k of run R = 4 ks + run, i.e. tap t = R / 7, maps 8 (R % 7) .. + 7
+    uint16_t *bh = (uint16_t *)(xw.data() + dmzx::CONV2_BH), *bl = (uint16_t *)(xw.data() + dmzx::CONV2_BL);
+    for (int ks = 0; ks < dmzx::C2_KSTEPS; ks++)
+      for (int nt = 0; nt < 3; nt++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 8; e++) {
+            const int R = 4 * ks + (lane >> 4), t = R / 7, mp = 8 * (R % 7) + e, nn = 16 * nt + (lane & 15);
+            const float wv = (t < 25 && mp < 50 && nn < 40) ? c2[nn * 1250 + mp * 25 + t] : 0.0f;
+            const uint16_t h = bf16_rne(wv);
+            const size_t idx = (((size_t)ks * 3 + nt) * 64 + lane) * 8 + e;
+            bh[idx] = h;
+            bl[idx] = bf16_rne(wv - bf16_to_float(h));
+          }
   }
   // cv::bilateralFilter(d = 3, sigmaColor = 0.95, sigmaSpace = 2/3) tables, expiry_categorize.cpp:52-57
   // (cvSmooth hands param3 to sigmaColor and param4 to sigmaSpace)
@@ -537,6 +567,14 @@ int dmz_hip_set_stream(dmz_hip_context *ctx, void *hip_stream) {
   if (!ctx) return DMZ_HIP_EINVAL;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_set_expiry_conv(dmz_hip_context *ctx, int mode) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (mode != DMZ_HIP_EXPIRY_CONV_F32 && mode != DMZ_HIP_EXPIRY_CONV_BF16X3 && mode != DMZ_HIP_EXPIRY_CONV_BF16)
+    return fail(ctx, DMZ_HIP_EINVAL, "unknown expiry conv mode");
+  ctx->expiry_conv = mode;
   return DMZ_HIP_OK;
 }
 
@@ -985,7 +1023,7 @@ static int run_model(dmz_hip_context *ctx, int which, int model, const float *x,
   else if (which == 2)
     dmz_launch_slash_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout);
   else if (which == 3)
-    dmz_launch_expiry_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout);
+    dmz_launch_expiry_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout, ctx->expiry_conv);
   else
     dmz_launch_digit_model(ctx->stream, ctx->d_weights, ctx->d_hidwt, model, (const float *)dx, n, dout);
   HIP_TRY(ctx, hipGetLastError());

@@ -29,9 +29,14 @@
 // u8 source tile, the u8 edge map and the u16 vote counters (39 KB / 30 KB per
 // workgroup => 4 workgroups, 28 / 16 waves per CU), so one workgroup's barriers
 // are covered by the others.  The adaptive thresholds need the box-wide mean of
-// |dx|+|dy| before NMS, so the walk runs twice (sum pass, NMS pass): recomputing
-// ~30 integer ops per pixel is cheaper than parking 44 KB of gradients per
-// workgroup in LDS.
+// |dx|+|dy| before NMS.  For the standard geometry (28- and 38-step boxes of a
+// 640 x 480 frame) the walk can run ONCE: the lane keeps the (dx, dy) of its 28 / 38
+// steps packed as sign-flipped s16 pairs in registers (one v_sad_u16 against
+// 0x80008000 gives |dx| + |dy| back), and the NMS pass reads them from there: used
+// for the left/right boxes (38 steps, 256-thread workgroups: 128 registers still
+// leave four workgroups per CU).  The top/bottom boxes and other box sizes take the
+// two-walk form (sum pass, NMS pass), which recomputes the gradients instead of
+// parking 44 KB of them per workgroup in LDS (see DMZ_DETECT_SINGLE_H below).
 #include "dmz_hip_internal.h"
 
 namespace {
@@ -105,6 +110,19 @@ __device__ __forceinline__ void window_step(const WalkCtx &c, Window &wn, int s,
   dy = clampi(VERT ? g_ds : g_sd, -32768, 32767);
 }
 
+// the same step with the slot arithmetic left to constant folding: for fully unrolled walks
+template <bool VERT>
+__device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
+  const int k = s % 7;
+  across_taps(c, clampi(s + 3, 0, c.S - 1), wn.d[(k + 6) % 7], wn.s[(k + 6) % 7]);
+  const int g_ds = (wn.d[k % 7] + wn.d[(k + 6) % 7]) + 6 * (wn.d[(k + 1) % 7] + wn.d[(k + 5) % 7]) +
+                   15 * (wn.d[(k + 2) % 7] + wn.d[(k + 4) % 7]) + 20 * wn.d[(k + 3) % 7];
+  const int g_sd = (wn.s[(k + 6) % 7] - wn.s[k % 7]) + 4 * (wn.s[(k + 5) % 7] - wn.s[(k + 1) % 7]) +
+                   5 * (wn.s[(k + 4) % 7] - wn.s[(k + 2) % 7]);
+  dx = clampi(VERT ? g_sd : g_ds, -32768, 32767);
+  dy = clampi(VERT ? g_ds : g_sd, -32768, 32767);
+}
+
 // NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
 // given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
 template <bool VERT>
@@ -163,7 +181,8 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   }
 }
 
-template <bool VERT, int NT>
+// SC > 0: the box has exactly SC steps (compile time) and the walk runs once; SC == 0: any size, two walks
+template <bool VERT, int NT, int SC>
 __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_stride, int row_stride,
                             const DmzBoxParams &bp, int frame, int box_id,
                             DmzBoxHit *__restrict__ hits, unsigned char *lds) {
@@ -260,6 +279,75 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   const bool inbox = c.l >= 0 && c.l < L;
   const bool owner = inbox && lane >= 1 && lane <= 62;  // produces output for its coordinate
 
+  // thresholds from the box-wide sum (canny.cpp:573-578: mean in double; low = cvFloor(mean),
+  // high = cvFloor(3.0f * mean))
+  auto thresholds_from = [&](long long local_sum) {
+    for (int o = 32; o > 0; o >>= 1) local_sum += __shfl_down(local_sum, o, 64);
+    if (lane == 0) s_red[wave] = local_sum;
+    __syncthreads();
+    if (tid == 0) {
+      long long tot = 0;
+      for (int i = 0; i < NT / 64; i++) tot += s_red[i];
+      const double mean = (double)tot / (double)N;
+      const double lowt = mean, hight = 3.0f * mean;
+      s_int[0] = (int)floor(lowt);
+      s_int[1] = (int)floor(hight);
+    }
+    __syncthreads();
+  };
+  int low, high;
+  if constexpr (SC > 0) {
+    // ---- B+C, single walk.  g[s] = (dy << 16 | dx & 0xffff) ^ 0x80008000: each half is the gradient
+    // plus 32768 as an unsigned 16-bit number, so |dx| + |dy| = v_sad_u16(g, 0x80008000, 0) exactly
+    // (|-32768| = 32768 included), and dx, dy come back with one xor, one v_bfe_i32, one shift.
+    uint32_t g[SC];
+    {
+      Window wn;
+      window_init(c, wn);
+      int acc = 0;
+#pragma unroll
+      for (int s0 = 0; s0 < SC; s0++) {
+        int dx, dy;
+        window_step_s<VERT>(c, wn, s0, dx, dy);
+        const int ax = iabs(dx), ay = iabs(dy);
+        acc += (ax > 32767 ? 32767 : ax) + (ay > 32767 ? 32767 : ay);  // cvAbs: 32768 -> 32767
+        g[s0] = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u) ^ 0x80008000u;
+#if DMZ_DETECT_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: hoisted tile reads cost registers
+#endif
+      }
+      thresholds_from(owner ? (long long)acc : 0ll);  // steps * 65534 fits an int for any box that fits LDS
+    }
+    low = s_int[0], high = s_int[1];
+    DMZ_STOP_AFTER(2, low + high)
+    {
+      // magnitudes of (own, lane-1, lane+1) at steps s-1 (p), s (c), s+1 (n)
+      int mp = 0, mp_lo = 0, mp_hi = 0;
+      int mc = 0, mc_lo = 0, mc_hi = 0;
+      uint32_t gc = 0x80008000u;
+#pragma unroll
+      for (int sn = 0; sn <= SC; sn++) {
+        const uint32_t gn = sn < SC ? g[sn < SC ? sn : 0] : 0x80008000u;
+        // outside the ROI the magnitude is 0
+        const int mn = (sn < SC && inbox) ? (int)__builtin_amdgcn_sad_u16(gn, 0x80008000u, 0u) : 0;
+        const int mn_lo = __shfl_up(mn, 1, 64);    // lane - 1
+        const int mn_hi = __shfl_down(mn, 1, 64);  // lane + 1
+        if (sn >= 1 && owner) {
+          const uint32_t h = gc ^ 0x80008000u;
+          const int dxc = (int)(short)(h & 0xffffu), dyc = (int)h >> 16;
+          nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo, mc_hi, mn, mn_lo, mn_hi,
+                          map, list, s_int);
+        }
+        mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;
+        mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;
+        gc = gn;
+#if DMZ_DETECT_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+      __syncthreads();
+    }
+  } else {
   // ---- B. pass 1: sum of saturated |dx| + |dy| (cvAbs: 32768 -> 32767) -> thresholds ----
   {
     long long local_sum = 0;
@@ -281,21 +369,9 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 #undef DMZ_P1_STEP
       local_sum = acc;  // steps * 65534 fits an int for any box that fits LDS
     }
-    for (int o = 32; o > 0; o >>= 1) local_sum += __shfl_down(local_sum, o, 64);
-    if (lane == 0) s_red[wave] = local_sum;
-    __syncthreads();
-    if (tid == 0) {
-      long long tot = 0;
-      for (int i = 0; i < NT / 64; i++) tot += s_red[i];
-      // canny.cpp:573-578: mean in double; low = cvFloor(mean), high = cvFloor(3.0f * mean)
-      const double mean = (double)tot / (double)N;
-      const double lowt = mean, hight = 3.0f * mean;
-      s_int[0] = (int)floor(lowt);
-      s_int[1] = (int)floor(hight);
-    }
-    __syncthreads();
+    thresholds_from(local_sum);
   }
-  const int low = s_int[0], high = s_int[1];
+  low = s_int[0], high = s_int[1];
   DMZ_STOP_AFTER(2, low + high)
 
   // ---- C. pass 2: gradients again, NMS + slope gate -> edge map (walk space) ----
@@ -329,6 +405,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     }
 #undef DMZ_P2_STEP
     __syncthreads();
+  }
   }
   DMZ_STOP_AFTER(3, map[0] + map[N - 1] + s_int[2])
 
@@ -460,8 +537,29 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 
 // VERT = false: boxes 0 and 2 (top, bottom: horizontal lines, lanes = columns);
 // VERT = true:  boxes 1 and 3 (left, right: vertical lines, lanes = rows).
-template <bool VERT, int NT>
-__global__ __launch_bounds__(NT) void k_detect_walk(const uint8_t *__restrict__ planes,
+// waves per SIMD the register allocation aims at: four workgroups per CU (what the LDS tiles allow)
+#ifndef DMZ_DETECT_SCHED_BARRIER
+#define DMZ_DETECT_SCHED_BARRIER 0
+#endif
+// Measured (ms per 16 384 frames, both boxes pairs): two walks everywhere 2.22; single walk for the
+// left/right boxes only 2.08; for the top/bottom boxes only 2.21 -- their 28 packed gradients push
+// the kernel from 62 to ~100 registers (two 448-thread workgroups per CU instead of four), and what
+// the walk saves in VALU issue (-33 % instructions) is lost to barrier and LDS latency at that
+// occupancy; with 72 registers forced the allocator spills 43 dwords and it is slower still.
+#ifndef DMZ_DETECT_SINGLE_H
+#define DMZ_DETECT_SINGLE_H 0
+#endif
+#ifndef DMZ_DETECT_SINGLE_V
+#define DMZ_DETECT_SINGLE_V 1
+#endif
+#ifndef DMZ_DETECT_WPS_H
+#define DMZ_DETECT_WPS_H 5
+#endif
+#ifndef DMZ_DETECT_WPS_V
+#define DMZ_DETECT_WPS_V 4
+#endif
+template <bool VERT, int NT, int SC>
+__global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H)) void k_detect_walk(const uint8_t *__restrict__ planes,
                                                      size_t frame_stride, int row_stride,
                                                      DmzDetectParams params,
                                                      DmzBoxHit *__restrict__ hits,
@@ -470,20 +568,20 @@ __global__ __launch_bounds__(NT) void k_detect_walk(const uint8_t *__restrict__ 
   const int frame = blockIdx.x >> 1;  // 1-D grid: gridDim.y is limited to 65535
   const int box_id = (blockIdx.x & 1) * 2 + (VERT ? 1 : 0);
   if (skip_mask && skip_mask[frame * 4 + box_id]) return;
-  detect_body<VERT, NT>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
+  detect_body<VERT, NT, SC>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
 }
 
-template <bool VERT, int NT>
+template <bool VERT, int NT, int SC>
 int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
                 const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask, int lds_bytes) {
   static int configured_lds = 0;  // per instantiation
   if (lds_bytes > configured_lds) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT>,
+    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT, SC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
     configured_lds = lds_bytes;
   }
-  hipLaunchKernelGGL((k_detect_walk<VERT, NT>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
+  hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
                      frame_stride, row_stride, p, hits, skip_mask);
   return 0;
 }
@@ -494,9 +592,13 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
   const DmzBoxParams &a = p.box[VERT ? 1 : 0], &b = p.box[VERT ? 3 : 2];
   const int nt = a.nthreads > b.nthreads ? a.nthreads : b.nthreads;
   const int lds = a.lds_total > b.lds_total ? a.lds_total : b.lds_total;
-  if (nt <= 256) return launch_pair<VERT, 256>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
-  if (nt <= 448) return launch_pair<VERT, 448>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
-  return launch_pair<VERT, 1024>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  // the boxes of a 640 x 480 frame (28 steps x 389 lanes, 38 steps x 241 lanes): single-walk kernels
+  constexpr int kSteps = VERT ? 38 : 28, kNt = VERT ? 256 : 448;
+  if (a.steps == kSteps && b.steps == kSteps && nt <= kNt && (VERT ? DMZ_DETECT_SINGLE_V : DMZ_DETECT_SINGLE_H))
+    return launch_pair<VERT, kNt, kSteps>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  if (nt <= 256) return launch_pair<VERT, 256, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  if (nt <= 448) return launch_pair<VERT, 448, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  return launch_pair<VERT, 1024, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
 }
 
 }  // namespace

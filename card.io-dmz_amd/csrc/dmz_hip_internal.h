@@ -105,7 +105,14 @@ namespace dmzx {
 constexpr int SLASH_W1T = 0;                      // [176][80]  (input-major)
 constexpr int CONV2_P = SLASH_W1T + 176 * 80;     // [1252][48]: tap-major, zero-padded to the MFMA tile grid
 constexpr int FC1_T = CONV2_P + 1252 * 48;        // [120][176]
-constexpr int TOTAL = FC1_T + 120 * 176;
+// conv2 for the bf16 matrix-core variants (v_mfma_f32_16x16x32_bf16): K ordered tap-major with the 50
+// maps of a tap padded to 56 (seven runs of eight), 44 k-steps of 32; B fragments stored exactly as
+// the lanes load them, [k-step 44][n-tile 3][lane 64][8 bf16], once as the bf16 rounding of the
+// weights (HI) and once as the bf16 rounding of the remainder (LO)
+constexpr int C2_KSTEPS = 44, C2_MAPS_PAD = 56;
+constexpr int CONV2_BH = FC1_T + 120 * 176;                  // C2_KSTEPS * 3 * 64 * 8 bf16 = 33,792 floats
+constexpr int CONV2_BL = CONV2_BH + C2_KSTEPS * 3 * 64 * 4;
+constexpr int TOTAL = CONV2_BL + C2_KSTEPS * 3 * 64 * 4;
 }  // namespace dmzx
 // offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)
 namespace dmzw {
@@ -149,9 +156,11 @@ void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *c
 void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* dmzx layout */,
                        const DmzExpiryTables *tables, const uint8_t *cards, size_t card_stride, int n,
                        const dmz_hip_frame_result *results, DmzExpiryStage *stage /* n x 3 */,
-                       dmz_hip_expiry_result *out, hipEvent_t mid /* recorded between seg and cat, or null */);
+                       dmz_hip_expiry_result *out, hipEvent_t mid /* recorded between seg and cat, or null */,
+                       int conv_mode /* DMZ_HIP_EXPIRY_CONV_* */);
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
-void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
+void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out,
+                             int conv_mode);
 void dmz_launch_sessions(hipStream_t s, const dmz_hip_frame_result *frames, const dmz_hip_expiry_result *expiry,
                          int n_sessions, int frames_per_session, int scan_expiry, int frame_interval_ms,
                          int now_year, int now_month, int allow_past, dmz_hip_session_result *out);

@@ -219,7 +219,11 @@ struct SegLds {
   short rL[64];                          // their left edges
   short cLeft[64], cTop[64];             // optimised character rects of the current group
   short okeep[64], oLeft[64], oTop[64];
-  short cmax[64], csum[64];
+  // per slot of optimize_character_rects: 24 entries apart (21 used), so that the wide reads the compiler
+  // merges a slot's 18 consecutive entries into start 16-byte aligned (a 42-byte slot pitch made them
+  // unaligned ds_read_b128: SQ_LDS_UNALIGNED_STALL was twice the kernel's LDS busy cycles)
+  __attribute__((aligned(16))) short cmax[80];
+  __attribute__((aligned(16))) short csum[80];
 };
 
 // four |p[c+1] - p[c-1]| of dword d of a row (prev / cur / next = dwords d-1, d, d+1), column index
@@ -571,11 +575,12 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
             mx = imax(mx, v[r]);
           }
         }
-        L.cmax[lane] = mx;
+        const int sidx = sl * 24 + c;  // this lane's entry of the per-slot arrays
+        L.cmax[sidx] = mx;
         __syncthreads();
         if (sl < 3) {
 #pragma unroll
-          for (int j = 0; j < 18; j++) mx = imax(mx, L.cmax[sl * 21 + j]);
+          for (int j = 0; j < 18; j++) mx = imax(mx, L.cmax[sl * 24 + j]);
         }
         // cvNormalize's scale is (float)(255.0 / (double)max); for every integer max in [1, 32767] that
         // equals the correctly rounded float quotient (checked exhaustively, tests/test_oracle_units.py)
@@ -589,25 +594,25 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
             if (c < 19) tile[(sl * 21 + r) * 19 + c] = t;
           }
         }
-        L.csum[lane] = cs;
+        L.csum[sidx] = cs;
         __syncthreads();
         // column trimming (every lane of the slot replays it: uniform within the slot)
         int lc = 0, rc = ciw - 1;
         if (sl < 3)
           for (int wv = ciw; wv > TW; wv--) {
-            if (L.csum[sl * 21 + lc] <= L.csum[sl * 21 + rc]) lc++;
+            if (L.csum[sl * 24 + lc] <= L.csum[sl * 24 + rc]) lc++;
             else rc--;
           }
         int rsm = 0;
         if (sl < 3)  // lane c is row c here
           for (int cc = lc; cc <= rc; cc++) rsm += tile[(sl * 21 + c) * 19 + cc];
         __syncthreads();
-        L.cmax[lane] = rsm;  // row sums
+        L.cmax[sidx] = rsm;  // row sums
         __syncthreads();
         if (sl < 3 && c == 0 && have) {
           int tr = 0, brw = cih - 1;
           for (int hv = cih; hv > TH; hv--) {
-            if (L.cmax[sl * 21 + tr] <= L.cmax[sl * 21 + brw]) tr++;
+            if (L.cmax[sl * 24 + tr] <= L.cmax[sl * 24 + brw]) tr++;
             else brw--;
           }
           L.okeep[k] = valid ? 1 : 0;
@@ -738,18 +743,28 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 constexpr int XC_THREADS = 256;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XIN_W = 20, XIN_H = 24;  // zero-padded input: 4 rows/cols of padding before, 4/5 after
+constexpr int C2_KSTEPS = dmzx::C2_KSTEPS, C2_MP = dmzx::C2_MAPS_PAD;  // conv2, bf16 variants: see dmz_hip_internal.h
+constexpr int L1_BF16_ELEMS = 4 * 70 * C2_MP;  // [digit][pooled position 10 x 7][map, padded to 56]
 struct CatLds {
-  float l1[4 * 50 * 70];        // 56,000 B; prep-time scratch overlays it
+  // layer-1 output.  F32 variant: float [digit][map 50][70] (56,000 B).  bf16 variants: the bf16 rounding of the
+  // activations and the bf16 rounding of the remainder, each [digit][position 70][map 56] (2 x 31,360 B), so that
+  // the eight k of a matrix-core fragment (eight maps of one tap) are one aligned 16-byte read.  Prep-time
+  // scratch and the conv2 partial sums overlay it.
+  __attribute__((aligned(16))) unsigned char l1raw[2 * L1_BF16_ELEMS * 2];  // 62,720 B
   __attribute__((aligned(8))) float xin[4 * XIN_H * XIN_W]; // 7,680 B
   float xf[4 * 176];
-  float l2[4 * 120];
-  float l3[4 * 176];
   float es[4 * 16];
   float mean[4];
-  __attribute__((aligned(8))) float c1w[25 * 50];  // conv1 weights, tap-major
+  // conv1 weights, tap-major, rewritten for every group; dead after layer 1, when the outputs of layer 2
+  // (4 x 120) and of the hidden layer (4 x 176) take their place -- 78.8 KB in all: two workgroups per CU
+  __attribute__((aligned(8))) float c1w[25 * 50];
   short hdr[DMZ_HIP_EXPIRY_MAX_GROUPS][16];
   int n_groups;
 };
+static_assert(4 * 120 + 4 * 176 <= 25 * 50, "l2 + l3 overlay the conv1 weights");
+static_assert(sizeof(CatLds) <= 80 * 1024, "two workgroups per CU");
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar redux order (Redux.h:77-90)
   const float a = (v[0] + v[1]) + (v[2] + (v[3] + v[4]));
@@ -760,10 +775,15 @@ __device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar r
 #ifndef DMZ_XCAT_STOP
 #define DMZ_XCAT_STOP 99
 #endif
-// xf[nd][176] raw inputs -> scores (global, nd x 10 floats at `out`, row stride 10)
+// xf[nd][176] raw inputs -> scores (global, nd x 10 floats at `out`, row stride 10).  MODE = DMZ_HIP_EXPIRY_CONV_*
+template <int MODE>
 __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, const float *__restrict__ xw, CatLds &S, int nd,
                                  float *__restrict__ out, int tid) {
   const float *xm = wts + dmzw::EXPIRY;
+  float *const l1f = (float *)S.l1raw;                                     // F32 variant
+  unsigned short *const l1h = (unsigned short *)S.l1raw;                   // bf16 variants: high parts ...
+  unsigned short *const l1l = l1h + L1_BF16_ELEMS;                         // ... and remainders
+  float *const l2 = S.c1w, *const l3 = S.c1w + 4 * 120;                    // after layer 1
   if (DMZ_XCAT_STOP == 1) return;
   for (int i = tid; i < 1250; i += XC_THREADS) {
     const int k = i / 25, t = i - k * 25;
@@ -782,6 +802,15 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     S.xin[d * XIN_H * XIN_W + (r + 4) * XIN_W + (c + 4)] = S.xf[i] - S.mean[d];
   }
   __syncthreads();
+  if (MODE != DMZ_HIP_EXPIRY_CONV_F32) {
+    // maps 50..55 of every position multiply zero weights, but must be finite: clear them (the partial
+    // sums of the previous group lay over this buffer)
+    for (int i = tid; i < 4 * 70 * 3; i += XC_THREADS) {
+      const int pos = i / 3, q = i - 3 * pos;
+      *(uint32_t *)(l1h + pos * C2_MP + 50 + 2 * q) = 0u;
+      *(uint32_t *)(l1l + pos * C2_MP + 50 + 2 * q) = 0u;
+    }
+  }
   // layer 1: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU.
   // Work item = (map pair, digit, pooled row): v_pk_fma_f32 carries two maps per instruction;
   // the 6 x 18 input strip of the pooled row sits in registers for its seven outputs.
@@ -796,7 +825,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     }
     const f32x2 bias = {xm[dmzw::X_C1B + 2 * kp], xm[dmzw::X_C1B + 2 * kp + 1]};
     const float *xi = S.xin + d * XIN_H * XIN_W + (2 * pr) * XIN_W;
-    float *o0 = S.l1 + (d * 50 + 2 * kp) * 70 + pr * 7, *o1 = o0 + 70;
+    float *o0 = l1f + (d * 50 + 2 * kp) * 70 + pr * 7, *o1 = o0 + 70;
 #pragma unroll 1
     for (int pc = 0; pc < 7; pc++) {
       float patch[6][6];
@@ -823,9 +852,20 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
             }
           m = (a == 0 && b == 0) ? acc : __builtin_elementwise_max(m, acc);
         }
-      const f32x2 v = m + bias;
-      o0[pc] = v.x > 0.0f ? v.x : 0.0f;
-      o1[pc] = v.y > 0.0f ? v.y : 0.0f;
+      f32x2 v = m + bias;
+      v.x = v.x > 0.0f ? v.x : 0.0f;
+      v.y = v.y > 0.0f ? v.y : 0.0f;
+      if (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
+        o0[pc] = v.x;
+        o1[pc] = v.y;
+      } else {
+        // x = hi + lo + O(2^-16 x): hi = bf16(x), lo = bf16(x - hi); the two maps of the pair are neighbours
+        const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+        const bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), bf16x2);
+        const int e = (d * 70 + pr * 7 + pc) * C2_MP + 2 * kp;
+        *(uint32_t *)(l1h + e) = __builtin_bit_cast(uint32_t, hi);
+        *(uint32_t *)(l1l + e) = __builtin_bit_cast(uint32_t, lo);
+      }
     }
   }
   __syncthreads();
@@ -838,6 +878,12 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   // LDS (over l1, dead by then) where the 2 x 3 max-pool, bias and ReLU finish the layer.
   {
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 3; nt++) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
     int baseA[5];
 #pragma unroll
     for (int mt = 0; mt < 5; mt++) {
@@ -845,11 +891,6 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       const int d = pc / 18, pos = pc - 18 * d, r = pos / 3, c = pos - 3 * r;
       baseA[mt] = d * 3500 + r * 7 + c;
     }
-    f32x4 acc[5][3];
-#pragma unroll
-    for (int mt = 0; mt < 5; mt++)
-#pragma unroll
-      for (int nt = 0; nt < 3; nt++) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const float *c2p = xw + dmzx::CONV2_P + m16;
     const int ks0 = wave * 79, ks1 = imin(ks0 + 79, 313);
     // k -> offset of tap (map, i, j) inside l1[d]; the two padded k rows multiply zero weights
@@ -866,7 +907,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     {
       const int off = tap_off(4 * ks0 + kk);
 #pragma unroll
-      for (int mt = 0; mt < 5; mt++) an[mt] = S.l1[baseA[mt] + off];
+      for (int mt = 0; mt < 5; mt++) an[mt] = l1f[baseA[mt] + off];
     }
     for (int kb = ks0; kb < ks1; kb += 4) {
       float bc[4][3];
@@ -886,7 +927,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
           for (int mt = 0; mt < 5; mt++) av[mt] = an[mt];
           const int off = tap_off(4 * imin(ks + 1, ks1 - 1) + kk);
 #pragma unroll
-          for (int mt = 0; mt < 5; mt++) an[mt] = S.l1[baseA[mt] + off];
+          for (int mt = 0; mt < 5; mt++) an[mt] = l1f[baseA[mt] + off];
 #pragma unroll
           for (int mt = 0; mt < 5; mt++)
 #pragma unroll
@@ -895,8 +936,70 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
         }
       }
     }
+    } else {
+      // bf16 variants on v_mfma_f32_16x16x32_bf16.  K is ordered tap-major, eight maps per run, four runs per
+      // k-step: lane (row m16, run kk) of k-step ks holds run R = 4 ks + kk = tap R / 7, maps 8 (R % 7) .. + 7 --
+      // one aligned 16-byte LDS read per operand part; B comes fragment-ordered from global memory (L2).
+      // BF16X3: a.b ~ al.bh + ah.bl + ah.bh (small terms first), fp32 accumulation.
+      int baseA[5];  // byte offset of (digit, row, column) of the 6 x 3 output grid, tap (0, 0), map 0
+#pragma unroll
+      for (int mt = 0; mt < 5; mt++) {
+        const int pp = 16 * mt + m16, pc = pp < 72 ? pp : 0;
+        const int d = pc / 18, pos = pc - 18 * d, r = pos / 3, c = pos - 3 * r;
+        baseA[mt] = (d * 70 + r * 7 + c) * C2_MP * 2;
+      }
+      const unsigned char *ah_b = (const unsigned char *)l1h;
+      const bf16x8 *bhp = (const bf16x8 *)(xw + dmzx::CONV2_BH) + lane;
+      const bf16x8 *blp = (const bf16x8 *)(xw + dmzx::CONV2_BL) + lane;
+      constexpr int kPerWave = C2_KSTEPS / 4;
+      static_assert(kPerWave * 4 == C2_KSTEPS, "k-steps split evenly over the four waves");
+      const int ks0 = wave * kPerWave;
+      auto load_b = [&](int ks, bf16x8 (&h)[3], bf16x8 (&l)[3]) {
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+          h[nt] = bhp[(ks * 3 + nt) * 64];
+          if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) l[nt] = blp[(ks * 3 + nt) * 64];
+        }
+      };
+      // One k-step: all operand fragments loaded and WAITED FOR, then the 45 (15) matrix instructions, with
+      // scheduling barriers so that the compiler neither starts them under outstanding loads nor hoists the
+      // next k-step's loads into them.  Overlapped schedules (the compiler's own, or register sets rotating
+      // under software prefetch) were faster by a few per cent on an otherwise idle CU and WRONG in the
+      // younger of two workgroups sharing a CU: accumulators came out different from run to run while
+      // operand fragments, LDS contents and the matrix instruction itself check out one by one
+      // (tools/dev/expiry_model_dup.py, tools/ubench/mfma_*_coresident.hip).  The strict form is
+      // deterministic in every configuration tried; the other workgroup of the CU hides its bubbles.
+#pragma unroll 1
+      for (int ks = ks0; ks < ks0 + kPerWave; ks++) {
+        bf16x8 ah[5], al[5], bh[3], bl[3];
+        load_b(ks, bh, bl);
+        const int R = 4 * ks + kk;
+        const int q7 = (R * 9363) >> 16;  // R / 7 for R < 176
+        const int t = imin(q7, 24);       // run 175 is padding (zero weights)
+        const int i5 = (t * 13) >> 6;     // t / 5
+        const int offA = ((i5 * 7 + (t - 5 * i5)) * C2_MP + 8 * (R - 7 * q7)) * 2;
+#pragma unroll
+        for (int mt = 0; mt < 5; mt++) {
+          ah[mt] = *(const bf16x8 *)(ah_b + baseA[mt] + offA);
+          if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) al[mt] = *(const bf16x8 *)(ah_b + L1_BF16_ELEMS * 2 + baseA[mt] + offA);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+          for (int nt = 0; nt < 3; nt++) {
+            if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) {  // small terms first
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __syncthreads();  // every wave is done with l1
-    float *part = S.l1;  // [4 waves][72][40]
+    float *part = l1f;  // [4 waves][72][40]
 #pragma unroll
     for (int mt = 0; mt < 5; mt++)
 #pragma unroll
@@ -918,7 +1021,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
         m = q == 0 ? t : fmaxf(m, t);
       }
       const float v = m + xm[dmzw::X_C2B + nn];
-      S.l2[idx] = v > 0.0f ? v : 0.0f;
+      l2[idx] = v > 0.0f ? v : 0.0f;
     }
   }
   __syncthreads();
@@ -932,7 +1035,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     const float *fc1t = xw + dmzx::FC1_T;
     float a1[30];
 #pragma unroll
-    for (int ks = 0; ks < 30; ks++) a1[ks] = m16 < nd ? S.l2[m16 * 120 + 4 * ks + kk] : 0.0f;
+    for (int ks = 0; ks < 30; ks++) a1[ks] = m16 < nd ? l2[m16 * 120 + 4 * ks + kk] : 0.0f;
     for (int nt = wave; nt < 11; nt += XC_THREADS / 64) {
       float b1[30];
 #pragma unroll
@@ -948,7 +1051,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
         for (int v = 0; v < 4; v++)
           if (v < nd) {
             const float t = acc[v] + hb;
-            S.l3[v * 176 + j] = t > 0.0f ? t : 0.0f;
+            l3[v * 176 + j] = t > 0.0f ? t : 0.0f;
           }
       }
     }
@@ -959,7 +1062,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     float a2[44], b2[44];
 #pragma unroll
     for (int ks = 0; ks < 44; ks++) {
-      a2[ks] = m16 < nd ? S.l3[m16 * 176 + 4 * ks + kk] : 0.0f;
+      a2[ks] = m16 < nd ? l3[m16 * 176 + 4 * ks + kk] : 0.0f;
       b2[ks] = m16 < 10 ? xm[dmzw::X_LW + m16 * 176 + 4 * ks + kk] : 0.0f;
     }
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -980,6 +1083,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   __syncthreads();
 }
 
+template <int MODE>
 __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
                                                            const DmzExpiryTables *__restrict__ tab,
                                                            const uint8_t *__restrict__ cards, size_t card_stride,
@@ -1031,7 +1135,7 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__res
   const int n_groups = S.n_groups;
   const uint8_t *card = cards + (size_t)f * card_stride;
   // prep scratch over l1 (dead until the first convolution)
-  unsigned char *gp = (unsigned char *)S.l1;               // 4 x 176 gradient / equalised patch
+  unsigned char *gp = S.l1raw;                             // 4 x 176 gradient / equalised patch
   unsigned char *sm = gp + 4 * 176;                        // 4 x 176 smoothed
   unsigned int *hist = (unsigned int *)(gp + 2 * 4 * 176); // 4 x 256
   for (int g = 0; g < n_groups; g++) {
@@ -1094,7 +1198,7 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__res
     __syncthreads();
     for (int p = lane; p < 176; p += 64) S.xf[d * 176 + p] = (float)sm[d * 176 + p] * (1.0f / 255.0f);
     __syncthreads();
-    expiry_cnn_block(wts, xw, S, 4, &er->groups[g].scores[0][0], tid);
+    expiry_cnn_block<MODE>(wts, xw, S, 4, &er->groups[g].scores[0][0], tid);
   }
 }
 
@@ -1128,6 +1232,7 @@ __global__ __launch_bounds__(64) void k_slash_model(const float *__restrict__ wt
 }
 
 // applyc_bf4dd6c8 on n inputs, four per workgroup
+template <int MODE>
 __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_model(const float *__restrict__ wts, const float *__restrict__ xw,
                                                              const float *__restrict__ x, int n, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1138,7 +1243,7 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_model(const float *__r
   for (int i = tid; i < 4 * XIN_H * XIN_W; i += XC_THREADS) S.xin[i] = 0.0f;
   for (int i = tid; i < nd * 176; i += XC_THREADS) S.xf[i] = x[(size_t)first * 176 + i];
   __syncthreads();
-  expiry_cnn_block(wts, xw, S, nd, out + (size_t)first * 10, tid);
+  expiry_cnn_block<MODE>(wts, xw, S, nd, out + (size_t)first * 10, tid);
 }
 
 }  // namespace
@@ -1147,29 +1252,47 @@ int dmz_configure_expiry(void) {
 #ifndef DMZ_XCAT_PAD  /* developer ablation: extra dynamic LDS = fewer workgroups per CU */
 #define DMZ_XCAT_PAD 0
 #endif
-  hipError_t e = hipFuncSetAttribute((const void *)k_expiry_cat, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(CatLds) + DMZ_XCAT_PAD);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void *)k_expiry_model, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CatLds));
-  return (int)e;
+  const void *kernels[6] = {(const void *)k_expiry_cat<0>,   (const void *)k_expiry_cat<1>,   (const void *)k_expiry_cat<2>,
+                            (const void *)k_expiry_model<0>, (const void *)k_expiry_model<1>, (const void *)k_expiry_model<2>};
+  for (int i = 0; i < 6; i++) {
+    hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(CatLds) + DMZ_XCAT_PAD);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
 }
 
 void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, const DmzExpiryTables *tables,
                        const uint8_t *cards, size_t card_stride, int n, const dmz_hip_frame_result *results,
-                       DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid) {
+                       DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid, int conv_mode) {
   hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
   hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
                      out, stage);
   if (mid) (void)hipEventRecord(mid, s);
-  hipLaunchKernelGGL(k_expiry_cat, dim3((unsigned)n), dim3(XC_THREADS), sizeof(CatLds) + DMZ_XCAT_PAD, s, weights, xw, tables, cards,
-                     card_stride, n, results, stage, out);
+  const dim3 grid((unsigned)n), block(XC_THREADS);
+  const size_t lds = sizeof(CatLds) + DMZ_XCAT_PAD;
+  if (conv_mode == DMZ_HIP_EXPIRY_CONV_F32)
+    hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_F32>, grid, block, lds, s, weights, xw, tables, cards, card_stride, n,
+                       results, stage, out);
+  else if (conv_mode == DMZ_HIP_EXPIRY_CONV_BF16)
+    hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_BF16>, grid, block, lds, s, weights, xw, tables, cards, card_stride, n,
+                       results, stage, out);
+  else
+    hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_BF16X3>, grid, block, lds, s, weights, xw, tables, cards, card_stride,
+                       n, results, stage, out);
 }
 
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out) {
   hipLaunchKernelGGL(k_slash_model, dim3((unsigned)n), dim3(64), 0, s, weights, xw, x, n, out);
 }
 
-void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out) {
-  hipLaunchKernelGGL(k_expiry_model, dim3((unsigned)((n + 3) / 4)), dim3(XC_THREADS), sizeof(CatLds), s, weights, xw, x,
-                     n, out);
+void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out,
+                             int conv_mode) {
+  const dim3 grid((unsigned)((n + 3) / 4)), block(XC_THREADS);
+  if (conv_mode == DMZ_HIP_EXPIRY_CONV_F32)
+    hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_F32>, grid, block, sizeof(CatLds), s, weights, xw, x, n, out);
+  else if (conv_mode == DMZ_HIP_EXPIRY_CONV_BF16)
+    hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_BF16>, grid, block, sizeof(CatLds), s, weights, xw, x, n, out);
+  else
+    hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_BF16X3>, grid, block, sizeof(CatLds) + DMZ_XCAT_PAD, s, weights, xw, x, n, out);
 }
