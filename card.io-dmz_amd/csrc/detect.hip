@@ -129,7 +129,7 @@ template <bool VERT>
 __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, int low,
                                           int high, int dxc, int dyc, int mp, int mp_lo, int mp_hi,
                                           int mc, int mc_lo, int mc_hi, int mn, int mn_lo, int mn_hi,
-                                          unsigned char *map, unsigned short *list, int *s_int) {
+                                          unsigned char *map, unsigned short *list, int list_cap, int *s_int) {
   const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
   const int m = mc;
   // neighbours in image coordinates
@@ -176,13 +176,15 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   map[q] = (unsigned char)flags;
   if ((flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND) {  // seeds need no propagation
     const int slot = atomicAdd(&s_int[2], 1);
-    if (slot < bp.list_cap) list[slot] = (unsigned short)q;
+    if (slot < list_cap) list[slot] = (unsigned short)q;
     else s_int[3] = 1;
   }
 }
 
-// SC > 0: the box has exactly SC steps (compile time) and the walk runs once; SC == 0: any size, two walks
-template <bool VERT, int NT, int SC>
+// SC > 0: the box has exactly SC steps (compile time) and the walk runs once; SC == 0: any size, two walks.
+// RG: how many of the SC packed gradients a lane keeps in registers; the rest is parked in LDS over the edge
+// map and the vote counters, which nobody needs before the NMS pass (see the single-walk branch).
+template <bool VERT, int NT, int SC, int RG>
 __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_stride, int row_stride,
                             const DmzBoxParams &bp, int frame, int box_id,
                             DmzBoxHit *__restrict__ hits, unsigned char *lds) {
@@ -193,10 +195,19 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   const uint32_t inv_L = bp.inv_w;
   const int off = bp.tile_off, sp = bp.tile_stride;
 
+  // LDS regions: source tile | edge map | vote counters | scratch.  In the parked single-walk form the edge map
+  // moves over the tile (dead once the walk is done; L * S <= tile bytes), the packed gradients of the steps
+  // that do not fit in registers take the old map + counter space, followed by the candidate list: waves
+  // run the NMS pass at their own pace, so what one wave writes there (map rows, list entries) must never
+  // overlap gradients another wave has yet to read.
+  constexpr bool kParked = SC > 0 && RG < SC;
   unsigned char *tile = lds;
-  unsigned char *map = lds + bp.lds_map;
+  unsigned char *map = kParked ? lds : lds + bp.lds_map;
   unsigned int *acc32 = (unsigned int *)(lds + bp.lds_acc);
-  unsigned short *list = (unsigned short *)(lds + bp.lds_acc);  // candidate list, before voting
+  // candidate list, before voting: over the vote counters (behind the parked gradients, if any)
+  const int park_bytes = kParked ? ((4 * bp.lanes * (SC - RG) + 15) & ~15) : 0;
+  unsigned short *list = kParked ? (unsigned short *)(lds + bp.lds_map + park_bytes) : (unsigned short *)(lds + bp.lds_acc);
+  const int list_cap = kParked ? (bp.lds_red - bp.lds_map - park_bytes) / 2 : bp.list_cap;
   long long *s_red = (long long *)(lds + bp.lds_red);                    // 16 x 8 B
   unsigned long long *s_best = (unsigned long long *)(lds + bp.lds_red + 128);  // 16 x 8 B
   int *s_int = (int *)(lds + bp.lds_red + 256);                          // low, high, ncand, overflow
@@ -300,21 +311,40 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     // ---- B+C, single walk.  g[s] = (dy << 16 | dx & 0xffff) ^ 0x80008000: each half is the gradient
     // plus 32768 as an unsigned 16-bit number, so |dx| + |dy| = v_sad_u16(g, 0x80008000, 0) exactly
     // (|-32768| = 32768 included), and dx, dy come back with one xor, one v_bfe_i32, one shift.
-    uint32_t g[SC];
+    // Parked gradients: step k >= RG of column l at gpark[(k - RG) * L + l].
+    uint32_t g[RG];
+    uint32_t *gpark = (uint32_t *)(lds + bp.lds_map);
+    static_assert(RG == SC || (RG % 7 == 0 && (SC - RG) % 7 == 0), "the parked part walks in groups of seven");
     {
       Window wn;
       window_init(c, wn);
       int acc = 0;
-#pragma unroll
-      for (int s0 = 0; s0 < SC; s0++) {
-        int dx, dy;
-        window_step_s<VERT>(c, wn, s0, dx, dy);
+      auto pack = [&](int dx, int dy) {
         const int ax = iabs(dx), ay = iabs(dy);
         acc += (ax > 32767 ? 32767 : ax) + (ay > 32767 ? 32767 : ay);  // cvAbs: 32768 -> 32767
-        g[s0] = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u) ^ 0x80008000u;
-#if DMZ_DETECT_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: hoisted tile reads cost registers
-#endif
+        return __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u) ^ 0x80008000u;
+      };
+#pragma unroll
+      for (int s0 = 0; s0 < RG; s0++) {
+        int dx, dy;
+        window_step_s<VERT>(c, wn, s0, dx, dy);
+        g[s0] = pack(dx, dy);
+      }
+      if constexpr (RG < SC) {
+        // the parked steps: a rolled loop over groups of seven (window slots stay compile-time constants)
+#define DMZ_PARK_STEP(K)                                                                       \
+  {                                                                                             \
+    int dx, dy;                                                                                 \
+    window_step<VERT, K>(c, wn, sb + K, dx, dy);                                                \
+    const uint32_t packed = pack(dx, dy);                                                       \
+    if (owner) gpark[(sb + K - RG) * L + c.l] = packed; /* one writer per column */             \
+  }
+#pragma unroll 1
+        for (int sb = RG; sb < SC; sb += 7) {
+          DMZ_PARK_STEP(0) DMZ_PARK_STEP(1) DMZ_PARK_STEP(2) DMZ_PARK_STEP(3)
+          DMZ_PARK_STEP(4) DMZ_PARK_STEP(5) DMZ_PARK_STEP(6)
+        }
+#undef DMZ_PARK_STEP
       }
       thresholds_from(owner ? (long long)acc : 0ll);  // steps * 65534 fits an int for any box that fits LDS
     }
@@ -325,9 +355,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       int mp = 0, mp_lo = 0, mp_hi = 0;
       int mc = 0, mc_lo = 0, mc_hi = 0;
       uint32_t gc = 0x80008000u;
-#pragma unroll
-      for (int sn = 0; sn <= SC; sn++) {
-        const uint32_t gn = sn < SC ? g[sn < SC ? sn : 0] : 0x80008000u;
+      auto nms_step = [&](int sn, uint32_t gn) {
         // outside the ROI the magnitude is 0
         const int mn = (sn < SC && inbox) ? (int)__builtin_amdgcn_sad_u16(gn, 0x80008000u, 0u) : 0;
         const int mn_lo = __shfl_up(mn, 1, 64);    // lane - 1
@@ -336,14 +364,20 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
           const uint32_t h = gc ^ 0x80008000u;
           const int dxc = (int)(short)(h & 0xffffu), dyc = (int)h >> 16;
           nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo, mc_hi, mn, mn_lo, mn_hi,
-                          map, list, s_int);
+                          map, list, list_cap, s_int);
         }
         mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;
         mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;
         gc = gn;
-#if DMZ_DETECT_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+      };
+#pragma unroll
+      for (int sn = 0; sn < RG; sn++) nms_step(sn, g[sn]);
+      if constexpr (RG < SC) {
+#pragma unroll 1
+        for (int sn = RG; sn <= SC; sn++)
+          nms_step(sn, (sn < SC && inbox) ? gpark[(sn - RG) * L + c.l] : 0x80008000u);
+      } else {
+        nms_step(SC, 0x80008000u);
       }
       __syncthreads();
     }
@@ -394,7 +428,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     const int mn_hi = __shfl_down(mn, 1, 64); /* lane + 1 */                              \
     if (sn >= 1 && owner)                                                                 \
       nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo,    \
-                      mc_hi, mn, mn_lo, mn_hi, map, list, s_int);                         \
+                      mc_hi, mn, mn_lo, mn_hi, map, list, list_cap, s_int);               \
     mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;                                                \
     mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;                                                \
     dxc = dxn; dyc = dyn;                                                                 \
@@ -538,27 +572,27 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 // VERT = false: boxes 0 and 2 (top, bottom: horizontal lines, lanes = columns);
 // VERT = true:  boxes 1 and 3 (left, right: vertical lines, lanes = rows).
 // waves per SIMD the register allocation aims at: four workgroups per CU (what the LDS tiles allow)
-#ifndef DMZ_DETECT_SCHED_BARRIER
-#define DMZ_DETECT_SCHED_BARRIER 0
-#endif
 // Measured (ms per 16 384 frames, both boxes pairs): two walks everywhere 2.22; single walk for the
 // left/right boxes only 2.08; for the top/bottom boxes only 2.21 -- their 28 packed gradients push
 // the kernel from 62 to ~100 registers (two 448-thread workgroups per CU instead of four), and what
 // the walk saves in VALU issue (-33 % instructions) is lost to barrier and LDS latency at that
 // occupancy; with 72 registers forced the allocator spills 43 dwords and it is slower still.
 #ifndef DMZ_DETECT_SINGLE_H
-#define DMZ_DETECT_SINGLE_H 0
+#define DMZ_DETECT_SINGLE_H 1
+#endif
+#ifndef DMZ_DETECT_REGS_H  /* top/bottom boxes: packed gradients kept in registers (the other 28 - n are parked in LDS) */
+#define DMZ_DETECT_REGS_H 14
 #endif
 #ifndef DMZ_DETECT_SINGLE_V
 #define DMZ_DETECT_SINGLE_V 1
 #endif
 #ifndef DMZ_DETECT_WPS_H
-#define DMZ_DETECT_WPS_H 5
+#define DMZ_DETECT_WPS_H 7
 #endif
 #ifndef DMZ_DETECT_WPS_V
 #define DMZ_DETECT_WPS_V 4
 #endif
-template <bool VERT, int NT, int SC>
+template <bool VERT, int NT, int SC, int RG>
 __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H)) void k_detect_walk(const uint8_t *__restrict__ planes,
                                                      size_t frame_stride, int row_stride,
                                                      DmzDetectParams params,
@@ -568,20 +602,20 @@ __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DE
   const int frame = blockIdx.x >> 1;  // 1-D grid: gridDim.y is limited to 65535
   const int box_id = (blockIdx.x & 1) * 2 + (VERT ? 1 : 0);
   if (skip_mask && skip_mask[frame * 4 + box_id]) return;
-  detect_body<VERT, NT, SC>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
+  detect_body<VERT, NT, SC, RG>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
 }
 
-template <bool VERT, int NT, int SC>
+template <bool VERT, int NT, int SC, int RG>
 int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
                 const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask, int lds_bytes) {
   static int configured_lds = 0;  // per instantiation
   if (lds_bytes > configured_lds) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT, SC>,
+    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT, SC, RG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
     configured_lds = lds_bytes;
   }
-  hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
+  hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC, RG>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
                      frame_stride, row_stride, p, hits, skip_mask);
   return 0;
 }
@@ -593,12 +627,16 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
   const int nt = a.nthreads > b.nthreads ? a.nthreads : b.nthreads;
   const int lds = a.lds_total > b.lds_total ? a.lds_total : b.lds_total;
   // the boxes of a 640 x 480 frame (28 steps x 389 lanes, 38 steps x 241 lanes): single-walk kernels
-  constexpr int kSteps = VERT ? 38 : 28, kNt = VERT ? 256 : 448;
-  if (a.steps == kSteps && b.steps == kSteps && nt <= kNt && (VERT ? DMZ_DETECT_SINGLE_V : DMZ_DETECT_SINGLE_H))
-    return launch_pair<VERT, kNt, kSteps>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
-  if (nt <= 256) return launch_pair<VERT, 256, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
-  if (nt <= 448) return launch_pair<VERT, 448, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
-  return launch_pair<VERT, 1024, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  constexpr int kSteps = VERT ? 38 : 28, kNt = VERT ? 256 : 448, kRegs = VERT ? 38 : DMZ_DETECT_REGS_H;
+  auto parks = [](const DmzBoxParams &q) {  // the parked gradients and a list of >= 1024 entries fit, the map fits the tile
+    return q.lds_red - q.lds_map - ((4 * q.lanes * (kSteps - kRegs) + 15) & ~15) >= 2048 && q.lanes * q.steps <= q.lds_map;
+  };
+  if (a.steps == kSteps && b.steps == kSteps && nt <= kNt && (VERT ? DMZ_DETECT_SINGLE_V : DMZ_DETECT_SINGLE_H) &&
+      (kRegs == kSteps || (parks(a) && parks(b))))
+    return launch_pair<VERT, kNt, kSteps, kRegs>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  if (nt <= 256) return launch_pair<VERT, 256, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  if (nt <= 448) return launch_pair<VERT, 448, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
+  return launch_pair<VERT, 1024, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
 }
 
 }  // namespace
