@@ -208,6 +208,13 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
     bp.slope_a = tanf((float)(DMZ_PI * (90 - gat) / 180.0f));
     bp.slope_b = tanf((float)(DMZ_PI * (90 + gat) / 180.0f));
   }
+  // the float quotient dy / dx rounds to >= slope_a exactly when the real quotient is >= the midpoint of
+  // slope_a and the float below it (a tie is impossible: the midpoint has 25 significant bits at an exponent
+  // where a quotient of two 16-bit integers has a denominator below 2^16), likewise for <= slope_b
+  bp.slope_ta = ((double)nextafterf(bp.slope_a, -INFINITY) + (double)bp.slope_a) * 0.5;
+  bp.slope_tb = ((double)nextafterf(bp.slope_b, INFINITY) + (double)bp.slope_b) * 0.5;
+  if (!(fabsf(bp.slope_a) < 64.0f && fabsf(bp.slope_b) < 64.0f && fabsf(bp.slope_a) > 1e-3f && fabsf(bp.slope_b) > 1e-3f))
+    return fail(ctx, DMZ_HIP_EUNSUPPORTED, "Hough slope bounds outside the exact-compare range");
   // geometry.cpp:34-43 for origin (x, y) of this box and each candidate angle.
   // NB: the shift uses the ORIGINAL rectangle origin handed to lineByShiftingOrigin
   // (detection_rects[i].x/.y, dmz.cpp:364), which equals the clipped one for in-image boxes.

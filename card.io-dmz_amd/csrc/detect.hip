@@ -123,8 +123,16 @@ __device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int 
   dy = clampi(VERT ? g_ds : g_sd, -32768, 32767);
 }
 
+// lane - 1 / lane + 1 of the wave by DPP (wave_shr:1 / wave_shl:1; the end lanes keep their own value, like
+// __shfl_up / __shfl_down): one VALU instruction instead of a ds_bpermute round trip
+__device__ __forceinline__ int lane_below(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_above(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+
 // NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
 // given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
+// The reference's branches are kept: a wave whose 62 pixels are all below the low threshold (most of
+// the background) skips the direction test, and the slope gate runs only where a pixel survived
+// (straight-line selects measured 17 % slower on the whole kernel).
 template <bool VERT>
 __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, int low,
                                           int high, int dxc, int dyc, int mp, int mp_lo, int mp_hi,
@@ -159,13 +167,16 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
     }
     if (is_max) {
       flags = MAP_CAND | (m > high ? MAP_EDGE : 0);
-      // Hough slope gate (hough.cpp:133-150); only edge pixels ever vote, so it is evaluated
-      // for NMS survivors only
+      // Hough slope gate (hough.cpp:133-150), evaluated for NMS survivors only (only edge pixels ever
+      // vote): (float)dy / (float)dx against the two tangents, without the division.  The float quotient
+      // is >= a exactly when the real quotient is >= the midpoint below a (no quotient of two 16-bit
+      // integers can sit ON a midpoint of neighbouring floats of this magnitude), likewise <= b; with the
+      // sign of dx folded into dy both become one exact fp64 multiply-and-compare (25 + 16 bits).
       bool use;
       if (dxc != 0) {
-        const float slope = (float)dyc / (float)dxc;
-        use = VERT ? (slope >= bp.slope_a && slope <= bp.slope_b)
-                   : (slope >= bp.slope_a || slope <= bp.slope_b);
+        const double ya = (double)(dxc < 0 ? -dyc : dyc), xa = (double)(int)ax;
+        const bool ge_a = ya >= bp.slope_ta * xa, le_b = ya <= bp.slope_tb * xa;
+        use = VERT ? (ge_a && le_b) : (ge_a || le_b);
       } else {
         use = !VERT;
       }
@@ -174,10 +185,19 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   }
   const int q = s * c.L + c.l;  // walk-space index
   map[q] = (unsigned char)flags;
-  if ((flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND) {  // seeds need no propagation
-    const int slot = atomicAdd(&s_int[2], 1);
-    if (slot < list_cap) list[slot] = (unsigned short)q;
-    else s_int[3] = 1;
+  // candidates that are not seeds go on the list (seeds need no propagation): one counter update per wave
+  const bool cand = (flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND;
+  const unsigned long long bal = __ballot(cand);
+  if (bal) {
+    int base = 0;
+    const int first = __builtin_ctzll(bal);
+    if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&s_int[2], __popcll(bal));
+    base = __builtin_amdgcn_readlane(base, first);
+    if (cand) {
+      const int slot = base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
+      if (slot < list_cap) list[slot] = (unsigned short)q;
+      else s_int[3] = 1;
+    }
   }
 }
 
@@ -358,8 +378,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       auto nms_step = [&](int sn, uint32_t gn) {
         // outside the ROI the magnitude is 0
         const int mn = (sn < SC && inbox) ? (int)__builtin_amdgcn_sad_u16(gn, 0x80008000u, 0u) : 0;
-        const int mn_lo = __shfl_up(mn, 1, 64);    // lane - 1
-        const int mn_hi = __shfl_down(mn, 1, 64);  // lane + 1
+        const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);
         if (sn >= 1 && owner) {
           const uint32_t h = gc ^ 0x80008000u;
           const int dxc = (int)(short)(h & 0xffffu), dyc = (int)h >> 16;
@@ -424,8 +443,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       window_step<VERT, K>(c, wn, sn, dxn, dyn);                                          \
       mn = inbox ? iabs(dxn) + iabs(dyn) : 0; /* outside the ROI the magnitude is 0 */   \
     }                                                                                     \
-    const int mn_lo = __shfl_up(mn, 1, 64);   /* lane - 1 */                              \
-    const int mn_hi = __shfl_down(mn, 1, 64); /* lane + 1 */                              \
+    const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);                             \
     if (sn >= 1 && owner)                                                                 \
       nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo,    \
                       mc_hi, mn, mn_lo, mn_hi, map, list, list_cap, s_int);               \

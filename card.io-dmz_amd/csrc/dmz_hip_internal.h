@@ -46,6 +46,8 @@ struct DmzBoxParams {
   int tab_sin[kNumAngle];
   int tab_cos[kNumAngle];
   float slope_a, slope_b;        // hough.cpp:117-124
+  double slope_ta, slope_tb;     // (float)dy / (float)dx >= slope_a  <=>  dy / dx >= slope_ta (midpoint below
+                                 // slope_a); <= slope_b  <=>  dy / dx <= slope_tb (midpoint above slope_b)
   float theta_n[kNumAngle];      // n*theta + theta_min (float)
   double delta_rho[kNumAngle];   // geometry.cpp:37-40 for this box origin and angle n
   float cos_t[kNumAngle];        // cosf(theta_n), geometry.cpp:22
