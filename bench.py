@@ -377,6 +377,29 @@ def main():
     for _ in range(prof_steps):
         hot_path(0)
     stage = ctx.stage_times(reset=True)
+    # BASELINE configs[3] "bf16 conv with fp32 parity check": the expiry CNN's conv2 in its three arithmetic
+    # variants on the same frames (untimed extra steps): stage time, score difference and digit agreement
+    # against the fp32 variant.  The timed region above ran the default (BF16X3).
+    variants = None
+    if with_expiry and rank == 0:
+        variants = {}
+        ref_scores = None
+        for name, mode in (("f32", pkg.EXPIRY_CONV_F32), ("bf16x3", pkg.EXPIRY_CONV_BF16X3), ("bf16", pkg.EXPIRY_CONV_BF16)):
+            ctx.set_expiry_conv(mode)
+            ctx.stage_times(reset=True)
+            hot_path(0)
+            ms = ctx.stage_times(reset=True)["expiry_cat"][0]
+            ex = expiry_b[0].cpu().numpy().view(pkg.EXPIRY_DTYPE).reshape(-1)
+            live = (np.arange(pkg.EXPIRY_MAX_GROUPS)[None, :] < ex["n_groups"][:, None]) & (ex["categorised"][:, None] != 0)
+            sc = ex["groups"]["scores"][live]  # [groups, 4, 10]
+            if ref_scores is None:
+                ref_scores = sc
+            variants[name] = {"expiry_cat_ms": round(ms, 4),
+                              "max_abs_score_diff_vs_f32": float(np.abs(sc - ref_scores).max()) if sc.size else 0.0,
+                              "digit_match_vs_f32": float((sc.argmax(-1) == ref_scores.argmax(-1)).mean()) if sc.size else 1.0,
+                              "groups": int(sc.shape[0])}
+        ctx.set_expiry_conv(pkg.EXPIRY_CONV_BF16X3)
+        hot_path(0)  # the records reported below come from the default variant again
     ctx.set_profiling(False)
 
     if rank == 0:
@@ -457,6 +480,8 @@ def main():
                                % (world, " + 1.6 KiB expiry" if with_expiry else ""),
                 "gate_pass_rates": gates,
                 "device_ms_per_step": round(dev_ms / args.steps, 3),
+                **({"expiry_conv": "bf16x3 (default: bf16 matrix core on split operands, fp32 accumulation)",
+                    "expiry_conv_variants": variants} if variants else {}),
             },
             "roofline": roof,
             "stages": per_stage,
