@@ -388,7 +388,7 @@ int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int
              dmz_hip_frame_result *results) {
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_VSEG);
-    dmz_launch_vseg(ctx->stream, ctx->d_weights, cards, card_stride, n, mode, results);
+    dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_hidwt + dmzv::WFRAG, cards, card_stride, n, mode, results);
   }
   if (mode & DMZ_HIP_SCAN_SKIP_NUMBER) {  // scan_card_image(collect_card_number = false), frame.cpp:49
     HIP_TRY(ctx, hipGetLastError());
@@ -477,11 +477,23 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     return DMZ_HIP_ENODEVICE;
   }
   const float *w = (const float *)(dmz_weights_blob + 16);
-  std::vector<float> hidwt(3 * 320 * 32);
+  std::vector<float> hidwt(3 * 320 * 32 + dmzv::WFRAG_FLOATS);
   for (int m = 0; m < 3; m++)
     for (int j = 0; j < 32; j++)
       for (int i = 0; i < 320; i++)
         hidwt[(size_t)m * 320 * 32 + j * 320 + i] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
+  // vseg hidden layer in matrix-core fragment order [wave 4][k-block 13][lane 64][4]: lane (unit = 16 wave +
+  // (lane & 15), kk = lane >> 4) of block u holds W1[unit][16 u + 4 kk .. + 3] (zero beyond unit 49 / k 203)
+  {
+    float *wf = hidwt.data() + dmzv::WFRAG;
+    for (int wv = 0; wv < 4; wv++)
+      for (int u = 0; u < 13; u++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 4; e++) {
+            const int j = 16 * wv + (lane & 15), k = 16 * u + 4 * (lane >> 4) + e;
+            wf[((wv * 13 + u) * 64 + lane) * 4 + e] = (j < 50 && k < 204) ? w[dmzw::VSEG_W1 + j * 204 + k] : 0.0f;
+          }
+  }
   // expiry models: slash W1 input-major, conv2 tap-major, FC1 input-major (coalesced across lanes)
   std::vector<float> xw(dmzx::TOTAL);
   {

@@ -141,7 +141,12 @@ void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMa
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride);
-void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
+// vseg hidden-layer weights in fragment order, appended to the digit hidden-matrix buffer (float offsets)
+namespace dmzv {
+constexpr int WFRAG = 3 * 320 * 32;
+constexpr int WFRAG_FLOATS = 4 * 13 * 64 * 4;
+}  // namespace dmzv
+void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag /* dmzv layout */, const uint8_t *cards, size_t card_stride,
                      int n, int mode /* DMZ_HIP_SCAN_* */, dmz_hip_frame_result *results);
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results);

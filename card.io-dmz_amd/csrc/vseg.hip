@@ -166,7 +166,12 @@ __device__ __forceinline__ float feat_of(uint32_t word, int byte, float fs, floa
 
 // Hidden + logistic layers for `nrows` rows.  Wave `wave` owns hidden units
 // 16*wave .. 16*wave+15; bw[u] holds W1[j][16u + 4kk .. +3] for this lane's (kk, j).
-__device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], float b1, float w20,
+// VS_RES of the 13 k-blocks of this wave's weights stay in registers (bw), the others are streamed per tile
+// pair from the fragment-ordered copy (wf: this wave's 13 x 64 float4, one coalesced 1-KB load per block):
+// all 52 registers of weights do not fit beside the seven-workgroups-per-CU register budget, and what the
+// allocator spilled went to scratch -- 39 KB of HBM writes per card -- and came back from there per tile pair.
+template <int RES>
+__device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[RES], const f32x4 *__restrict__ wf, float b1, float w20,
                                               float w21, float w22,
                                               const unsigned char *__restrict__ grad,
                                               const float *__restrict__ norm, int nrows,
@@ -197,17 +202,25 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
     const float fs0 = norm[2 * r0], fb0 = norm[2 * r0 + 1];
     const float fs1 = norm[2 * r1], fb1 = norm[2 * r1 + 1];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < VS_KSTEPS; u++) {
+    auto step2 = [&](int u, const f32x4 &b) {
       const uint32_t g0 = a0p[4 * u], g1 = a1p[4 * u];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), bw[u].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 0, fs1, fb1), bw[u].x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), bw[u].y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 1, fs1, fb1), bw[u].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), bw[u].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 2, fs1, fb1), bw[u].z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), bw[u].w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 3, fs1, fb1), bw[u].w, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), b.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 0, fs1, fb1), b.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), b.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 1, fs1, fb1), b.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), b.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 2, fs1, fb1), b.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), b.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 3, fs1, fb1), b.w, acc1, 0, 0, 0);
+    };
+    f32x4 ws = RES < VS_KSTEPS ? wf[RES * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};  // first streamed block: in flight
+#pragma unroll
+    for (int u = 0; u < RES; u++) step2(u, bw[u]);
+#pragma unroll 1
+    for (int u = RES; u < VS_KSTEPS; u++) {  // rolled: unrolled, all the loads are hoisted and spill again
+      const f32x4 b = ws;
+      ws = wf[imin(u + 1, VS_KSTEPS - 1) * 64];
+      step2(u, b);
     }
     finish_tile(acc0, mt);
     finish_tile(acc1, mt + 1);
@@ -218,13 +231,21 @@ __device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[VS_KSTEPS], floa
     const uint32_t *a0p = (const uint32_t *)(grad + r0 * VS_GSTRIDE + 4 * kk);
     const float fs0 = norm[2 * r0], fb0 = norm[2 * r0 + 1];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < VS_KSTEPS; u++) {
+    auto step1 = [&](int u, const f32x4 &b) {
       const uint32_t g0 = a0p[4 * u];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), bw[u].x, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), bw[u].y, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), bw[u].z, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), bw[u].w, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), b.x, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), b.y, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), b.z, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), b.w, acc0, 0, 0, 0);
+    };
+    f32x4 ws = RES < VS_KSTEPS ? wf[RES * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < RES; u++) step1(u, bw[u]);
+#pragma unroll 1
+    for (int u = RES; u < VS_KSTEPS; u++) {
+      const f32x4 b = ws;
+      ws = wf[imin(u + 1, VS_KSTEPS - 1) * 64];
+      step1(u, b);
     }
     finish_tile(acc0, mt);
   }
@@ -329,7 +350,11 @@ __device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts,
   w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
 }
 
+#ifndef VS_RES  /* k-blocks of the hidden weights a wave keeps in registers (of 13) */
+#define VS_RES 3
+#endif
 __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const float *__restrict__ wts,
+                                                      const f32x4 *__restrict__ wfrag,
                                                       const uint8_t *__restrict__ cards,
                                                       size_t card_stride, int n, int mode,
                                                       dmz_hip_frame_result *__restrict__ results) {
@@ -369,11 +394,23 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = (unsigned short)(4 * i);
   __syncthreads();
   vseg_prepare_rows(card, row_y, VS_MAXROWS, grad, norm, wave, lane);
-  VsegWeights w;
-  vseg_load_weights(wts, wave, lane, w);
+  // this wave's hidden units 16 wave .. + 15: resident weight blocks, bias and the logistic weights
+  const f32x4 *wf = wfrag + wave * VS_KSTEPS * 64 + lane;
+  f32x4 bwr[VS_RES];
+#pragma unroll
+  for (int u = 0; u < VS_RES; u++) bwr[u] = wf[u * 64];
+  struct { float b1, w20, w21, w22; } w;
+  {
+    const int j = 16 * wave + (lane & 15);
+    const bool unit = j < 50;
+    w.b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
+    w.w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
+    w.w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
+    w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
+  }
   __syncthreads();
   VS_STOP(1, grad[0] + norm[5])
-  vseg_mlp_rows(w.bw, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
+  vseg_mlp_rows<VS_RES>(bwr, wf, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
   __syncthreads();
   VS_STOP(2, part[0] + part[100])
   vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
@@ -398,7 +435,7 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   if (nfine > 0) {
     vseg_prepare_rows(card, row_y, nfine, grad, norm, wave, lane);
     __syncthreads();
-    vseg_mlp_rows(w.bw, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
+    vseg_mlp_rows<VS_RES>(bwr, wf, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
     __syncthreads();
     vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
     __syncthreads();
@@ -487,9 +524,9 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
 
 }  // namespace
 
-void dmz_launch_vseg(hipStream_t s, const float *weights, const uint8_t *cards, size_t card_stride,
+void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag, const uint8_t *cards, size_t card_stride,
                      int n, int mode, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, cards, card_stride, n,
+  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, (const f32x4 *)wfrag, cards, card_stride, n,
                      mode, results);
 }
 
