@@ -520,6 +520,23 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
             bh[idx] = h;
             bl[idx] = bf16_rne(wv - bf16_to_float(h));
           }
+    // slash hidden layer: W1[n][k] / 255 (the 1/255 of the input scaling folded in, in double) as three bf16 parts
+    uint16_t *sb = (uint16_t *)(xw.data() + dmzx::SLASH_B3);
+    for (int ks = 0; ks < dmzx::SLASH_KSTEPS; ks++)
+      for (int nt = 0; nt < 5; nt++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 8; e++) {
+            const int k = 32 * ks + 8 * (lane >> 4) + e, nn = 16 * nt + (lane & 15);
+            const double wv = k < 176 ? (double)sw[nn * 176 + k] / 255.0 : 0.0;
+            const uint16_t p0 = bf16_rne((float)wv);
+            const double r1 = wv - (double)bf16_to_float(p0);
+            const uint16_t p1 = bf16_rne((float)r1);
+            const double r2 = r1 - (double)bf16_to_float(p1);
+            const uint16_t p2 = bf16_rne((float)r2);
+            const uint16_t parts[3] = {p0, p1, p2};
+            for (int part = 0; part < 3; part++)
+              sb[((((size_t)part * dmzx::SLASH_KSTEPS + ks) * 5 + nt) * 64 + lane) * 8 + e] = parts[part];
+          }
   }
   // cv::bilateralFilter(d = 3, sigmaColor = 0.95, sigmaSpace = 2/3) tables, expiry_categorize.cpp:52-57
   // (cvSmooth hands param3 to sigmaColor and param4 to sigmaSpace)

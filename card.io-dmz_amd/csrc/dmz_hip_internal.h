@@ -114,7 +114,11 @@ constexpr int FC1_T = CONV2_P + 1252 * 48;        // [120][176]
 constexpr int C2_KSTEPS = 44, C2_MAPS_PAD = 56;
 constexpr int CONV2_BH = FC1_T + 120 * 176;                  // C2_KSTEPS * 3 * 64 * 8 bf16 = 33,792 floats
 constexpr int CONV2_BL = CONV2_BH + C2_KSTEPS * 3 * 64 * 4;
-constexpr int TOTAL = CONV2_BL + C2_KSTEPS * 3 * 64 * 4;
+// slash MLP hidden layer for v_mfma_f32_16x16x32_bf16: W1 / 255 split into three bf16 parts (hi, mid, lo),
+// fragments [part 3][k-step 6][n-tile 5][lane 64][8 bf16]; K = 176 padded to 192
+constexpr int SLASH_KSTEPS = 6;
+constexpr int SLASH_B3 = CONV2_BL + C2_KSTEPS * 3 * 64 * 4;
+constexpr int TOTAL = SLASH_B3 + 3 * SLASH_KSTEPS * 5 * 64 * 4;
 }  // namespace dmzx
 // offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)
 namespace dmzw {

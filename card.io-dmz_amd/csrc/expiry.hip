@@ -271,6 +271,8 @@ __device__ __forceinline__ float row16_sum(float x) {  // total of a 16-lane DPP
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32: |error| ~ 2e-7 absolute
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -635,54 +637,64 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 
     // ---- slash search (643-674): character first+2 of every window of five, sixteen candidates
     // per pass.  applym_730c4cbd (176 -> 80 tanh -> 2 softmax): the hidden layer is a
-    // [16 x 176] x [176 x 80] product on v_mfma_f32_16x16x4_f32 -- A[m = lane & 15][k = lane >> 4]
-    // is candidate m's Scharr sample k (built from three inter bytes), B the input-major copy of
-    // the weights; D[row = candidate][col = hidden unit] comes back as 4 candidates x 5 tiles per
-    // lane.  The output layer is a DPP row reduction over the 16 lanes that share a candidate. ----
+    // [16 x 176] x [176 x 80] product.  On v_mfma_f32_16x16x32_bf16 with EXACT operand splits: a Scharr
+    // sample is an integer <= 4080 = 256 a + b, and 256 a and b are both bf16 numbers; the weights,
+    // pre-divided by 255 (the reference's x = s * (1/255) differs from that by one float rounding
+    // per input), are split into three bf16 parts (24 bits).  Six matrix instructions per (k-step of 32,
+    // tile) reproduce the fp32 product to ~2^-24 per term at 1/2.7 of the fp32 matrix-core time.
+    // A[m = lane & 15][k = 32 ks + 8 (lane >> 4) + e] is candidate m's sample k (three inter bytes);
+    // D[row = candidate][col = hidden unit] comes back as 4 candidates x 5 tiles per lane.  The output
+    // layer is a DPP row reduction over the 16 lanes that share a candidate.
+    // Each k-step: the 15 weight fragments are requested (L2), the A fragments are built meanwhile, all
+    // loads are waited for, and only then the 30 matrix instructions issue (see the conv2 loop below for
+    // why no load stays in flight across them).
     for (int p0 = 2; p0 + 2 < n2; p0 += 16) {
       const int nc = imin(16, n2 - 2 - p0);
       const int m = lane & 15, kk = lane >> 4;
       const bool live = m < nc;
       const int pl = live ? L.cLeft[p0 + m] : 0, pt = live ? L.cTop[p0 + m] - (base - 3) : 0;
-      const float *w1t = xw + dmzx::SLASH_W1T + kk * 80 + m;
+      const bf16x8 *wfrag = (const bf16x8 *)(xw + dmzx::SLASH_B3) + lane;
       f32x4 acc[5];
 #pragma unroll
       for (int t = 0; t < 5; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-      // software pipeline: the B operands of the next block of four k-steps (20 loads) are in
-      // flight while the current block multiplies -- the matrix comes from L2 on every pass
-      float bnx[4][5];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int t = 0; t < 5; t++) bnx[u][t] = w1t[4 * u * 80 + 16 * t];
-      // A operands (Scharr sample k = 4 ks + kk of candidate m) are built one block ahead as well
-      auto a_of = [&](int ks) {
-        const int k = 4 * ks + kk, r = (k * 373) >> 12, c = k - TW * r;  // k / 11, k % 11 for k < 176
-        return live ? (float)sob_at(L.inter, vmask, pt + r, pl + c) * (1.0f / 255.0f) : 0.0f;
-      };
-      float anx[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) anx[u] = a_of(u);
 #pragma unroll 1
-      for (int kb = 0; kb < (DMZ_XSEG_STOP == 8 ? 4 : 44); kb += 4) {
-        float bc[4][5], ac[4];
-        const float *wnext = w1t + (kb < 40 ? 4 * (kb + 4) * 80 : 0);
+      for (int ks = 0; ks < (DMZ_XSEG_STOP == 8 ? 1 : dmzx::SLASH_KSTEPS); ks++) {
+        bf16x8 wb[3][5];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int part = 0; part < 3; part++)
 #pragma unroll
-          for (int t = 0; t < 5; t++) {
-            bc[u][t] = bnx[u][t];
-            bnx[u][t] = wnext[4 * u * 80 + 16 * t];
+          for (int t = 0; t < 5; t++) wb[part][t] = wfrag[((part * dmzx::SLASH_KSTEPS + ks) * 5 + t) * 64];
+        // eight samples of this lane: k = 32 ks + 8 kk + e -> (row k / 11, column k % 11); k >= 176 is padding
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          float fh[2], fl[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int k = 32 * ks + 8 * kk + 2 * e2 + h, r = (k * 373) >> 12, c = k - TW * r;  // k / 11, k % 11 for k < 192
+            const int sv = (live && k < 176) ? sob_at(L.inter, vmask, pt + r, pl + c) : 0;
+            fh[h] = (float)(sv & ~255);                              // 256 a: a bf16 number
+            fl[h] = (float)(sv & 255);                               // b (v_cvt_f32_ubyte0)
           }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          ac[u] = anx[u];
-          anx[u] = a_of(imin(kb + 4 + u, 43));
+          // the upper halves of the two floats = their (exact) bf16 forms
+          hi[e2] = __builtin_amdgcn_perm(__float_as_uint(fh[1]), __float_as_uint(fh[0]), 0x07060302u);
+          lo[e2] = __builtin_amdgcn_perm(__float_as_uint(fl[1]), __float_as_uint(fl[0]), 0x07060302u);
         }
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){hi[0], hi[1], hi[2], hi[3]});
+        const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], lo[2], lo[3]});
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int t = 0; t < 5; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bc[u][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 5; t++) {  // small terms first
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wb[2][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[2][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wb[1][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[1][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wb[0][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[0][t], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       const float *sw = wts + dmzw::SLASH;
       float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
