@@ -482,17 +482,32 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     for (int j = 0; j < 32; j++)
       for (int i = 0; i < 320; i++)
         hidwt[(size_t)m * 320 * 32 + j * 320 + i] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
-  // vseg hidden layer in matrix-core fragment order [wave 4][k-block 13][lane 64][4]: lane (unit = 16 wave +
-  // (lane & 15), kk = lane >> 4) of block u holds W1[unit][16 u + 4 kk .. + 3] (zero beyond unit 49 / k 203)
+  // vseg hidden layer for v_mfma_f32_16x16x32_bf16 (vseg.hip): W1 / 255 in three bf16 parts, fragment order
+  // [wave 4][k-step 7][part 3][lane 64][8]: lane (unit = 16 wave + (lane & 15), run = lane >> 4) of k-step ks
+  // holds k = 32 ks + 8 run .. + 7 (zero beyond unit 49 / k 203); and the row sums of W1
   {
-    float *wf = hidwt.data() + dmzv::WFRAG;
+    uint16_t *wb = (uint16_t *)(hidwt.data() + dmzv::WFRAG + dmzv::WB3);
+    float *rowsum = hidwt.data() + dmzv::WFRAG + dmzv::ROWSUM;
     for (int wv = 0; wv < 4; wv++)
-      for (int u = 0; u < 13; u++)
+      for (int ks = 0; ks < 7; ks++)
         for (int lane = 0; lane < 64; lane++)
-          for (int e = 0; e < 4; e++) {
-            const int j = 16 * wv + (lane & 15), k = 16 * u + 4 * (lane >> 4) + e;
-            wf[((wv * 13 + u) * 64 + lane) * 4 + e] = (j < 50 && k < 204) ? w[dmzw::VSEG_W1 + j * 204 + k] : 0.0f;
+          for (int e = 0; e < 8; e++) {
+            const int j = 16 * wv + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+            const double wv255 = (j < 50 && k < 204) ? (double)w[dmzw::VSEG_W1 + j * 204 + k] / 255.0 : 0.0;
+            const uint16_t p0 = bf16_rne((float)wv255);
+            const double r1 = wv255 - (double)bf16_to_float(p0);
+            const uint16_t p1 = bf16_rne((float)r1);
+            const uint16_t p2 = bf16_rne((float)(r1 - (double)bf16_to_float(p1)));
+            const uint16_t parts[3] = {p0, p1, p2};
+            for (int part = 0; part < 3; part++)
+              wb[((((size_t)wv * 7 + ks) * 3 + part) * 64 + lane) * 8 + e] = parts[part];
           }
+    for (int j = 0; j < 64; j++) {
+      double sum = 0.0;
+      if (j < 50)
+        for (int k = 0; k < 204; k++) sum += (double)w[dmzw::VSEG_W1 + j * 204 + k];
+      rowsum[j] = (float)sum;
+    }
   }
   // expiry models: slash W1 input-major, conv2 tap-major, FC1 input-major (coalesced across lanes)
   std::vector<float> xw(dmzx::TOTAL);

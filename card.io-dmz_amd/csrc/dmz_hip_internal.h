@@ -147,8 +147,12 @@ void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, 
                      size_t card_stride);
 // vseg hidden-layer weights in fragment order, appended to the digit hidden-matrix buffer (float offsets)
 namespace dmzv {
-constexpr int WFRAG = 3 * 320 * 32;
-constexpr int WFRAG_FLOATS = 4 * 13 * 64 * 4;
+constexpr int WFRAG = 3 * 320 * 32;                 // offset of this block in the buffer
+// (offsets below are relative to WFRAG)
+constexpr int WB3 = 0;                              // W1 / 255 in three bf16 parts, fragments of v_mfma_f32_16x16x32_bf16:
+                                                    // [wave 4][k-step 7][part 3][lane 64][8 bf16]
+constexpr int ROWSUM = 4 * 7 * 3 * 64 * 4;          // sum_k W1[j][k], 64 floats (zero beyond unit 49)
+constexpr int WFRAG_FLOATS = ROWSUM + 64;
 }  // namespace dmzv
 void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag /* dmzv layout */, const uint8_t *cards, size_t card_stride,
                      int n, int mode /* DMZ_HIP_SCAN_* */, dmz_hip_frame_result *results);

@@ -13,14 +13,15 @@
 //     dwords (12 bytes) of the row and produces 4 of the 204 down-sampled gradient
 //     bytes in registers (v_max3/v_min3); a wave min/max reduction gives the row's
 //     normalisation (scale, shift).  LDS keeps the u8 gradients + (scale, shift) per
-//     row -- 1/4 of the float features -- and the float feature is rebuilt (same three
-//     IEEE operations as the reference) when it is fed to the matrix core.
-//   * hidden layer = the one real contraction of the stage, [rows x 204] x [204 x 50]:
-//     v_mfma_f32_16x16x4_f32 (exact f32, the vector rate without the VALU's operand
-//     traffic).  Wave w owns hidden units 16w..16w+15: its B operands (13 float4 per
-//     lane, straight from the row-major weight matrix) stay in registers for the whole
-//     card; A operands are one ds_read_b32 (4 k-values) per four MFMAs; two row tiles
-//     are accumulated at a time so the 40-cycle dependent latency is covered.
+//     row -- 1/4 of the float features.
+//   * hidden layer = the one real contraction of the stage, [rows x 204] x [204 x 50], on
+//     v_mfma_f32_16x16x32_bf16 with exact operand splits (gradient bytes are bf16 numbers,
+//     the weights / 255 go in three bf16 parts, the row's scale and shift enter once per
+//     output: see vseg_mlp_rows_bf16).  Wave w owns hidden units 16w..16w+15 and streams
+//     its 21 weight fragments once per pass; all row tiles of a pass go through one sweep
+//     over k.  (The fp32 matrix core with register-resident weights, v_mfma_f32_16x16x4_f32,
+//     needed 16 times the matrix-pipe time per k and four VALU instructions per feature:
+//     0.47 instead of 0.33 ms per 8192 cards; the model entry point below still uses it.)
 //   * tanh, the 50->3 logistic layer (wave-local 16-lane reductions + a 4-wave LDS
 //     sum), softmax, and the literal running box sum on one lane (its LDS reads are
 //     independent of the float chain and are issued nine steps ahead).
@@ -75,8 +76,9 @@ constexpr int VS_THREADS = 256;
 constexpr int VS_WAVES = 4;
 constexpr int VS_MAXROWS = 68;   // coarse pass rows; the fine pass needs <= 43
 constexpr int VS_PROWS = 68;     // rows of the per-wave partial-sum table
-constexpr int VS_GSTRIDE = 208;  // gradient row stride in bytes (13 x 16 k-values, zero tail)
-constexpr int VS_KSTEPS = 13;    // 13 x 16 = 208 >= 204
+constexpr int VS_GSTRIDE = 224;  // gradient row stride in bytes (7 x 32 k-values, zero tail)
+constexpr int VS_KSTEPS = 13;    // fp32 matrix core (model entry point): 13 x 16 = 208 >= 204
+constexpr int VS_KS32 = 7;       // bf16 matrix core: 7 x 32 = 224 >= 204
 constexpr int VS_RIF = 6;        // rows in flight per wave while loading
 
 struct RowRaw {
@@ -124,7 +126,7 @@ __device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned cha
     vmin = imin(vmin, __shfl_xor(vmin, o, 64));
     vmax = imax(vmax, __shfl_xor(vmax, o, 64));
   }
-  if (lane < 52)  // lane 51 writes the zero k-tail 204..207
+  if (lane < 56)  // lanes 51..55 write the zero k-tail 204..223
     *(uint32_t *)(grow + 4 * lane) =
         lane < 51 ? (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24) : 0u;
   if (lane == 0) {
@@ -158,97 +160,79 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
   }
 }
 
-// the float feature of gradient byte `d`: (d * (1/255)) * scale + shift, three IEEE ops
-__device__ __forceinline__ float feat_of(uint32_t word, int byte, float fs, float fb) {
-  const float f = (float)((word >> (8 * byte)) & 255u) * (1.0f / 255.0f);
-  return f * fs + fb;
-}
-
-// Hidden + logistic layers for `nrows` rows.  Wave `wave` owns hidden units
-// 16*wave .. 16*wave+15; bw[u] holds W1[j][16u + 4kk .. +3] for this lane's (kk, j).
-// VS_RES of the 13 k-blocks of this wave's weights stay in registers (bw), the others are streamed per tile
-// pair from the fragment-ordered copy (wf: this wave's 13 x 64 float4, one coalesced 1-KB load per block):
-// all 52 registers of weights do not fit beside the seven-workgroups-per-CU register budget, and what the
-// allocator spilled went to scratch -- 39 KB of HBM writes per card -- and came back from there per tile pair.
-template <int RES>
-__device__ __forceinline__ void vseg_mlp_rows(const f32x4 (&bw)[RES], const f32x4 *__restrict__ wf, float b1, float w20,
-                                              float w21, float w22,
-                                              const unsigned char *__restrict__ grad,
-                                              const float *__restrict__ norm, int nrows,
-                                              float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
-                                              int lane) {
+// Hidden + logistic layers for up to 16 NT rows on v_mfma_f32_16x16x32_bf16 with EXACT operand splits.
+// The feature of gradient byte d in a row with normalisation (s, t) is ((d / 255) s + t) (three float
+// operations in the reference), so  sum_k W[j][k] f_k = s sum_k (W[j][k] / 255) d_k + t sum_k W[j][k]:
+// d is an integer <= 255 -- a bf16 number as it is -- and W / 255 is split into three bf16 parts (24
+// bits), so three matrix instructions per 32 k reproduce the fp32 product of the integer sums to ~2^-24
+// per term; the two row constants enter once per output.  (Against the reference this regroups three
+// float roundings per feature: differences of the order of the 1e-6 that any reordering of the 204-term
+// sums makes; the 1e-4 contract on the scores and the proven-near-tie rule for y_offset are unchanged.)
+// One sixteenth of the fp32 matrix-core time per k, and 1.5 VALU instructions per feature instead of 4.
+// All NT row tiles go through one sweep over k, so a wave streams its 21 weight fragments (fragment order,
+// 1-KB coalesced loads, prefetched one k-step ahead) once per pass.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb /* this wave + lane: [ks 7][part 3] x 64 */,
+                                                   float rowsum, float b1, float w20, float w21, float w22,
+                                                   const unsigned char *__restrict__ grad,
+                                                   const float *__restrict__ norm, int nrows,
+                                                   float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
+                                                   int lane) {
   const int ii = lane & 15, kk = lane >> 4;
-  const int ntiles = (nrows + 15) >> 4;
+  const unsigned char *ap[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) ap[t] = grad + imin(t * 16 + ii, nrows - 1) * VS_GSTRIDE + 8 * kk;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 wn[3];
+#pragma unroll
+  for (int p = 0; p < 3; p++) wn[p] = wb[p * 64];
+#pragma unroll 1
+  for (int ks = 0; ks < VS_KS32; ks++) {
+    bf16x8 w[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      w[p] = wn[p];
+      wn[p] = wb[(imin(ks + 1, VS_KS32 - 1) * 3 + p) * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const uint2 by = *(const uint2 *)(ap[t] + 32 * ks);  // eight gradient bytes k = 32 ks + 8 kk ..
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        f[e] = (float)((by.x >> (8 * e)) & 255u);
+        f[4 + e] = (float)((by.y >> (8 * e)) & 255u);
+      }
+      u32x4 a;  // the upper halves of the floats are their exact bf16 forms
+      a.x = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+      a.y = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
+      a.z = __builtin_amdgcn_perm(__float_as_uint(f[5]), __float_as_uint(f[4]), 0x07060302u);
+      a.w = __builtin_amdgcn_perm(__float_as_uint(f[7]), __float_as_uint(f[6]), 0x07060302u);
+      const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[2], acc[t], 0, 0, 0);  // small terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[0], acc[t], 0, 0, 0);
+    }
+  }
   // D layout: column (hidden unit) = lane & 15, row = 4 * (lane >> 4) + v
-  auto finish_tile = [&](const f32x4 &acc, int tile) {
+#pragma unroll
+  for (int t = 0; t < NT; t++)
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-      const float hv = fast_tanh(acc[v] + b1);  // units >= 50 have zero logistic weights
+      const int row = t * 16 + 4 * kk + v, rc = imin(row, nrows - 1);
+      const float pre = fmaf(norm[2 * rc], acc[t][v], fmaf(norm[2 * rc + 1], rowsum, b1));
+      const float hv = fast_tanh(pre);  // units >= 50 have zero logistic weights
       // sum over the 16 hidden units of this wave (one DPP row)
       const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
-      const int row = tile * 16 + 4 * kk + v;
       if (ii == 15 && row < nrows) {
         float *p = part + (wave * VS_PROWS + row) * 3;
         p[0] = o0; p[1] = o1; p[2] = o2;
       }
     }
-  };
-  int mt = 0;
-  // tiles two at a time (two independent accumulator chains) ...
-  for (; mt + 1 < ntiles; mt += 2) {
-    const int r0 = imin(mt * 16 + ii, nrows - 1), r1 = imin(mt * 16 + 16 + ii, nrows - 1);
-    const uint32_t *a0p = (const uint32_t *)(grad + r0 * VS_GSTRIDE + 4 * kk);
-    const uint32_t *a1p = (const uint32_t *)(grad + r1 * VS_GSTRIDE + 4 * kk);
-    const float fs0 = norm[2 * r0], fb0 = norm[2 * r0 + 1];
-    const float fs1 = norm[2 * r1], fb1 = norm[2 * r1 + 1];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto step2 = [&](int u, const f32x4 &b) {
-      const uint32_t g0 = a0p[4 * u], g1 = a1p[4 * u];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), b.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 0, fs1, fb1), b.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), b.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 1, fs1, fb1), b.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), b.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 2, fs1, fb1), b.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), b.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g1, 3, fs1, fb1), b.w, acc1, 0, 0, 0);
-    };
-    f32x4 ws = RES < VS_KSTEPS ? wf[RES * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};  // first streamed block: in flight
-#pragma unroll
-    for (int u = 0; u < RES; u++) step2(u, bw[u]);
-#pragma unroll 1
-    for (int u = RES; u < VS_KSTEPS; u++) {  // rolled: unrolled, all the loads are hoisted and spill again
-      const f32x4 b = ws;
-      ws = wf[imin(u + 1, VS_KSTEPS - 1) * 64];
-      step2(u, b);
-    }
-    finish_tile(acc0, mt);
-    finish_tile(acc1, mt + 1);
-  }
-  // ... and an odd last tile on its own instead of paired with a copy of itself
-  if (mt < ntiles) {
-    const int r0 = imin(mt * 16 + ii, nrows - 1);
-    const uint32_t *a0p = (const uint32_t *)(grad + r0 * VS_GSTRIDE + 4 * kk);
-    const float fs0 = norm[2 * r0], fb0 = norm[2 * r0 + 1];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-    auto step1 = [&](int u, const f32x4 &b) {
-      const uint32_t g0 = a0p[4 * u];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 0, fs0, fb0), b.x, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 1, fs0, fb0), b.y, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 2, fs0, fb0), b.z, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(feat_of(g0, 3, fs0, fb0), b.w, acc0, 0, 0, 0);
-    };
-    f32x4 ws = RES < VS_KSTEPS ? wf[RES * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < RES; u++) step1(u, bw[u]);
-#pragma unroll 1
-    for (int u = RES; u < VS_KSTEPS; u++) {
-      const f32x4 b = ws;
-      ws = wf[imin(u + 1, VS_KSTEPS - 1) * 64];
-      step1(u, b);
-    }
-    finish_tile(acc0, mt);
-  }
 }
 
 // n_vseg.cpp:49-92, called by one wave.  The reference's ring buffer entry read at step y is the
@@ -350,11 +334,8 @@ __device__ __forceinline__ void vseg_load_weights(const float *__restrict__ wts,
   w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
 }
 
-#ifndef VS_RES  /* k-blocks of the hidden weights a wave keeps in registers (of 13) */
-#define VS_RES 3
-#endif
 __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const float *__restrict__ wts,
-                                                      const f32x4 *__restrict__ wfrag,
+                                                      const float *__restrict__ wfrag /* dmzv layout */,
                                                       const uint8_t *__restrict__ cards,
                                                       size_t card_stride, int n, int mode,
                                                       dmz_hip_frame_result *__restrict__ results) {
@@ -394,15 +375,13 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   for (int i = tid; i < VS_MAXROWS; i += VS_THREADS) row_y[i] = (unsigned short)(4 * i);
   __syncthreads();
   vseg_prepare_rows(card, row_y, VS_MAXROWS, grad, norm, wave, lane);
-  // this wave's hidden units 16 wave .. + 15: resident weight blocks, bias and the logistic weights
-  const f32x4 *wf = wfrag + wave * VS_KSTEPS * 64 + lane;
-  f32x4 bwr[VS_RES];
-#pragma unroll
-  for (int u = 0; u < VS_RES; u++) bwr[u] = wf[u * 64];
-  struct { float b1, w20, w21, w22; } w;
+  // this wave's hidden units 16 wave .. + 15: weight fragments, row sum, bias and the logistic weights
+  const bf16x8 *wb = (const bf16x8 *)(wfrag + dmzv::WB3) + wave * VS_KS32 * 3 * 64 + lane;
+  struct { float b1, w20, w21, w22, rowsum; } w;
   {
     const int j = 16 * wave + (lane & 15);
     const bool unit = j < 50;
+    w.rowsum = wfrag[dmzv::ROWSUM + j];
     w.b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
     w.w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
     w.w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
@@ -410,7 +389,7 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   }
   __syncthreads();
   VS_STOP(1, grad[0] + norm[5])
-  vseg_mlp_rows<VS_RES>(bwr, wf, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
+  vseg_mlp_rows_bf16<5>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
   __syncthreads();
   VS_STOP(2, part[0] + part[100])
   vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
@@ -435,7 +414,7 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   if (nfine > 0) {
     vseg_prepare_rows(card, row_y, nfine, grad, norm, wave, lane);
     __syncthreads();
-    vseg_mlp_rows<VS_RES>(bwr, wf, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
+    vseg_mlp_rows_bf16<3>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
     __syncthreads();
     vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
     __syncthreads();
@@ -526,7 +505,7 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
 
 void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag, const uint8_t *cards, size_t card_stride,
                      int n, int mode, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, (const f32x4 *)wfrag, cards, card_stride, n,
+  hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, wfrag, cards, card_stride, n,
                      mode, results);
 }
 
