@@ -97,7 +97,8 @@ __device__ __forceinline__ void window_init(const WalkCtx &c, Window &wn) {
 }
 
 // step s = s0 + K (s0 a multiple of 7): push position s+3, return the saturated (dx, dy)
-template <bool VERT, int K>
+// SAT = false leaves the saturation to the caller (pack_gradient does it while packing)
+template <bool VERT, int K, bool SAT = true>
 __device__ __forceinline__ void window_step(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
   across_taps(c, clampi(s + 3, 0, c.S - 1), wn.d[(K + 6) % 7], wn.s[(K + 6) % 7]);
   // along axis: smooth the derivative, differentiate the smooth
@@ -106,12 +107,28 @@ __device__ __forceinline__ void window_step(const WalkCtx &c, Window &wn, int s,
   const int g_sd = (wn.s[(K + 6) % 7] - wn.s[K % 7]) + 4 * (wn.s[(K + 5) % 7] - wn.s[(K + 1) % 7]) +
                    5 * (wn.s[(K + 4) % 7] - wn.s[(K + 2) % 7]);
   // top/bottom boxes: across = x  => dx = g_ds, dy = g_sd ; left/right boxes: across = y
-  dx = clampi(VERT ? g_sd : g_ds, -32768, 32767);
-  dy = clampi(VERT ? g_ds : g_sd, -32768, 32767);
+  dx = SAT ? clampi(VERT ? g_sd : g_ds, -32768, 32767) : (VERT ? g_sd : g_ds);
+  dy = SAT ? clampi(VERT ? g_ds : g_sd, -32768, 32767) : (VERT ? g_ds : g_sd);
+}
+
+// (dx, dy) of a step, saturated to 16 bits and packed with the sign bits flipped in ONE v_cvt_pk_i16_i32 + xor:
+// each half is the gradient plus 32768 as an unsigned 16-bit number
+__device__ __forceinline__ uint32_t pack_gradient(int gx, int gy) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 p = __builtin_amdgcn_cvt_pk_i16(gx, gy);  // {sat16(gx), sat16(gy)}
+  return __builtin_bit_cast(uint32_t, p) ^ 0x80008000u;
+}
+// sum of the saturated |dx| + |dy| (cvAbs: |-32768| -> 32767) of a packed gradient, added to acc: the half
+// 0x0000 (= -32768) is lifted to 0x0001 (= -32767), then one v_sad_u16 against the bias
+__device__ __forceinline__ int add_abs_sat(uint32_t g, int acc) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 one = {1, 1};
+  const u16x2 lifted = __builtin_elementwise_max(__builtin_bit_cast(u16x2, g), one);
+  return (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, lifted), 0x80008000u, (uint32_t)acc);
 }
 
 // the same step with the slot arithmetic left to constant folding: for fully unrolled walks
-template <bool VERT>
+template <bool VERT, bool SAT = true>
 __device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
   const int k = s % 7;
   across_taps(c, clampi(s + 3, 0, c.S - 1), wn.d[(k + 6) % 7], wn.s[(k + 6) % 7]);
@@ -119,8 +136,8 @@ __device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int 
                    15 * (wn.d[(k + 2) % 7] + wn.d[(k + 4) % 7]) + 20 * wn.d[(k + 3) % 7];
   const int g_sd = (wn.s[(k + 6) % 7] - wn.s[k % 7]) + 4 * (wn.s[(k + 5) % 7] - wn.s[(k + 1) % 7]) +
                    5 * (wn.s[(k + 4) % 7] - wn.s[(k + 2) % 7]);
-  dx = clampi(VERT ? g_sd : g_ds, -32768, 32767);
-  dy = clampi(VERT ? g_ds : g_sd, -32768, 32767);
+  dx = SAT ? clampi(VERT ? g_sd : g_ds, -32768, 32767) : (VERT ? g_sd : g_ds);
+  dy = SAT ? clampi(VERT ? g_ds : g_sd, -32768, 32767) : (VERT ? g_ds : g_sd);
 }
 
 // lane - 1 / lane + 1 of the wave by DPP (wave_shr:1 / wave_shl:1; the end lanes keep their own value, like
@@ -340,14 +357,14 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       window_init(c, wn);
       int acc = 0;
       auto pack = [&](int dx, int dy) {
-        const int ax = iabs(dx), ay = iabs(dy);
-        acc += (ax > 32767 ? 32767 : ax) + (ay > 32767 ? 32767 : ay);  // cvAbs: 32768 -> 32767
-        return __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u) ^ 0x80008000u;
+        const uint32_t packed = pack_gradient(dx, dy);
+        acc = add_abs_sat(packed, acc);
+        return packed;
       };
 #pragma unroll
       for (int s0 = 0; s0 < RG; s0++) {
         int dx, dy;
-        window_step_s<VERT>(c, wn, s0, dx, dy);
+        window_step_s<VERT, false>(c, wn, s0, dx, dy);
         g[s0] = pack(dx, dy);
       }
       if constexpr (RG < SC) {
@@ -355,7 +372,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 #define DMZ_PARK_STEP(K)                                                                       \
   {                                                                                             \
     int dx, dy;                                                                                 \
-    window_step<VERT, K>(c, wn, sb + K, dx, dy);                                                \
+    window_step<VERT, K, false>(c, wn, sb + K, dx, dy);                                         \
     const uint32_t packed = pack(dx, dy);                                                       \
     if (owner) gpark[(sb + K - RG) * L + c.l] = packed; /* one writer per column */             \
   }
