@@ -3,7 +3,7 @@
 #   1. bench.py lines: config 4 (default command), config 2, config 3
 #   2. rocprofv3 --kernel-trace --stats of the default bench.py command (minus the CPU baseline leg)
 #   3. PMC passes (separate runs, kernel-trace only): FETCH_SIZE, WRITE_SIZE per kernel (batch 4096)
-#   4. SQ counter passes (batch 2048): VALU / MFMA / LDS / wait counters per kernel
+#   4. SQ counter passes (batch 8192): VALU / MFMA / LDS / wait counters per kernel
 # Copy what should be judged into profiles/ and name the tag in profiles/CURRENT.
 TAG=${1:-r2}
 B=${BATCH:-65536}
@@ -48,9 +48,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 SQ1="SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES"
 SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS"
-rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/pmc_sq1 -o pmc -- python3 $ROOT/tools/stage_times.py 2048 1 > /dev/null 2>&1
-summarise $OUT/pmc_sq1 $OUT/${TAG}_pmc_SQ_issue_batch2048.txt 2048 $SQ1
-rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OUT/pmc_sq2 -o pmc -- python3 $ROOT/tools/stage_times.py 2048 1 > /dev/null 2>&1
-summarise $OUT/pmc_sq2 $OUT/${TAG}_pmc_SQ_insts_batch2048.txt 2048 $SQ2
+rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/pmc_sq1 -o pmc -- python3 $ROOT/tools/stage_times.py 8192 1 > /dev/null 2>&1
+summarise $OUT/pmc_sq1 $OUT/${TAG}_pmc_SQ_issue_batch8192.txt 8192 $SQ1
+rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OUT/pmc_sq2 -o pmc -- python3 $ROOT/tools/stage_times.py 8192 1 > /dev/null 2>&1
+summarise $OUT/pmc_sq2 $OUT/${TAG}_pmc_SQ_insts_batch8192.txt 8192 $SQ2
 rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2
 ls -la $OUT
