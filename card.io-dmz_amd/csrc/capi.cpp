@@ -541,8 +541,10 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
       for (int nt = 0; nt < 5; nt++)
         for (int lane = 0; lane < 64; lane++)
           for (int e = 0; e < 8; e++) {
-            const int k = 32 * ks + 8 * (lane >> 4) + e, nn = 16 * nt + (lane & 15);
-            const double wv = k < 176 ? (double)sw[nn * 176 + k] / 255.0 : 0.0;
+            // K order of k_expiry_seg: fragment element (ks, kk = lane >> 4, e) is the sample in window row
+            // 8 (kk & 1) + e, column 2 ks + (kk >> 1) of the 16 x 11 input (input index row * 11 + column)
+            const int kk = lane >> 4, wr = 8 * (kk & 1) + e, wc = 2 * ks + (kk >> 1), nn = 16 * nt + (lane & 15);
+            const double wv = wc < 11 ? (double)sw[nn * 176 + wr * 11 + wc] / 255.0 : 0.0;
             const uint16_t p0 = bf16_rne((float)wv);
             const double r1 = wv - (double)bf16_to_float(p0);
             const uint16_t p1 = bf16_rne((float)r1);

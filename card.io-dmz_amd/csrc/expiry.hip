@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include "dmz_hip_internal.h"
+#include "dmz_wave.h"
 
 // developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
 #ifndef DMZ_LDS_PAD
@@ -43,38 +44,12 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
 
-// Wave-wide reductions: four DPP row_shr steps leave each 16-lane row's result in its lane 15
-// (out-of-row sources read as 0: the identity of + and of unsigned max), the four row results
-// are combined on the scalar unit.  ~8 instructions instead of six ds_bpermute round trips.
-#define DMZ_DPP_SHR(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x110 + (n), 0xf, 0xf, true)
-__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
-  int v = (int)x;
-  unsigned o;
-  o = (unsigned)DMZ_DPP_SHR(v, 1), v = (int)((unsigned)v > o ? (unsigned)v : o);
-  o = (unsigned)DMZ_DPP_SHR(v, 2), v = (int)((unsigned)v > o ? (unsigned)v : o);
-  o = (unsigned)DMZ_DPP_SHR(v, 4), v = (int)((unsigned)v > o ? (unsigned)v : o);
-  o = (unsigned)DMZ_DPP_SHR(v, 8), v = (int)((unsigned)v > o ? (unsigned)v : o);
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane(v, 15), b = (unsigned)__builtin_amdgcn_readlane(v, 31);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane(v, 47), d = (unsigned)__builtin_amdgcn_readlane(v, 63);
-  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-  v += DMZ_DPP_SHR(v, 1);
-  v += DMZ_DPP_SHR(v, 2);
-  v += DMZ_DPP_SHR(v, 4);
-  v += DMZ_DPP_SHR(v, 8);
-  return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) +
-         __builtin_amdgcn_readlane(v, 63);
-}
+// Wave-wide reductions on DPP (dmz_wave.h)
+#define DMZ_DPP_SHR(v, n) DMZ_DPP_SHR0(v, n)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) { return dmzwave::max_u32(x); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return dmzwave::sum_i32(v); }
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
-    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
-    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-    v = w < v ? w : v;
-  }
-  return v;
+  return dmzwave::min_u64((unsigned)(v >> 32), (unsigned)v);
 }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
@@ -231,11 +206,14 @@ struct SegLds {
 __device__ __forceinline__ uint32_t scharr_inter4(uint32_t prev, uint32_t cur, uint32_t next, int d) {
   const uint32_t left = d > 0 ? __builtin_amdgcn_alignbyte(cur, prev, 3) : ((cur << 8) | (cur & 0xFFu));
   const uint32_t right = d < 106 ? __builtin_amdgcn_alignbyte(next, cur, 1) : ((cur >> 8) | (cur & 0xFF000000u));
-  uint32_t out = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    out |= (uint32_t)iabs((int)((right >> (8 * k)) & 255u) - (int)((left >> (8 * k)) & 255u)) << (8 * k);
-  return out;
+  // |right - left| per byte on packed 16-bit halves: even bytes and odd bytes separately (v_pk_sub_i16,
+  // v_pk_max_i16 of the difference and its negation), then re-interleaved
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 re = __builtin_bit_cast(s16x2, right & 0x00FF00FFu), le = __builtin_bit_cast(s16x2, left & 0x00FF00FFu);
+  const s16x2 ro = __builtin_bit_cast(s16x2, (right >> 8) & 0x00FF00FFu), lo = __builtin_bit_cast(s16x2, (left >> 8) & 0x00FF00FFu);
+  const s16x2 de = re - le, dod = ro - lo;
+  const s16x2 ae = __builtin_elementwise_max(de, -de), ao = __builtin_elementwise_max(dod, -dod);
+  return __builtin_bit_cast(uint32_t, ae) | (__builtin_bit_cast(uint32_t, ao) << 8);
 }
 
 // |Scharr dx| at window row k (image row base-3+k, k = 0..20) and column c; vmask = rows inside the ROI
@@ -642,7 +620,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     // pre-divided by 255 (the reference's x = s * (1/255) differs from that by one float rounding
     // per input), are split into three bf16 parts (24 bits).  Six matrix instructions per (k-step of 32,
     // tile) reproduce the fp32 product to ~2^-24 per term at 1/2.7 of the fp32 matrix-core time.
-    // A[m = lane & 15][k = 32 ks + 8 (lane >> 4) + e] is candidate m's sample k (three inter bytes);
+    // A[m = lane & 15][k' = 32 ks + 8 (lane >> 4) + e] is candidate m's sample (row 8 (kk & 1) + e, column 2 ks + (kk >> 1));
     // D[row = candidate][col = hidden unit] comes back as 4 candidates x 5 tiles per lane.  The output
     // layer is a DPP row reduction over the 16 lanes that share a candidate.
     // Each k-step: the 15 weight fragments are requested (L2), the A fragments are built meanwhile, all
@@ -653,7 +631,14 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       const int m = lane & 15, kk = lane >> 4;
       const bool live = m < nc;
       const int pl = live ? L.cLeft[p0 + m] : 0, pt = live ? L.cTop[p0 + m] - (base - 3) : 0;
-      const bf16x8 *wfrag = (const bf16x8 *)(xw + dmzx::SLASH_B3) + lane;
+      // (buffer loads: descriptor + 32-bit lane offset + scalar fragment offset, no 64-bit address arithmetic)
+      const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(xw + dmzx::SLASH_B3), 0, 3 * dmzx::SLASH_KSTEPS * 5 * 64 * 16, 0x00020000);
+      const int r0 = pt + 8 * (kk & 1);  // first window row of this lane's samples (r0 + 9 <= 22)
+      const unsigned char *ip = L.inter + r0 * ISTRIDE + pl + (kk >> 1);
+      int rowmask[8];                    // all-ones where the sample's row lies inside the ROI (and the lane is live)
+#pragma unroll
+      for (int e = 0; e < 8; e++) rowmask[e] = live ? __builtin_amdgcn_sbfe((int)vmask, r0 + e, 1) : 0;
       f32x4 acc[5];
 #pragma unroll
       for (int t = 0; t < 5; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -663,16 +648,23 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 #pragma unroll
         for (int part = 0; part < 3; part++)
 #pragma unroll
-          for (int t = 0; t < 5; t++) wb[part][t] = wfrag[((part * dmzx::SLASH_KSTEPS + ks) * 5 + t) * 64];
-        // eight samples of this lane: k = 32 ks + 8 kk + e -> (row k / 11, column k % 11); k >= 176 is padding
+          for (int t = 0; t < 5; t++) wb[part][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, lane * 16, ((part * dmzx::SLASH_KSTEPS + ks) * 5 + t) * 1024, 0));
+        // eight samples of this lane: k' = 32 ks + 8 kk + e <-> window column 2 ks + (kk >> 1), rows 8 (kk & 1) + e
+        // (the K order is ours to choose -- capi.cpp lays the weights out to match): eight vertically adjacent
+        // samples share ten bytes of one `inter` column.  Column 11 (ks = 5, kk >= 2) meets zero weights.
+        int iv[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) iv[i] = ip[i * ISTRIDE];
+        ip += 2;
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) {
           float fh[2], fl[2];
 #pragma unroll
           for (int h = 0; h < 2; h++) {
-            const int k = 32 * ks + 8 * kk + 2 * e2 + h, r = (k * 373) >> 12, c = k - TW * r;  // k / 11, k % 11 for k < 192
-            const int sv = (live && k < 176) ? sob_at(L.inter, vmask, pt + r, pl + c) : 0;
+            const int e = 2 * e2 + h;
+            const int sv = (3 * (iv[e] + iv[e + 2]) + 10 * iv[e + 1]) & rowmask[e];
             fh[h] = (float)(sv & ~255);                              // 256 a: a bf16 number
             fl[h] = (float)(sv & 255);                               // b (v_cvt_f32_ubyte0)
           }

@@ -22,6 +22,7 @@
 #include <float.h>
 
 #include "dmz_hip_internal.h"
+#include "dmz_wave.h"
 
 namespace {
 
@@ -47,10 +48,7 @@ __device__ __forceinline__ unsigned pattern_mask(int pt) {
    : (j) == 12 ? 0.48471646f : (j) == 13 ? 0.46457738f : (j) == 14 ? 0.42799847f : (j) == 15 ? 0.38851183f \
    : (j) == 16 ? 0.33966308f : (j) == 17 ? 0.28802608f : 0.25377602f)
 
-__device__ __forceinline__ int wave_max(int v) {
-  for (int o = 32; o > 0; o >>= 1) v = imax(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ __forceinline__ int wave_max(int v) { return (int)dmzwave::max_u32((unsigned)v); }  // v >= 0
 
 // the pattern-offset range and count of one width iteration (n_hseg.cpp:46-53)
 __device__ __forceinline__ int offsets_for_width(int plen, float width, int omin, int omax, int ostep) {
@@ -148,18 +146,15 @@ __device__ void hseg_pass(const float *__restrict__ g, int pt, float wmin, float
     }
     const float score = hseg_score(g, pt, my_w, my_off, has);
     // wave arg-min; ties -> earliest candidate (strict < in iteration order)
-    unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned int)my;
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long other = __shfl_xor(key, o, 64);
-      key = other < key ? other : key;
-    }
+    // (scores are non-negative floats: their bit patterns order like the values)
+    const unsigned long long key = dmzwave::min_u64(__float_as_uint(score), (unsigned int)my);
     const float smin = __uint_as_float((unsigned int)(key >> 32));
     const int winner = (int)(key & 0xffffffffu);
     if (smin < best.score) {
       const int wl = winner - base;  // lane that holds the winner
       best.score = smin;
-      best.width = __shfl(my_w, wl, 64);
-      best.offset = __shfl(my_off, wl, 64);
+      best.width = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), wl));
+      best.offset = __builtin_amdgcn_readlane(my_off, wl);
     }
   }
 }
@@ -206,10 +201,8 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
     lmin = imin(lmin, imin(imin(sum0, sum1), imin(sum2, sum3)));
     lmax = imax(lmax, imax(imax(sum0, sum1), imax(sum2, sum3)));
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    lmin = imin(lmin, __shfl_xor(lmin, o, 64));
-    lmax = imax(lmax, __shfl_xor(lmax, o, 64));
-  }
+  lmin = (int)dmzwave::min_u32((unsigned)lmin);  // column sums are >= 0; idle lanes hold 2^30 / -1 -> 0
+  lmax = (int)dmzwave::max_u32((unsigned)imax(lmax, 0));
   __syncthreads();
   {
     // cvNormalize(0,1,MINMAX) on the float sums

@@ -30,6 +30,7 @@
 #include <float.h>
 
 #include "dmz_hip_internal.h"
+#include "dmz_wave.h"
 
 // developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
 #ifndef DMZ_LDS_PAD
@@ -122,21 +123,32 @@ __device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned cha
       vmax = imax(vmax, d[m]);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    vmin = imin(vmin, __shfl_xor(vmin, o, 64));
-    vmax = imax(vmax, __shfl_xor(vmax, o, 64));
-  }
+  // (lanes >= 51 hold the identities 255 / 0)
+  vmin = 255 - (int)dmzwave::max_u32((unsigned)(255 - vmin));
+  vmax = (int)dmzwave::max_u32((unsigned)vmax);
   if (lane < 56)  // lanes 51..55 write the zero k-tail 204..223
     *(uint32_t *)(grow + 4 * lane) =
         lane < 51 ? (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24) : 0u;
+  // the row's (min, max) parked as two integers; vseg_row_norms turns them into (scale, shift) for many rows
+  // at once (the fp64 division costs ~30 issue slots whether one lane or 64 need it)
   if (lane == 0) {
-    // cvConvertScale(1/255) then cvNormalize(0,1,MINMAX): SURVEY A7/A8
+    norm[0] = __int_as_float(vmin);
+    norm[1] = __int_as_float(vmax);
+  }
+}
+
+// cvConvertScale(1/255) then cvNormalize(0,1,MINMAX) for the rows wave, wave + 4, ... this wave
+// has just prepared: one lane per row
+__device__ __forceinline__ void vseg_row_norms(float *__restrict__ norm, int nrows, int wave, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int i = wave + VS_WAVES * lane; i < nrows; i += VS_WAVES * 64) {
+    const int vmin = __float_as_int(norm[2 * i]), vmax = __float_as_int(norm[2 * i + 1]);
     const float s255 = 1.0f / 255.0f;
     const double smin = (double)((float)vmin * s255), smax = (double)((float)vmax * s255);
     const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.;
     const double shift = 0.0 - smin * scale;
-    norm[0] = (float)scale;
-    norm[1] = (float)shift;
+    norm[2 * i] = (float)scale;
+    norm[2 * i + 1] = (float)shift;
   }
 }
 
@@ -158,6 +170,7 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
       if (i < nrows) vseg_row_features(raw[k], grad + i * VS_GSTRIDE, norm + 2 * i, lane);
     }
   }
+  vseg_row_norms(norm, nrows, wave, lane);
 }
 
 // Hidden + logistic layers for up to 16 NT rows on v_mfma_f32_16x16x32_bf16 with EXACT operand splits.
