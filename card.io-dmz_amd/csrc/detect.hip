@@ -351,7 +351,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     // Parked gradients: step k >= RG of column l at gpark[(k - RG) * L + l].
     uint32_t g[RG];
     uint32_t *gpark = (uint32_t *)(lds + bp.lds_map);
-    static_assert(RG == SC || (RG % 7 == 0 && (SC - RG) % 7 == 0), "the parked part walks in groups of seven");
+    static_assert(RG == SC || RG % 7 == 0, "the parked part walks in groups of seven (a partial last group is guarded)");
     {
       Window wn;
       window_init(c, wn);
@@ -370,7 +370,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       if constexpr (RG < SC) {
         // the parked steps: a rolled loop over groups of seven (window slots stay compile-time constants)
 #define DMZ_PARK_STEP(K)                                                                       \
-  {                                                                                             \
+  if ((SC - RG) % 7 == 0 || sb + K < SC) {                                                      \
     int dx, dy;                                                                                 \
     window_step<VERT, K, false>(c, wn, sb + K, dx, dy);                                         \
     const uint32_t packed = pack(dx, dy);                                                       \
@@ -621,11 +621,14 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 #ifndef DMZ_DETECT_SINGLE_V
 #define DMZ_DETECT_SINGLE_V 1
 #endif
+#ifndef DMZ_DETECT_REGS_V  /* left/right boxes: packed gradients kept in registers */
+#define DMZ_DETECT_REGS_V 28
+#endif
 #ifndef DMZ_DETECT_WPS_H
 #define DMZ_DETECT_WPS_H 7
 #endif
 #ifndef DMZ_DETECT_WPS_V
-#define DMZ_DETECT_WPS_V 4
+#define DMZ_DETECT_WPS_V 5
 #endif
 template <bool VERT, int NT, int SC, int RG>
 __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H)) void k_detect_walk(const uint8_t *__restrict__ planes,
@@ -662,7 +665,7 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
   const int nt = a.nthreads > b.nthreads ? a.nthreads : b.nthreads;
   const int lds = a.lds_total > b.lds_total ? a.lds_total : b.lds_total;
   // the boxes of a 640 x 480 frame (28 steps x 389 lanes, 38 steps x 241 lanes): single-walk kernels
-  constexpr int kSteps = VERT ? 38 : 28, kNt = VERT ? 256 : 448, kRegs = VERT ? 38 : DMZ_DETECT_REGS_H;
+  constexpr int kSteps = VERT ? 38 : 28, kNt = VERT ? 256 : 448, kRegs = VERT ? DMZ_DETECT_REGS_V : DMZ_DETECT_REGS_H;
   auto parks = [](const DmzBoxParams &q) {  // the parked gradients and a list of >= 1024 entries fit, the map fits the tile
     return q.lds_red - q.lds_map - ((4 * q.lanes * (kSteps - kRegs) + 15) & ~15) >= 2048 && q.lanes * q.steps <= q.lds_map;
   };
