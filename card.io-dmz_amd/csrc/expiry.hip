@@ -172,34 +172,34 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
     return;                                    \
   }
 constexpr int IROWS = 23;    // inter rows: image rows base-4 .. base+18 (clamped to the ROI)
-constexpr int ISTRIDE = 432; // bytes per inter row
+constexpr int ISTRIDE = 428; // bytes per inter row (107 dwords)
 struct SegLds {
-  unsigned char inter[IROWS * ISTRIDE];  // 9,936 B
-  int colB[432];                         // column sums over rows base-1 .. base+15 (regrid_group)
+  unsigned char inter[IROWS * ISTRIDE];  // 9,844 B
+  int colB[428];                         // column sums over rows base-1 .. base+15 (regrid_group)
+  // three tenants, one after the other (a single wave: its LDS operations execute in program order)
   union {
-    struct {                             // until the local groups are formed
-      int colA[432];                     // column sums over rows base .. base+16, later the pick map
-      int rsum[432];                     // 9-wide sliding rect sums
-      int itemL[64], itemS[64];          // non-overlapping rects sorted by left
-      int gstart[66];
+    int colA[428];                       // column sums over rows base .. base+16, until the rect sums are in registers
+    struct {                             // the picked rects sorted by left, until the local groups are formed
+      int itemS[64];
+      short itemL[64];
+      short gstart[66];
     } a;
     struct {                             // per group
       unsigned char tile[3 * 21 * 19 + 3];  // thresholded tiles of optimize_character_rects
+      // 16-bit: positions and widths < 432, sums of at most 21 bytes (the workgroup's LDS decides how
+      // many stripes a CU holds, and the kernel is latency-bound)
+      short rL[64];                      // their left edges
+      short cLeft[64], cTop[64];         // optimised character rects of the current group
+      // per slot of optimize_character_rects: 24 entries apart (21 used), so that the wide reads the compiler
+      // merges a slot's 18 consecutive entries into start 16-byte aligned (a 42-byte slot pitch made them
+      // unaligned ds_read_b128: SQ_LDS_UNALIGNED_STALL was twice the kernel's LDS busy cycles).  Column maxima,
+      // then column sums, then row sums.
+      __attribute__((aligned(16))) short cm[80];
     } b;
   } u;
-  // 16-bit: positions and widths < 432, sums of at most 21 bytes (the workgroup's LDS decides how
-  // many stripes a CU holds, and the kernel is latency-bound)
   short gL[64], gW[64];                  // surviving local groups
-  int rS[64];                            // sums of the regridded rects of the current group
-  short rL[64];                          // their left edges
-  short cLeft[64], cTop[64];             // optimised character rects of the current group
-  short okeep[64], oLeft[64], oTop[64];
-  // per slot of optimize_character_rects: 24 entries apart (21 used), so that the wide reads the compiler
-  // merges a slot's 18 consecutive entries into start 16-byte aligned (a 42-byte slot pitch made them
-  // unaligned ds_read_b128: SQ_LDS_UNALIGNED_STALL was twice the kernel's LDS busy cycles)
-  __attribute__((aligned(16))) short cmax[80];
-  __attribute__((aligned(16))) short csum[80];
 };
+static_assert(sizeof(SegLds) <= 13648, "twelve stripes per CU");
 
 // four |p[c+1] - p[c-1]| of dword d of a row (prev / cur / next = dwords d-1, d, d+1), column index
 // clamped at 0 and 427 (sobel.cpp:729-734), as bytes
@@ -230,6 +230,19 @@ __device__ __forceinline__ void strip_white_space(const int *__restrict__ sums, 
     const long long thr = (long long)((double)q * 0.8);
     if ((long long)sums[s] < thr) s++;
     else if ((long long)sums[e - 1] < thr) e--;
+    else break;
+  }
+}
+
+// the same on sums held one per lane (lane k = sums[k]); s and e are wave-uniform
+__device__ __forceinline__ void strip_white_space_lanes(int mine, int &s, int &e) {
+  auto at = [&](int i) { return (long long)__builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane(i)); };
+  while (e - s > 5) {
+    const int idx = s + (e - s - 4) / 2;
+    const long long q = (at(idx) + at(idx + 1) + at(idx + 2) + at(idx + 3)) / 4;
+    const long long thr = (long long)((double)q * 0.8);
+    if (at(s) < thr) s++;
+    else if (at(e - 1) < thr) e--;
     else break;
   }
 }
@@ -334,20 +347,12 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      L.u.a.colA[4 * d + q] = a[q];
+      L.u.colA[4 * d + q] = a[q];
       L.colB[4 * d + q] = a[q] + s2[q] - s19[q];
     }
   }
   __syncthreads();
-  for (int c = lane; c < CW - SCW + 1; c += 64) {
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < SCW; k++) s += L.u.a.colA[c + k];
-    L.u.a.rsum[c] = s;
-  }
-  __syncthreads();
-
-  XSEG_STOP(2, L.u.a.rsum[lane])
+  XSEG_STOP(2, L.u.colA[lane])
   // thresholds (expiry_seg.cpp:447-449, 488-494).  While the running total stays below 2^24 every
   // float addition of these integers is exact, so the float total equals the integer total whenever
   // that is < 2^24 (the common case); only beyond that the additions round and the reference's
@@ -361,7 +366,13 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 #pragma unroll
     for (int j = 0; j < 7; j++) {
       const int c = lane + 64 * j;
-      rs7[j] = c < CW - SCW + 1 ? L.u.a.rsum[c] : 0;
+      // sliding 9-wide rect sum of columns c .. c + 8 (expiry_seg.cpp:456-486)
+      int rs = 0;
+      if (c < CW - SCW + 1) {
+#pragma unroll
+        for (int k = 0; k < SCW; k++) rs += L.u.colA[c + k];
+      }
+      rs7[j] = rs;
       if (c < CW - SCW + 1 && (float)rs7[j] > thr1) isum += rs7[j], icnt++;
     }
     // rect sums are < 2^20 and there are <= 420 of them: the integer total fits 32 bits
@@ -372,7 +383,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     } else {
       total = 0.0f;
       for (int c = 0; c < CW - SCW + 1; c++) {
-        const float sv = (float)L.u.a.rsum[c];
+        int rs = 0;
+        for (int k = 0; k < SCW; k++) rs += L.u.colA[c + k];
+        const float sv = (float)rs;
         if (sv > thr1) total += sv;
       }
     }
@@ -391,8 +404,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     if (c < CW - SCW + 1 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
       key[j] = ((unsigned)rs7[j] << 9) | (unsigned)(511 - c);
   }
-  for (int c = lane; c < 432; c += 64) L.u.a.colA[c] = 0;  // pick map: sum of the rect picked at column c
-  __syncthreads();
+  unsigned picked = 0u;  // bit j: the rect at column lane + 64 j was picked
   for (;;) {
     unsigned m = key[0];
 #pragma unroll
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     m = wave_max_u32(m);
     if (m == 0u) break;
     const int pl = 511 - (int)(m & 511u);
-    if (lane == 0) L.u.a.colA[pl] = (int)(m >> 9);
+    picked |= lane == (pl & 63) ? 1u << (pl >> 6) : 0u;
     // either end of a rect within 8 columns of the pick would hit the mask
     key[0] = iabs(lane - pl) < SCW ? 0u : key[0];
     key[1] = iabs(lane + 64 - pl) < SCW ? 0u : key[1];
@@ -410,14 +422,13 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     key[5] = iabs(lane + 320 - pl) < SCW ? 0u : key[5];
     key[6] = iabs(lane + 384 - pl) < SCW ? 0u : key[6];
   }
-  __syncthreads();
-  XSEG_STOP(4, L.u.a.colA[lane])
-  // sorted by left = column order
+  XSEG_STOP(4, picked)
+  // sorted by left = column order (a picked rect's sum passed the thresholds: it is > 0)
   int n_items = 0;
 #pragma unroll
   for (int j = 0; j < 7; j++) {
     const int c = lane + 64 * j;
-    const int s = c < CW ? L.u.a.colA[c] : 0;
+    const int s = ((picked >> j) & 1u) ? rs7[j] : 0;
     const unsigned long long bal = __ballot(s != 0);
     if (s != 0) {
       const int pos = n_items + __popcll(bal & lanemask_lt(lane));
@@ -511,22 +522,21 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       else sp = 15, so = q - 50;
     }
     int nR;
+    int my_sum = 0;  // sum of the regridded rect `lane`
     {
       const int off = so + lane * sp;
       const bool ok = off + 1 < bw;
       if (ok) {
-        int s = 0;
         const int cend = imin(off + sp, bw);
-        for (int c = off + 1; c < cend; c++) s += L.colB[bl + c];
-        L.rL[lane] = bl + off + 1;
-        L.rS[lane] = s;
+        for (int c = off + 1; c < cend; c++) my_sum += L.colB[bl + c];
+        L.u.b.rL[lane] = bl + off + 1;
       }
       nR = __popcll(__ballot(ok));
     }
     __syncthreads();
     const int cw = sp - 1;
     int rs = 0, re = nR;
-    strip_white_space(L.rS, rs, re);
+    strip_white_space_lanes(my_sum, rs, re);
     if (DMZ_XSEG_STOP == 6) continue;
 
     // ---- optimize_character_rects (231-339): three rects per pass, 21 lanes each.  Lane c of a
@@ -534,13 +544,14 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     // the max, the normalise+threshold and the column sum; the row sums come from a transposed
     // read of the thresholded tile (lane r = row r). ----
     const int ciw = cw + 4, cih = 17 + 4;
+    int my_left = -1, my_top = 0;  // optimised rect `lane` (my_left < 0: dropped)
     {
       const int sl = lane / 21, c = lane - sl * 21;
       unsigned char *tile = L.u.b.tile;  // [3][21][19]
       for (int b0 = rs; b0 < re; b0 += 3) {
         const int k = b0 + sl;
         const bool have = sl < 3 && k < re;
-        const int rect_left = have ? L.rL[k] - 2 : 0;
+        const int rect_left = have ? L.u.b.rL[k] - 2 : 0;
         const bool valid = have && !(rect_left < 0 || rect_left + ciw > CW || (g_top - 2) + cih > CH);
         const bool col = valid && c < ciw;
         int v[21];
@@ -556,11 +567,11 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           }
         }
         const int sidx = sl * 24 + c;  // this lane's entry of the per-slot arrays
-        L.cmax[sidx] = mx;
+        L.u.b.cm[sidx] = mx;
         __syncthreads();
         if (sl < 3) {
 #pragma unroll
-          for (int j = 0; j < 18; j++) mx = imax(mx, L.cmax[sl * 24 + j]);
+          for (int j = 0; j < 18; j++) mx = imax(mx, L.u.b.cm[sl * 24 + j]);
         }
         // cvNormalize's scale is (float)(255.0 / (double)max); for every integer max in [1, 32767] that
         // equals the correctly rounded float quotient (checked exhaustively, tests/test_oracle_units.py)
@@ -574,41 +585,45 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
             if (c < 19) tile[(sl * 21 + r) * 19 + c] = t;
           }
         }
-        L.csum[sidx] = cs;
+        L.u.b.cm[sidx] = cs;
         __syncthreads();
         // column trimming (every lane of the slot replays it: uniform within the slot)
         int lc = 0, rc = ciw - 1;
         if (sl < 3)
           for (int wv = ciw; wv > TW; wv--) {
-            if (L.csum[sl * 24 + lc] <= L.csum[sl * 24 + rc]) lc++;
+            if (L.u.b.cm[sl * 24 + lc] <= L.u.b.cm[sl * 24 + rc]) lc++;
             else rc--;
           }
         int rsm = 0;
         if (sl < 3)  // lane c is row c here
           for (int cc = lc; cc <= rc; cc++) rsm += tile[(sl * 21 + c) * 19 + cc];
         __syncthreads();
-        L.cmax[sidx] = rsm;  // row sums
+        L.u.b.cm[sidx] = rsm;  // row sums
         __syncthreads();
+        int tr = 0;
         if (sl < 3 && c == 0 && have) {
-          int tr = 0, brw = cih - 1;
+          int brw = cih - 1;
           for (int hv = cih; hv > TH; hv--) {
-            if (L.cmax[sl * 24 + tr] <= L.cmax[sl * 24 + brw]) tr++;
+            if (L.u.b.cm[sl * 24 + tr] <= L.u.b.cm[sl * 24 + brw]) tr++;
             else brw--;
           }
-          L.okeep[k] = valid ? 1 : 0;
-          L.oLeft[k] = rect_left + lc;
-          L.oTop[k] = (g_top - 2) + tr;
         }
-        __syncthreads();
+        // the slot's result (held by its lane 0) goes to the lane that owns rect b0 + slot
+        const int out_left = valid ? rect_left + lc : -1, out_top = (g_top - 2) + tr;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int vl = __builtin_amdgcn_readlane(out_left, 21 * q), vt = __builtin_amdgcn_readlane(out_top, 21 * q);
+          if (lane == b0 + q && b0 + q < re) my_left = vl, my_top = vt;
+        }
       }
     }
-    const bool keep = lane >= rs && lane < re && L.okeep[lane] != 0;
+    const bool keep = lane >= rs && lane < re && my_left >= 0;
     const unsigned long long kbal = __ballot(keep);
     const int n2 = __popcll(kbal);
     if (keep) {
       const int pos = __popcll(kbal & lanemask_lt(lane));
-      L.cLeft[pos] = L.oLeft[lane];
-      L.cTop[pos] = L.oTop[lane];
+      L.u.b.cLeft[pos] = my_left;
+      L.u.b.cTop[pos] = my_top;
     }
     __syncthreads();
     if (n2 < 5 || DMZ_XSEG_STOP == 7) continue;  // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623)
@@ -630,7 +645,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       const int nc = imin(16, n2 - 2 - p0);
       const int m = lane & 15, kk = lane >> 4;
       const bool live = m < nc;
-      const int pl = live ? L.cLeft[p0 + m] : 0, pt = live ? L.cTop[p0 + m] - (base - 3) : 0;
+      const int pl = live ? L.u.b.cLeft[p0 + m] : 0, pt = live ? L.u.b.cTop[p0 + m] - (base - 3) : 0;
       // (buffer loads: descriptor + 32-bit lane offset + scalar fragment offset, no 64-bit address arithmetic)
       const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(xw + dmzx::SLASH_B3), 0, 3 * dmzx::SLASH_KSTEPS * 5 * 64 * 16, 0x00020000);
@@ -716,9 +731,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
         if (!((hitmask >> q) & 1u)) continue;
         if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
           const int first = p0 + q - 2;
-          int top = L.cTop[first], gleft = L.cLeft[first], gwidth = SCW, gheight = SCH;
+          int top = L.u.b.cTop[first], gleft = L.u.b.cLeft[first], gwidth = SCW, gheight = SCH;
           for (int i = 0; i < 5; i++) {
-            const int ct = L.cTop[first + i], cl = L.cLeft[first + i];
+            const int ct = L.u.b.cTop[first + i], cl = L.u.b.cLeft[first + i];
             const int former_bottom = top + gheight;
             top = imin(ct, top);
             gwidth = (cl + SCW) - gleft;
@@ -727,8 +742,8 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           short *h = sg->hdr[n_emitted];
           h[0] = (short)top, h[1] = (short)gleft, h[2] = (short)gwidth, h[3] = (short)gheight;
           for (int i = 0; i < 5; i++) {
-            h[4 + i] = (short)L.cTop[first + i];
-            h[9 + i] = (short)L.cLeft[first + i];
+            h[4 + i] = (short)L.u.b.cTop[first + i];
+            h[9 + i] = (short)L.u.b.cLeft[first + i];
           }
           h[14] = (short)base;
           h[15] = 0;
