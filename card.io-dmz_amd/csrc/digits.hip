@@ -120,6 +120,7 @@ __device__ __forceinline__ void digit_fc1(const Fc1B &w, const float *__restrict
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
   }
   // D: column (hidden unit) = lane & 15, row (digit) = 4 * (lane >> 4) + v
+  __syncthreads();  // `part` lies over the pooled activations the other waves may still be reading
 #pragma unroll
   for (int v = 0; v < 4; v++) part[(kh * 16 + 4 * kk + v) * 32 + nt * 16 + ii] = acc0[v] + acc1[v];
 }
@@ -151,16 +152,21 @@ __device__ __forceinline__ void digit_head(const float *__restrict__ mw, const f
   __syncthreads();
 }
 
-__global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restrict__ wts,
+#ifndef DMZ_DIGITS_WGS  /* workgroups per CU the register allocation and the LDS layout aim at */
+#define DMZ_DIGITS_WGS 5
+#endif
+__global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const float *__restrict__ wts,
                                                         const float *__restrict__ hidw /* 3 x [32][320] */,
                                                         const uint8_t *__restrict__ cards,
                                                         size_t card_stride, int n,
                                                         dmz_hip_frame_result *__restrict__ results) {
   __shared__ __attribute__((aligned(16))) float pooled[16 * DG_PSTRIDE];  // 20,736 B; hist overlays it
   __shared__ __attribute__((aligned(16))) unsigned char eq[16 * DG_ESTRIDE];  // 8,448 B
-  __shared__ float part[2 * 16 * 32];
-  __shared__ float hid[16 * 32];
   __shared__ float prob[3 * 16 * 10];
+  // the FC1 partial sums and the hidden activations reuse the first 6 KB of `pooled` (rows 0 .. 4, rewritten by
+  // every model's convolution): 31 KB per workgroup, five workgroups per CU
+  float *part = pooled;               // 2 x 16 x 32
+  float *hid = pooled + 2 * 16 * 32;  // 16 x 32
   // pooled is dead until the first conv: it first holds the 16 histograms (u16 counters,
   // 8 KB) and the 27 x 428 number strip (11.6 KB)
   unsigned int *hist32 = (unsigned int *)pooled;                       // 16 x 128 words
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restric
   for (int m = 0; m < 3; m++) {
     const float *mw = wts + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
     Fc1B fcb;
-    digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);
+    if (DMZ_DIGITS_WGS < 5) digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);  // early: 40 registers across the conv
     for (int i = tid; i < nd * 40; i += DG_THREADS) {
       const int d = i / 40, pos = i - d * 40;
       const int pr = pos / 5, pc = pos - pr * 5;
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(DG_THREADS, 4) void k_digits(const float *__restric
     }
     __syncthreads();
     DG_STOP(3, pooled[0] + pooled[300])
+    if (DMZ_DIGITS_WGS >= 5) digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);
     digit_fc1(fcb, pooled, part, wave, lane);
     __syncthreads();
     DG_STOP(4, part[0] + part[600])
