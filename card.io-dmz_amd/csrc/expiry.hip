@@ -80,12 +80,14 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   if (nrows > 128 || nrows < 18) return;  // y_offset >= 121 for a card that is not upside down
   const uint8_t *card = cards + (size_t)f * card_stride;
 
-  // eight rows per trip: 16 dword loads in flight per lane (the rows come from HBM)
-  for (int r0 = 0; r0 < nrows; r0 += 8) {
-    uint32_t a[8], b[8];
-    unsigned extra[8];
+  // sixteen rows per trip: 32 dword loads in flight per lane (the rows come from HBM; the kernel is bound by the
+  // latency of these trips), and two rows per wave reduction (a lane's sum is < 2^11, a 16-lane row's < 2^15)
+  constexpr int kTrip = 16;
+  for (int r0 = 0; r0 < nrows; r0 += kTrip) {
+    uint32_t a[kTrip], b[kTrip];
+    unsigned extra[kTrip];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < kTrip; u++) {
       const int r = imin(r0 + u, nrows - 1);
       const uint32_t *row = (const uint32_t *)(card + (size_t)(y0 + r) * CW);
       a[u] = row[6 + lane];
@@ -99,11 +101,24 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t left = __builtin_amdgcn_alignbyte(b[u], a[u], 2);  // p[26 + 4 lane ..]
-      unsigned s = __builtin_amdgcn_sad_u8(b[u], left, extra[u]);       // p[28 + 4 lane ..] vs left
-      s = (unsigned)wave_sum_i32((int)s);
-      if (lane == 0 && r0 + u < nrows) I[r0 + u] = (int)s;
+    for (int u = 0; u < kTrip; u += 2) {
+      unsigned s[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t left = __builtin_amdgcn_alignbyte(b[u + h], a[u + h], 2);  // p[26 + 4 lane ..]
+        s[h] = __builtin_amdgcn_sad_u8(b[u + h], left, extra[u + h]);              // p[28 + 4 lane ..] vs left
+      }
+      int v = (int)(s[0] | (s[1] << 16));
+      v += DMZ_DPP_SHR(v, 1);
+      v += DMZ_DPP_SHR(v, 2);
+      v += DMZ_DPP_SHR(v, 4);
+      v += DMZ_DPP_SHR(v, 8);
+      const unsigned q0 = (unsigned)__builtin_amdgcn_readlane(v, 15), q1 = (unsigned)__builtin_amdgcn_readlane(v, 31);
+      const unsigned q2 = (unsigned)__builtin_amdgcn_readlane(v, 47), q3 = (unsigned)__builtin_amdgcn_readlane(v, 63);
+      const unsigned lo = (q0 & 0xffffu) + (q1 & 0xffffu) + (q2 & 0xffffu) + (q3 & 0xffffu);
+      const unsigned hi = (q0 >> 16) + (q1 >> 16) + (q2 >> 16) + (q3 >> 16);
+      if (lane == 0 && r0 + u < nrows) I[r0 + u] = (int)lo;
+      if (lane == 0 && r0 + u + 1 < nrows) I[r0 + u + 1] = (int)hi;
     }
   }
   __syncthreads();

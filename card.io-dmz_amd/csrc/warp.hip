@@ -50,7 +50,15 @@ constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
 #endif
 constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at up to 1.47 source px per card px; with the row
                                  // records the workgroup uses 20,288 B of LDS: eight per CU
-constexpr int kStagePasses = LH / 8;
+// waves per strip: each walks TH / kWaves rows of the strip's 64 columns.  Per-wave set-up (column terms, the start
+// of the reciprocal chains) is ~15 % of a 23-row walk; two waves of 45 rows issue 12 % fewer instructions but leave
+// 16 waves per CU instead of 32 and run 4 % slower (0.758 vs 0.729 ms per 8192 frames).
+#ifndef DMZ_WARP_WAVES
+#define DMZ_WARP_WAVES 4
+#endif
+constexpr int kWaves = DMZ_WARP_WAVES, kThreads = 64 * kWaves;
+constexpr int kStageRows = kThreads / 32;  // window rows staged per pass (a thread = one dword column)
+constexpr int kStagePasses = LH / kStageRows;
 constexpr int kFastFlag = 1 << 16;  // DmzWarpWin.wrows: the strip admits the extrapolated reciprocal (k_warp)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
   mats[frame].win[tile] = w;
 }
 
-__global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes, size_t frame_stride,
+__global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ planes, size_t frame_stride,
                                                int row_stride, int sw, int sh, int n, int n_pad,
                                                const DmzWarpMat *__restrict__ mats,
                                                uint8_t *__restrict__ cards, size_t card_stride) {
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   if (!wm.valid) {
     const bool col_ok = x + lane < DMZ_CARD_WIDTH;
     if (col_ok)
-      for (int j = wave; j < TH; j += 4) dbase[(y0 + j) * DMZ_CARD_WIDTH + x + lane] = 0;
+      for (int j = wave; j < TH; j += kWaves) dbase[(y0 + j) * DMZ_CARD_WIDTH + x + lane] = 0;
     return;
   }
   const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
   if (ww.wdw == 0) {
     // ---- generic path: range-checked coordinates, taps straight from global memory ----
     __syncthreads();
-    for (int i = tid; i < TW * TH; i += 256) {
+    for (int i = tid; i < TW * TH; i += kThreads) {
       const int x1 = i & (TW - 1), j = i >> 6;
       if (x + x1 >= DMZ_CARD_WIDTH) continue;
       const RowXYW r = s_row[j];
@@ -243,25 +251,26 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
           (void *)src, 0, fbytes > 0xfffffffcu ? 0xfffffffcu : (unsigned)fbytes, 0x00020000);
       const int voff = (wy0 + sj) * row_stride + wx0 + 4 * sq;
       unsigned char *lp = win + sj * LW + 4 * sq;
-      constexpr int kA = 12;
+      constexpr int kA = 96 / kStageRows;  // the 96 rows of a strip at scale 1
       uint32_t sa[kA], sb[kStagePasses - kA];
 #pragma unroll
-      for (int it = 0; it < kA; it++) sa[it] = __builtin_amdgcn_raw_buffer_load_b32(frame_rs, voff, 8 * it * row_stride, 0);
-      if (wrows > 8 * kA) {
+      for (int it = 0; it < kA; it++)
+        sa[it] = __builtin_amdgcn_raw_buffer_load_b32(frame_rs, voff, kStageRows * it * row_stride, 0);
+      if (wrows > kStageRows * kA) {
 #pragma unroll
         for (int it = kA; it < kStagePasses; it++)
-          sb[it - kA] = __builtin_amdgcn_raw_buffer_load_b32(frame_rs, voff, 8 * it * row_stride, 0);
+          sb[it - kA] = __builtin_amdgcn_raw_buffer_load_b32(frame_rs, voff, kStageRows * it * row_stride, 0);
       }
 #pragma unroll
-      for (int it = 0; it < kA; it++) *(uint32_t *)(lp + 8 * it * LW) = sa[it];
-      if (wrows > 8 * kA) {
+      for (int it = 0; it < kA; it++) *(uint32_t *)(lp + kStageRows * it * LW) = sa[it];
+      if (wrows > kStageRows * kA) {
 #pragma unroll
-        for (int it = kA; it < kStagePasses; it++) *(uint32_t *)(lp + 8 * it * LW) = sb[it - kA];
+        for (int it = kA; it < kStagePasses; it++) *(uint32_t *)(lp + kStageRows * it * LW) = sb[it - kA];
       }
     }
   } else {
     const int wdw = -ww.wdw;
-    for (int i = tid; i < wdw * wrows; i += 256) {
+    for (int i = tid; i < wdw * wrows; i += kThreads) {
       const int j = i / wdw, q = i - j * wdw;
       const int gy = wy0 + j, gx = wx0 + 4 * q;
       uint32_t v = 0u;
@@ -369,8 +378,8 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ planes
 
   // ---- the strip: wave w takes the 23 rows from a = min(23 w, 67) (rows 67, 68 are produced twice,
   // with the same bytes), two rows per iteration as independent chains ----
-  constexpr int kRows = 23;
-  static_assert(4 * kRows >= TH && (kRows & 1) == 1, "rows per wave");
+  constexpr int kRows = ((TH + kWaves - 1) / kWaves) | 1;  // 45 (two waves: no row twice) / 23 (four: rows 67, 68 twice)
+  static_assert(kWaves * kRows >= TH && (kRows & 1) == 1 && TH <= kThreads, "rows per wave");
   const int a = imin(wave_s * kRows, TH - kRows);
 
   if (!(ww.wrows & kFastFlag)) {
@@ -506,6 +515,6 @@ void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, 
   const int aligned = ((((uintptr_t)planes) | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
   hipLaunchKernelGGL(k_warp_windows, dim3((unsigned)((n * kTiles + 255) / 256)), dim3(256), 0, s, n, width,
                      height, aligned, mats);
-  hipLaunchKernelGGL(k_warp, dim3((unsigned)n_pad * kTiles), dim3(256), 0, s, planes, frame_stride,
+  hipLaunchKernelGGL(k_warp, dim3((unsigned)n_pad * kTiles), dim3(kThreads), 0, s, planes, frame_stride,
                      row_stride, width, height, n, n_pad, mats, cards, card_stride);
 }
