@@ -486,6 +486,10 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
   // [wave 4][k-step 7][part 3][lane 64][8]: lane (unit = 16 wave + (lane & 15), run = lane >> 4) of k-step ks
   // holds k = 32 ks + 8 run .. + 7 (zero beyond unit 49 / k 203); and the row sums of W1
   {
+    for (int m = 0; m < 3; m++)
+      for (int i = 0; i < 72; i++)
+        hidwt[dmzv::WFRAG + dmzv::CONVS + m * 72 + i] =
+            w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_CONV_W + i] * (1.0f / 255.0f);
     uint16_t *wb = (uint16_t *)(hidwt.data() + dmzv::WFRAG + dmzv::WB3);
     float *rowsum = hidwt.data() + dmzv::WFRAG + dmzv::ROWSUM;
     for (int wv = 0; wv < 4; wv++)

@@ -57,23 +57,26 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // conv 3x3 valid -> 3x3 max pool -> + bias -> tanh for one pooled position; the 8 kernels
 // share the 5x5 input patch, two kernels per v_pk_fma_f32.
+// cw: the 8 x 9 conv weights (k_digits: pre-multiplied by 1/255, the input patch holds the raw byte values)
 __device__ __forceinline__ void digit_conv_pool(const float (&in)[5][5], const float *__restrict__ mw,
-                                                int pos, float *__restrict__ pooled /* row */) {
-#pragma unroll 1
+                                                const float *__restrict__ cw, int pos, float *__restrict__ pooled /* row */) {
+#ifndef DMZ_DIGITS_CONV_UNROLL
+#define DMZ_DIGITS_CONV_UNROLL 2
+#endif
+#pragma unroll DMZ_DIGITS_CONV_UNROLL
   for (int k = 0; k < 8; k += 2) {
     f32x2 acc[9];
 #pragma unroll
-    for (int o = 0; o < 9; o++) acc[o] = (f32x2){0.f, 0.f};
-#pragma unroll
     for (int t = 0; t < 9; t++) {
-      const f32x2 w2 = {mw[dmzw::D_CONV_W + k * 9 + t], mw[dmzw::D_CONV_W + (k + 1) * 9 + t]};
+      const f32x2 w2 = {cw[k * 9 + t], cw[(k + 1) * 9 + t]};
       const int ti = t / 3, tj = t - 3 * (t / 3);
 #pragma unroll
       for (int oy = 0; oy < 3; oy++)
 #pragma unroll
         for (int ox = 0; ox < 3; ox++) {
           const f32x2 x2 = {in[oy + ti][ox + tj], in[oy + ti][ox + tj]};
-          acc[oy * 3 + ox] = __builtin_elementwise_fma(w2, x2, acc[oy * 3 + ox]);
+          // (the first tap starts the sum: no zero-initialised accumulators)
+          acc[oy * 3 + ox] = t == 0 ? w2 * x2 : __builtin_elementwise_fma(w2, x2, acc[oy * 3 + ox]);
         }
     }
     f32x2 m = acc[0];
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
   __syncthreads();
 
   // ---- three CNNs ----
-  const float s255 = 1.0f / 255.0f;
   for (int m = 0; m < 3; m++) {
     const float *mw = wts + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
+    const float *cws = hidw + dmzv::WFRAG + dmzv::CONVS + m * 72;
     Fc1B fcb;
     if (DMZ_DIGITS_WGS < 5) digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);  // early: 40 registers across the conv
     for (int i = tid; i < nd * 40; i += DG_THREADS) {
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
 #pragma unroll
       for (int a = 0; a < 5; a++)
 #pragma unroll
-        for (int b = 0; b < 5; b++) in[a][b] = (float)xp[a * 19 + b] * s255;  // n_categorize.cpp:99
-      digit_conv_pool(in, mw, pos, pooled + d * DG_PSTRIDE);
+        for (int b = 0; b < 5; b++) in[a][b] = (float)xp[a * 19 + b];  // the x 1/255 of n_categorize.cpp:99 is in cws
+      digit_conv_pool(in, mw, cws, pos, pooled + d * DG_PSTRIDE);
     }
     __syncthreads();
     DG_STOP(3, pooled[0] + pooled[300])
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restr
     for (int a = 0; a < 5; a++)
 #pragma unroll
       for (int b = 0; b < 5; b++) in[a][b] = xp[a * 19 + b];
-    digit_conv_pool(in, mw, pos, pooled + d * DG_PSTRIDE);
+    digit_conv_pool(in, mw, mw + dmzw::D_CONV_W, pos, pooled + d * DG_PSTRIDE);
   }
   __syncthreads();
   Fc1B fcb;

@@ -152,7 +152,8 @@ constexpr int WFRAG = 3 * 320 * 32;                 // offset of this block in t
 constexpr int WB3 = 0;                              // W1 / 255 in three bf16 parts, fragments of v_mfma_f32_16x16x32_bf16:
                                                     // [wave 4][k-step 7][part 3][lane 64][8 bf16]
 constexpr int ROWSUM = 4 * 7 * 3 * 64 * 4;          // sum_k W1[j][k], 64 floats (zero beyond unit 49)
-constexpr int WFRAG_FLOATS = ROWSUM + 64;
+constexpr int CONVS = ROWSUM + 64;                  // the digit models' conv weights x 1/255 (the input scaling folded in), 3 x 72
+constexpr int WFRAG_FLOATS = CONVS + 3 * 72;
 }  // namespace dmzv
 void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag /* dmzv layout */, const uint8_t *cards, size_t card_stride,
                      int n, int mode /* DMZ_HIP_SCAN_* */, dmz_hip_frame_result *results);
