@@ -140,10 +140,10 @@ __device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int 
   dy = SAT ? clampi(VERT ? g_ds : g_sd, -32768, 32767) : (VERT ? g_ds : g_sd);
 }
 
-// lane - 1 / lane + 1 of the wave by DPP (wave_shr:1 / wave_shl:1; the end lanes keep their own value, like
-// __shfl_up / __shfl_down): one VALU instruction instead of a ds_bpermute round trip
-__device__ __forceinline__ int lane_below(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int lane_above(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+// lane - 1 / lane + 1 of the wave by DPP (wave_shr:1 / wave_shl:1; the end lanes, which own no pixel, read 0):
+// one VALU instruction instead of a ds_bpermute round trip
+__device__ __forceinline__ int lane_below(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int lane_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 
 // NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
 // given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
@@ -154,7 +154,7 @@ template <bool VERT>
 __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, int low,
                                           int high, int dxc, int dyc, int mp, int mp_lo, int mp_hi,
                                           int mc, int mc_lo, int mc_hi, int mn, int mn_lo, int mn_hi,
-                                          unsigned char *map, unsigned short *list, int list_cap, int *s_int) {
+                                          unsigned char *map, unsigned short *seg, int seg_cap, int &ncand, int *s_int) {
   const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
   const int m = mc;
   // neighbours in image coordinates
@@ -202,19 +202,17 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   }
   const int q = s * c.L + c.l;  // walk-space index
   map[q] = (unsigned char)flags;
-  // candidates that are not seeds go on the list (seeds need no propagation): one counter update per wave
+  // candidates that are not seeds go on THIS WAVE's list (seeds need no propagation): the count is wave-uniform,
+  // so an append is a ballot and a prefix count -- no LDS atomic, no wait
   const bool cand = (flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND;
   const unsigned long long bal = __ballot(cand);
   if (bal) {
-    int base = 0;
-    const int first = __builtin_ctzll(bal);
-    if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&s_int[2], __popcll(bal));
-    base = __builtin_amdgcn_readlane(base, first);
     if (cand) {
-      const int slot = base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
-      if (slot < list_cap) list[slot] = (unsigned short)q;
+      const int slot = ncand + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
+      if (slot < seg_cap) seg[slot] = (unsigned short)q;
       else s_int[3] = 1;
     }
+    ncand += __popcll(bal);
   }
 }
 
@@ -245,6 +243,10 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   const int park_bytes = kParked ? ((4 * bp.lanes * (SC - RG) + 15) & ~15) : 0;
   unsigned short *list = kParked ? (unsigned short *)(lds + bp.lds_map + park_bytes) : (unsigned short *)(lds + bp.lds_acc);
   const int list_cap = kParked ? (bp.lds_red - bp.lds_map - park_bytes) / 2 : bp.list_cap;
+  // one list segment per wave
+  const int seg_cap = list_cap / (NT / 64);
+  unsigned short *seg = list + wave * seg_cap;
+  int ncand = 0;  // wave-uniform
   long long *s_red = (long long *)(lds + bp.lds_red);                    // 16 x 8 B
   unsigned long long *s_best = (unsigned long long *)(lds + bp.lds_red + 128);  // 16 x 8 B
   int *s_int = (int *)(lds + bp.lds_red + 256);                          // low, high, ncand, overflow
@@ -400,7 +402,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
           const uint32_t h = gc ^ 0x80008000u;
           const int dxc = (int)(short)(h & 0xffffu), dyc = (int)h >> 16;
           nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo, mc_hi, mn, mn_lo, mn_hi,
-                          map, list, list_cap, s_int);
+                          map, seg, seg_cap, ncand, s_int);
         }
         mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;
         mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;
@@ -463,7 +465,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);                             \
     if (sn >= 1 && owner)                                                                 \
       nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo,    \
-                      mc_hi, mn, mn_lo, mn_hi, map, list, list_cap, s_int);               \
+                      mc_hi, mn, mn_lo, mn_hi, map, seg, seg_cap, ncand, s_int);          \
     mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;                                                \
     mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;                                                \
     dxc = dxn; dyc = dyn;                                                                 \
@@ -476,18 +478,22 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     __syncthreads();
   }
   }
-  DMZ_STOP_AFTER(3, map[0] + map[N - 1] + s_int[2])
+  DMZ_STOP_AFTER(3, map[0] + map[N - 1] + ncand)
 
+  // (the appends ran on the owner lanes only: lane 1 of every wave is one)
+  ncand = __builtin_amdgcn_readlane(ncand, 1);
   // ---- D. hysteresis: propagate MAP_EDGE over 8-connected candidates until stable ----
   // (8-adjacency is the same in walk space: rows = steps, columns = lanes)
   {
+    // every wave works through its own list; a wave that ran out of room sends everybody over the whole map
     const bool overflow = s_int[3] != 0;
-    const int nitems = overflow ? N : (s_int[2] < bp.list_cap ? s_int[2] : bp.list_cap);
+    const int nitems = overflow ? N : ncand;
+    const int i0 = overflow ? tid : lane, istep = overflow ? NT : 64;
     volatile unsigned char *vmap = map;
     for (;;) {
       int changed = 0;
-      for (int i = tid; i < nitems; i += NT) {
-        int q = overflow ? i : (int)list[i];
+      for (int i = i0; i < nitems; i += istep) {
+        int q = overflow ? i : (int)seg[i];
         if ((vmap[q] & (MAP_CAND | MAP_EDGE)) != MAP_CAND) continue;
         int a = __umulhi((uint32_t)q, inv_L);
         int l = q - a * L;
