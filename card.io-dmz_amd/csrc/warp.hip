@@ -51,14 +51,15 @@ constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
 constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at up to 1.47 source px per card px; with the row
                                  // records the workgroup uses 20,288 B of LDS: eight per CU
 // waves per strip: each walks TH / kWaves rows of the strip's 64 columns.  Per-wave set-up (column terms, the start
-// of the reciprocal chains) is ~15 % of a 23-row walk; two waves of 45 rows issue 12 % fewer instructions but leave
-// 16 waves per CU instead of 32 and run 4 % slower (0.758 vs 0.729 ms per 8192 frames).
+// of the reciprocal chains) is ~13 % of a 23-row walk.  Three waves of 30 rows cover the 90 rows exactly (no row twice,
+// no odd-row tail): 7 % fewer instructions at 24 instead of 32 waves per CU, measured 1 - 5 % faster than four waves
+// of 23; two waves of 45 rows (16 waves per CU) are 4 % slower.
 #ifndef DMZ_WARP_WAVES
-#define DMZ_WARP_WAVES 4
+#define DMZ_WARP_WAVES 3
 #endif
 constexpr int kWaves = DMZ_WARP_WAVES, kThreads = 64 * kWaves;
 constexpr int kStageRows = kThreads / 32;  // window rows staged per pass (a thread = one dword column)
-constexpr int kStagePasses = LH / kStageRows;
+constexpr int kStagePasses = (LH + kStageRows - 1) / kStageRows;  // (a partial last pass is guarded)
 constexpr int kFastFlag = 1 << 16;  // DmzWarpWin.wrows: the strip admits the extrapolated reciprocal (k_warp)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
       for (int it = 0; it < kA; it++) *(uint32_t *)(lp + kStageRows * it * LW) = sa[it];
       if (wrows > kStageRows * kA) {
 #pragma unroll
-        for (int it = kA; it < kStagePasses; it++) *(uint32_t *)(lp + kStageRows * it * LW) = sb[it - kA];
+        for (int it = kA; it < kStagePasses; it++)
+          if (LH % kStageRows == 0 || it < kStagePasses - 1 || sj + kStageRows * it < LH)
+            *(uint32_t *)(lp + kStageRows * it * LW) = sb[it - kA];
       }
     }
   } else {
@@ -378,8 +381,9 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
 
   // ---- the strip: wave w takes the 23 rows from a = min(23 w, 67) (rows 67, 68 are produced twice,
   // with the same bytes), two rows per iteration as independent chains ----
-  constexpr int kRows = ((TH + kWaves - 1) / kWaves) | 1;  // 45 (two waves: no row twice) / 23 (four: rows 67, 68 twice)
-  static_assert(kWaves * kRows >= TH && (kRows & 1) == 1 && TH <= kThreads, "rows per wave");
+  // 45 (two waves: no row twice) / 30 (three: even, no row twice) / 23 (four: rows 67, 68 twice)
+  constexpr int kRows = kWaves == 3 ? 30 : ((TH + kWaves - 1) / kWaves) | 1;
+  static_assert(kWaves * kRows >= TH && TH <= kThreads, "rows per wave");
   const int a = imin(wave_s * kRows, TH - kRows);
 
   if (!(ww.wrows & kFastFlag)) {
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
       store_row(j0, va);
       store_row(j1, vb);
     }
-    {
+    if constexpr (kRows & 1) {
       const int j = a + kRows - 1;
       uint32_t Xa, Ya, va, vb;
       exact_xy(s_row[j], Xa, Ya);
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     store_row(j0, va);
     store_row(j1, vb);
   }
-  {
+  if constexpr (kRows & 1) {
     const int j = a + kRows - 1;
     uint32_t Xa, Ya, va, vb;
     fast_xy(cA, Xa, Ya);
