@@ -559,6 +559,23 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
               sb[((((size_t)part * dmzx::SLASH_KSTEPS + ks) * 5 + nt) * 64 + lane) * 8 + e] = parts[part];
           }
   }
+  {
+    // expiry CNN conv1 weights [map 50][tap 25] as the B operand of a [positions x 32] x [32 x 64] product, three bf16 parts
+    const float *c1 = w + dmzw::EXPIRY + dmzw::X_C1W;
+    uint16_t *cb = (uint16_t *)(xw.data() + dmzx::CONV1_B3);
+    for (int nt = 0; nt < 4; nt++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 8; e++) {
+          const int k = 8 * (lane >> 4) + e, nn = 16 * nt + (lane & 15);
+          const float wv = (k < 25 && nn < 50) ? c1[nn * 25 + k] : 0.0f;
+          const uint16_t p0 = bf16_rne(wv);
+          const float r1 = wv - bf16_to_float(p0);
+          const uint16_t p1 = bf16_rne(r1);
+          const float r2 = r1 - bf16_to_float(p1);
+          const uint16_t parts[3] = {p0, p1, bf16_rne(r2)};
+          for (int part = 0; part < 3; part++) cb[(((size_t)part * 4 + nt) * 64 + lane) * 8 + e] = parts[part];
+        }
+  }
   // cv::bilateralFilter(d = 3, sigmaColor = 0.95, sigmaSpace = 2/3) tables, expiry_categorize.cpp:52-57
   // (cvSmooth hands param3 to sigmaColor and param4 to sigmaSpace)
   DmzExpiryTables xtab;

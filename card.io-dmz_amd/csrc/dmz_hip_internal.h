@@ -118,7 +118,10 @@ constexpr int CONV2_BL = CONV2_BH + C2_KSTEPS * 3 * 64 * 4;
 // fragments [part 3][k-step 6][n-tile 5][lane 64][8 bf16]; K = 176 padded to 192
 constexpr int SLASH_KSTEPS = 6;
 constexpr int SLASH_B3 = CONV2_BL + C2_KSTEPS * 3 * 64 * 4;
-constexpr int TOTAL = SLASH_B3 + 3 * SLASH_KSTEPS * 5 * 64 * 4;
+// expiry CNN conv1 for v_mfma_f32_16x16x32_bf16: B[k = tap (25, padded to 32)][n = map (50, padded to 64)] split into three
+// bf16 parts, fragments [part 3][n-tile 4][lane 64][8 bf16]
+constexpr int CONV1_B3 = SLASH_B3 + 3 * SLASH_KSTEPS * 5 * 64 * 4;
+constexpr int TOTAL = CONV1_B3 + 3 * 4 * 64 * 4;
 }  // namespace dmzx
 // offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)
 namespace dmzw {

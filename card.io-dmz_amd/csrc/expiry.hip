@@ -814,13 +814,21 @@ struct CatLds {
   // the eight k of a matrix-core fragment (eight maps of one tap) are one aligned 16-byte read.  Prep-time
   // scratch and the conv2 partial sums overlay it.
   __attribute__((aligned(16))) unsigned char l1raw[2 * L1_BF16_ELEMS * 2];  // 62,720 B
-  __attribute__((aligned(8))) float xin[4 * XIN_H * XIN_W]; // 7,680 B
-  float xf[4 * 176];
+  // zero-padded, mean-free inputs [digit][24][20]: floats (F32 variant) or three bf16 planes hi / mid / lo whose sum is
+  // the float (the A operand of the matrix-core conv1)
+  union {
+    __attribute__((aligned(8))) float xin[4 * XIN_H * XIN_W];  // 7,680 B
+    unsigned short xin3[3][4 * XIN_H * XIN_W];                 // 11,520 B
+  };
   float es[4 * 16];
   float mean[4];
-  // conv1 weights, tap-major, rewritten for every group; dead after layer 1, when the outputs of layer 2
-  // (4 x 120) and of the hidden layer (4 x 176) take their place -- 78.8 KB in all: two workgroups per CU
-  __attribute__((aligned(8))) float c1w[25 * 50];
+  // the raw inputs, until the mean is subtracted; then (F32 variant only) the conv1 weights, tap-major, rewritten for
+  // every group; after layer 1 the outputs of layer 2 (4 x 120) and of the hidden layer (4 x 176) -- 78 KB in all: two
+  // workgroups per CU
+  union {
+    float xf[4 * 176];
+    __attribute__((aligned(8))) float c1w[25 * 50];
+  };
   short hdr[DMZ_HIP_EXPIRY_MAX_GROUPS][16];
   int n_groups;
 };
@@ -848,10 +856,6 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   unsigned short *const l1l = l1h + L1_BF16_ELEMS;                         // ... and remainders
   float *const l2 = S.c1w, *const l3 = S.c1w + 4 * 120;                    // after layer 1
   if (DMZ_XCAT_STOP == 1) return;
-  for (int i = tid; i < 1250; i += XC_THREADS) {
-    const int k = i / 25, t = i - k * 25;
-    S.c1w[t * 50 + k] = xm[dmzw::X_C1W + i];
-  }
   // modelc_bf4dd6c8.cpp:13459: subtract the mean (sequential 176-term sum)
   if (tid < nd) {
     const float *x = S.xf + tid * 176;
@@ -862,19 +866,108 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   __syncthreads();
   for (int i = tid; i < nd * 176; i += XC_THREADS) {
     const int d = i / 176, p = i - d * 176, r = p / 11, c = p - r * 11;
-    S.xin[d * XIN_H * XIN_W + (r + 4) * XIN_W + (c + 4)] = S.xf[i] - S.mean[d];
-  }
-  __syncthreads();
-  if (MODE != DMZ_HIP_EXPIRY_CONV_F32) {
-    // maps 50..55 of every position multiply zero weights, but must be finite: clear them (the partial
-    // sums of the previous group lay over this buffer)
-    for (int i = tid; i < 4 * 70 * 3; i += XC_THREADS) {
-      const int pos = i / 3, q = i - 3 * pos;
-      *(uint32_t *)(l1h + pos * C2_MP + 50 + 2 * q) = 0u;
-      *(uint32_t *)(l1l + pos * C2_MP + 50 + 2 * q) = 0u;
+    const float v = S.xf[i] - S.mean[d];
+    const int at = d * XIN_H * XIN_W + (r + 4) * XIN_W + (c + 4);
+    if (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
+      S.xin[at] = v;
+    } else {
+      // v = hi + mid + lo exactly (three bf16 numbers: 24 bits of mantissa)
+      const __bf16 hi = (__bf16)v;
+      const float r1 = v - (float)hi;
+      const __bf16 mid = (__bf16)r1;
+      const __bf16 lo = (__bf16)(r1 - (float)mid);
+      S.xin3[0][at] = __builtin_bit_cast(unsigned short, hi);
+      S.xin3[1][at] = __builtin_bit_cast(unsigned short, mid);
+      S.xin3[2][at] = __builtin_bit_cast(unsigned short, lo);
     }
   }
-  // layer 1: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU.
+  __syncthreads();
+  if constexpr (MODE != DMZ_HIP_EXPIRY_CONV_F32) {
+    // layer 1 on the matrix cores: the "full" 5x5 correlation (20 x 14), pool 2x2 -> 10 x 7, + bias, ReLU as
+    // out[p][n] = sum_k patch[p][k] W[k][n], p = pre-pool position, k = tap (25 -> 32), n = map (50 -> 64), on
+    // v_mfma_f32_16x16x32_bf16 with both operands split in three bf16 parts and the six products that carry 2^-24 kept
+    // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid): the fp32 convolution to rounding, at half the time of the
+    // packed-FMA form (below, F32 variant).  A tile's sixteen rows are four pool windows x their four positions, so the
+    // four accumulator elements of a lane ARE a pool window: max, bias, ReLU, hi/lo split for conv2, one store pair.
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    bf16x8 wb[3][4];
+    {
+      const bf16x8 *bsrc = (const bf16x8 *)(xw + dmzx::CONV1_B3) + lane;
+#pragma unroll
+      for (int part = 0; part < 3; part++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wb[part][nt] = bsrc[(part * 4 + nt) * 64];
+    }
+    float bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) bias[nt] = 16 * nt + m16 < 50 ? xm[dmzw::X_C1B + 16 * nt + m16] : 0.0f;
+    int toff[8];  // element offset of tap k = 8 kk + e inside the padded input (taps >= 25 meet zero weights)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int k = 8 * kk + e, ti = (k * 205) >> 10;  // k / 5 for k < 32
+      toff[e] = k < 25 ? ti * XIN_W + (k - 5 * ti) : 0;
+    }
+    typedef const volatile __attribute__((address_space(3))) unsigned short *lds_vu16;  // (keeps the reads 16-bit)
+    const int nwin = nd * 70;
+    for (int t = wave; 4 * t < nwin; t += XC_THREADS / 64) {
+      int W = 4 * t + (m16 >> 2);
+      W = W < nwin ? W : 0;
+      const int d = (W * 937) >> 16, pos = W - 70 * d;     // W / 70 for W < 280
+      const int pr = (pos * 37) >> 8, pc = pos - 7 * pr;   // pos / 7 for pos < 70
+      const int base = d * XIN_H * XIN_W + (2 * pr + ((m16 >> 1) & 1)) * XIN_W + 2 * pc + (m16 & 1);
+      uint32_t a[3][4];
+#pragma unroll
+      for (int part = 0; part < 3; part++) {
+        const lds_vu16 pl = (lds_vu16)S.xin3[part] + base;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) a[part][e2] = (uint32_t)pl[toff[2 * e2]] | ((uint32_t)pl[toff[2 * e2 + 1]] << 16);
+      }
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){a[0][0], a[0][1], a[0][2], a[0][3]});
+      const bf16x8 am = __builtin_bit_cast(bf16x8, (u32x4){a[1][0], a[1][1], a[1][2], a[1][3]});
+      const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){a[2][0], a[2][1], a[2][2], a[2][3]});
+      // no load in flight across the matrix instructions (see the note at the conv2 loop)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[4];
+      // small terms first; the four map tiles are independent chains, interleaved
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wb[0][nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[2][nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wb[1][nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wb[0][nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[1][nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[0][nt], acc[nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // D: column (map) = 16 nt + (lane & 15), rows 4 kk .. 4 kk + 3 = the four positions of pool window 4 t + kk
+      const int Wd = 4 * t + kk;
+      if (Wd < nwin) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+          const int n = 16 * nt + m16;
+          if (n < C2_MP) {  // maps 50 .. 55 multiply zero weights in conv2 but must be finite: written as 0
+            const float mx = fmaxf(fmaxf(acc[nt][0], acc[nt][1]), fmaxf(acc[nt][2], acc[nt][3]));
+            const float v = n < 50 ? fmaxf(mx + bias[nt], 0.0f) : 0.0f;
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            l1h[Wd * C2_MP + n] = __builtin_bit_cast(unsigned short, hi);
+            l1l[Wd * C2_MP + n] = __builtin_bit_cast(unsigned short, lo);
+          }
+        }
+      }
+    }
+  } else {
+  for (int i = tid; i < 1250; i += XC_THREADS) {  // (the raw inputs that shared this buffer are consumed)
+    const int k = i / 25, t = i - k * 25;
+    S.c1w[t * 50 + k] = xm[dmzw::X_C1W + i];
+  }
+  __syncthreads();
+  // layer 1, F32 variant: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU.
   // Work item = (map pair, digit, pooled row): v_pk_fma_f32 carries two maps per instruction;
   // the 6 x 18 input strip of the pooled row sits in registers for its seven outputs.
   for (int idx = tid; idx < 25 * nd * 10; idx += XC_THREADS) {
@@ -918,19 +1011,11 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       f32x2 v = m + bias;
       v.x = v.x > 0.0f ? v.x : 0.0f;
       v.y = v.y > 0.0f ? v.y : 0.0f;
-      if (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
-        o0[pc] = v.x;
-        o1[pc] = v.y;
-      } else {
-        // x = hi + lo + O(2^-16 x): hi = bf16(x), lo = bf16(x - hi); the two maps of the pair are neighbours
-        const bf16x2 hi = __builtin_convertvector(v, bf16x2);
-        const bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), bf16x2);
-        const int e = (d * 70 + pr * 7 + pc) * C2_MP + 2 * kp;
-        *(uint32_t *)(l1h + e) = __builtin_bit_cast(uint32_t, hi);
-        *(uint32_t *)(l1l + e) = __builtin_bit_cast(uint32_t, lo);
-      }
+      o0[pc] = v.x;
+      o1[pc] = v.y;
     }
   }
+  }  // F32 variant
   __syncthreads();
   if (DMZ_XCAT_STOP == 2) return;
   // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU,
@@ -1193,7 +1278,7 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__res
   }
   if (!(flags & DMZ_HIP_FLAG_USABLE)) return;  // scan.cpp:57-59
   if (tid == 0) er->categorised = 1;
-  for (int i = tid; i < 4 * XIN_H * XIN_W; i += XC_THREADS) S.xin[i] = 0.0f;
+  for (int i = tid; i < (int)(sizeof(S.xin3) / 4); i += XC_THREADS) ((uint32_t *)S.xin3)[i] = 0u;  // the zero padding
   __syncthreads();
   const int n_groups = S.n_groups;
   const uint8_t *card = cards + (size_t)f * card_stride;
@@ -1303,7 +1388,7 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_model(const float *__r
   const int tid = threadIdx.x, first = blockIdx.x * 4;
   const int nd = imin(4, n - first);
   if (nd <= 0) return;
-  for (int i = tid; i < 4 * XIN_H * XIN_W; i += XC_THREADS) S.xin[i] = 0.0f;
+  for (int i = tid; i < (int)(sizeof(S.xin3) / 4); i += XC_THREADS) ((uint32_t *)S.xin3)[i] = 0u;  // the zero padding
   for (int i = tid; i < nd * 176; i += XC_THREADS) S.xf[i] = x[(size_t)first * 176 + i];
   __syncthreads();
   expiry_cnn_block<MODE>(wts, xw, S, nd, out + (size_t)first * 10, tid);
