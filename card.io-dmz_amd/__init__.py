@@ -84,7 +84,7 @@ EXPORTS = (
     "dmz_hip_scan_expiry_batch", "dmz_hip_pipeline_expiry_batch",
     "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
     "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
-    "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv",
+    "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv", "dmz_hip_set_two_queues",
 )
 
 
@@ -119,6 +119,7 @@ def load_library():
     lib.dmz_hip_synchronize.argtypes = [vp]
     lib.dmz_hip_set_stream.argtypes = [vp, vp]
     lib.dmz_hip_set_expiry_conv.argtypes = [vp, i]
+    lib.dmz_hip_set_two_queues.argtypes = [vp, i]
     lib.dmz_hip_last_error.argtypes = [vp]
     lib.dmz_hip_last_error.restype = C.c_char_p
     lib.dmz_hip_detect_batch.argtypes = [vp, vp, sz, i, i, i, vp, vp, sz, i, i, i, vp]
@@ -228,6 +229,10 @@ class Context:
     def set_expiry_conv(self, mode):
         """arithmetic of the expiry CNN's conv2: EXPIRY_CONV_F32 / _BF16X3 (default) / _BF16"""
         self._check(self.lib.dmz_hip_set_expiry_conv(self.h, mode))
+
+    def set_two_queues(self, on):
+        """pipeline_expiry: expiry segmentation on a second device queue beside hseg + digits (default on)"""
+        self._check(self.lib.dmz_hip_set_two_queues(self.h, int(on)))
 
     def set_profiling(self, on):
         self._check(self.lib.dmz_hip_set_profiling(self.h, int(on)))

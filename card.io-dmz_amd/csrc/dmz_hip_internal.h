@@ -176,7 +176,7 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* d
                        const DmzExpiryTables *tables, const uint8_t *cards, size_t card_stride, int n,
                        const dmz_hip_frame_result *results, DmzExpiryStage *stage /* n x 3 */,
                        dmz_hip_expiry_result *out, hipEvent_t mid /* recorded between seg and cat, or null */,
-                       int conv_mode /* DMZ_HIP_EXPIRY_CONV_* */);
+                       int conv_mode /* DMZ_HIP_EXPIRY_CONV_* */, int phases = 3 /* 1: stripes + seg, 2: cat */);
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
 void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out,
                              int conv_mode);

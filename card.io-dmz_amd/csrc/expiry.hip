@@ -1412,11 +1412,14 @@ int dmz_configure_expiry(void) {
 
 void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, const DmzExpiryTables *tables,
                        const uint8_t *cards, size_t card_stride, int n, const dmz_hip_frame_result *results,
-                       DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid, int conv_mode) {
-  hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
-  hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
-                     out, stage);
+                       DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid, int conv_mode, int phases) {
+  if (phases & 1) {
+    hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
+    hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
+                       out, stage);
+  }
   if (mid) (void)hipEventRecord(mid, s);
+  if (!(phases & 2)) return;
   const dim3 grid((unsigned)n), block(XC_THREADS);
   const size_t lds = sizeof(CatLds) + DMZ_XCAT_PAD;
   if (conv_mode == DMZ_HIP_EXPIRY_CONV_F32)

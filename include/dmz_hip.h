@@ -185,6 +185,12 @@ int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t
 #define DMZ_HIP_EXPIRY_CONV_BF16 2
 int dmz_hip_set_expiry_conv(dmz_hip_context *ctx, int mode);
 
+/* dmz_hip_pipeline_expiry_batch schedules the expiry segmentation (which depends on the number row only) on a
+ * second device queue beside the digit segmentation / categorisation, and joins the two before the expiry CNN.  Results
+ * are identical either way; enable = 0 keeps everything on the context's stream (the default is 1; profiling
+ * (dmz_hip_set_profiling) always runs on one queue so that the per-stage times add up). */
+int dmz_hip_set_two_queues(dmz_hip_context *ctx, int enable);
+
 /* dmz_hip_pipeline_batch followed by dmz_hip_scan_expiry_batch (scanner_add_frame_with_expiry
  * with scan_expiry = true, scan.cpp:41-86 / BASELINE config 4). */
 int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride,

@@ -72,3 +72,26 @@ def test_only_warped_clears_stale_gate_flags(ctx, pkg):
         ctx.lib.dmz_hip_scan_cards_batch.restype  # noqa: B018 (attribute exists)
         ctx._check(ctx.lib.dmz_hip_scan_cards_batch(ctx.h, cards.ptr, pkg.CARD_BYTES, n, 4, rec.ctypes.data))
     cards.free()
+
+
+def test_two_queue_schedule_gives_the_same_bytes_as_one_queue(ctx, pkg):
+    """dmz_hip_set_two_queues: the expiry segmentation beside hseg + digits on a second device queue, joined before
+    the expiry CNN -- every record, expiry record and card byte equal to the single-queue run."""
+    n = 3072
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 9000, n, y.ptr)
+    outs = []
+    for two in (True, False, True):
+        ctx.set_two_queues(two)
+        res = ctx.alloc(n * 1024)
+        cards = ctx.alloc(n * pkg.CARD_BYTES)
+        exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
+        ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
+        ctx.synchronize()
+        outs.append((res.download(np.uint8).copy(), exp.download(np.uint8).copy(), cards.download(np.uint8).copy()))
+    ctx.set_two_queues(True)
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert np.array_equal(a, b)
+    got = outs[0][0].view(pkg.RESULT_DTYPE)
+    assert (got["flags"] & pkg.FLAG_USABLE).astype(bool).sum() > n // 2  # the batch does exercise the expiry CNN
