@@ -21,13 +21,16 @@ extern "C" const unsigned char dmz_weights_blob_end[];
 
 #define DMZ_PI 3.1415926535897932384626433832795  // CV_PI
 
+constexpr int kMaxChunks = 8;  // pipeline_impl: scan chunks in flight on three queues
+
 struct dmz_hip_context {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  // second queue for the expiry segmentation, which depends on vseg only and runs beside hseg + digits (pipeline_impl)
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // second / third queue for the expiry segmentation (depends on vseg only: runs beside hseg + digits) and the expiry
+  // CNN (pipeline_impl)
+  hipStream_t aux_stream = nullptr, aux2_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_seg[kMaxChunks] = {}, ev_dig[kMaxChunks] = {};
   bool overlap = true;
   std::string err;
 
@@ -474,11 +477,18 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     return DMZ_HIP_ENODEVICE;
   }
   ctx->stream = ctx->own_stream;
-  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    ctx->overlap = false;
+  {
+    bool ok = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < kMaxChunks; i++)
+      ok = hipEventCreateWithFlags(&ctx->ev_seg[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_dig[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      ctx->overlap = false;
+    }
   }
   if (getenv("DMZ_HIP_NO_OVERLAP")) ctx->overlap = false;  // developer switch (A/B timing)
   // weights: blob + the two transposed copies the kernels read coalesced
@@ -640,7 +650,12 @@ void dmz_hip_context_destroy(dmz_hip_context *ctx) {
   if (ctx->d_xtab) (void)hipFree(ctx->d_xtab);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (int i = 0; i < kMaxChunks; i++) {
+    if (ctx->ev_seg[i]) (void)hipEventDestroy(ctx->ev_seg[i]);
+    if (ctx->ev_dig[i]) (void)hipEventDestroy(ctx->ev_dig[i]);
+  }
   if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+  if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -660,7 +675,8 @@ int dmz_hip_set_stream(dmz_hip_context *ctx, void *hip_stream) {
 
 int dmz_hip_set_two_queues(dmz_hip_context *ctx, int enable) {
   if (!ctx) return DMZ_HIP_EINVAL;
-  ctx->overlap = enable != 0 && ctx->aux_stream && ctx->ev_fork && ctx->ev_join;
+  ctx->overlap = enable != 0 && ctx->aux_stream && ctx->aux2_stream && ctx->ev_fork && ctx->ev_join &&
+                 ctx->ev_seg[kMaxChunks - 1] && ctx->ev_dig[kMaxChunks - 1];
   return DMZ_HIP_OK;
 }
 
@@ -810,52 +826,55 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
       dexp = (dmz_hip_expiry_result *)ctx->stage_exp.p;
     }
   }
-  // Two queues outside profiling.  The expiry path of a chunk of frames -- stripes, segmentation (needs the number row
-  // vseg found, nothing of hseg / the digit models), then the expiry CNN (needs the digit models' usable flag) -- runs
-  // on the second queue while the main queue goes on with hseg + digits: the expiry kernels are bound by the latency of their list logic and by the matrix pipe (a third of their
-  // issue slots used), the main-queue kernels by VALU issue, and a CU that holds workgroups of both fills slots either
-  // alone leaves idle.  Measured at 65 536 frames: the hseg + digits | stripes + seg window shrinks from 8.44 to 7.94 ms.
-  // Cutting the batch into chunks so that a chunk's expiry kernels also run beside the NEXT chunk's detect / warp was
-  // measured too (DMZ_HIP_CHUNKS=4): 27.3 vs 26.0 ms per step -- detect and warp live on their occupancy, and the
-  // expiry workgroups' LDS takes it away; hence one chunk.
+  if ((rc = run_detect(ctx, (const uint8_t *)dy, frame_stride, row_stride, nullptr, nullptr, 0, 0, n, dres)))
+    return rc;
+  if ((rc = run_transform(ctx, (const uint8_t *)dy, frame_stride, row_stride, width, height, n,
+                          orientation, options, dres, dcards, card_stride)))
+    return rc;
+  // Three queues outside profiling.  After vseg the scan splits into chains that need each other only at the end:
+  // hseg -> digit models (main queue), expiry stripes -> segmentation (needs the number row vseg found, nothing of hseg /
+  // the digit models; second queue) and the expiry CNN (needs both; third queue).  The expiry kernels are bound by the
+  // latency of their list logic and by the matrix pipe (a third to three quarters of their issue slots used), hseg and
+  // the digit conv by VALU issue, and a CU that holds workgroups of both fills slots either alone leaves idle: the
+  // hseg + digits | stripes + seg window shrinks from 8.44 to 7.94 ms at 65 536 frames.  Cut in chunks (developer
+  // switch), a chunk's expiry CNN would also run beside the next chunk's hseg / digits / segmentation: no gain.  detect
+  // and warp stay whole and alone: they live on their occupancy (a variant that ran expiry kernels beside them: +5 % per step).
   const bool fork = with_expiry && ctx->overlap && !ctx->profiling;
-  int nchunks = 1;
-  if (const char *e = getenv("DMZ_HIP_CHUNKS")) {  // developer switch
-    const int v = atoi(e);
-    if (fork && v >= 1 && v <= 16 && n >= 64 * v) nchunks = v;
-  }
-  if (fork && (rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * 3 * (size_t)n))) return rc;
-  for (int ck = 0; ck < nchunks; ck++) {
-    const int first = (int)((long long)n * ck / nchunks), cn = (int)((long long)n * (ck + 1) / nchunks) - first;
-    const uint8_t *cy = (const uint8_t *)dy + (size_t)first * frame_stride;
-    dmz_hip_frame_result *cres = dres + first;
-    uint8_t *ccards = dcards + (size_t)first * card_stride;
-    if ((rc = run_detect(ctx, cy, frame_stride, row_stride, nullptr, nullptr, 0, 0, cn, cres))) return rc;
-    if ((rc = run_transform(ctx, cy, frame_stride, row_stride, width, height, cn, orientation, options, cres, ccards,
-                            card_stride)))
-      return rc;
-    if (!fork) {
-      if ((rc = run_scan(ctx, ccards, card_stride, cn, 1, cres))) return rc;
-      if (with_expiry && (rc = run_expiry(ctx, ccards, card_stride, cn, cres, dexp + first))) return rc;
-      continue;
+  if (!fork) {
+    if ((rc = run_scan(ctx, dcards, card_stride, n, 1, dres))) return rc;
+    if (with_expiry && (rc = run_expiry(ctx, dcards, card_stride, n, dres, dexp))) return rc;
+  } else {
+    // (measured at 65 536 frames, ms per step: one queue 25.63; three queues, 1 chunk 25.53, 2 chunks 25.52, 4 chunks
+    // 25.96, 8 chunks 26.19 -- the finer the chunks, the more the kernels of one chain thin out each other's occupancy)
+    int nchunks = 1;
+    if (const char *e = getenv("DMZ_HIP_CHUNKS")) {  // developer switch
+      const int v = atoi(e);
+      if (v >= 1 && v <= kMaxChunks && n >= 64 * v) nchunks = v;
     }
-    DmzExpiryStage *cstage = (DmzExpiryStage *)ctx->xstage.p + (size_t)3 * first;
-    dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_hidwt + dmzv::WFRAG, ccards, card_stride, cn, 1, cres);
+    if ((rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * 3 * (size_t)n))) return rc;
+    dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_hidwt + dmzv::WFRAG, dcards, card_stride, n, 1, dres);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-    dmz_launch_expiry(ctx->aux_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
-                      dexp + first, nullptr, ctx->expiry_conv, 1);
-    dmz_launch_hseg(ctx->stream, ccards, card_stride, cn, cres);
-    dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, ccards, card_stride, cn, cres);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_join, 0));
-    dmz_launch_expiry(ctx->aux_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
-                      dexp + first, nullptr, ctx->expiry_conv, 2);
+    for (int ck = 0; ck < nchunks; ck++) {
+      const int first = (int)((long long)n * ck / nchunks), cn = (int)((long long)n * (ck + 1) / nchunks) - first;
+      dmz_hip_frame_result *cres = dres + first;
+      const uint8_t *ccards = dcards + (size_t)first * card_stride;
+      DmzExpiryStage *cstage = (DmzExpiryStage *)ctx->xstage.p + (size_t)3 * first;
+      dmz_launch_expiry(ctx->aux_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
+                        dexp + first, nullptr, ctx->expiry_conv, 1);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_seg[ck], ctx->aux_stream));
+      dmz_launch_hseg(ctx->stream, ccards, card_stride, cn, cres);
+      dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, ccards, card_stride, cn, cres);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_dig[ck], ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_seg[ck], 0));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_dig[ck], 0));
+      dmz_launch_expiry(ctx->aux2_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
+                        dexp + first, nullptr, ctx->expiry_conv, 2);
+    }
     HIP_TRY(ctx, hipGetLastError());
-  }
-  if (fork) {  // the main queue continues after the second queue's last kernel
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->aux_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    // the main queue continues after the third queue's last kernel (which waited for the second's)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux2_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   }
   if (with_expiry) {
     if (!exp_dev)
