@@ -480,6 +480,8 @@ def main():
                                % (world, " + 1.6 KiB expiry" if with_expiry else ""),
                 "gate_pass_rates": gates,
                 "device_ms_per_step": round(dev_ms / args.steps, 3),
+                **({"queues": "timed steps: scan chains forked after vseg on three device queues (dmz_hip_set_two_queues, "
+                              "default); `stages` / `roofline` leg: one queue, per-kernel hipEvents"} if with_expiry else {}),
                 **({"expiry_conv": "bf16x3 (default: bf16 matrix core on split operands, fp32 accumulation)",
                     "expiry_conv_variants": variants} if variants else {}),
             },
