@@ -807,13 +807,18 @@ constexpr int XC_THREADS = 256;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XIN_W = 20, XIN_H = 24;  // zero-padded input: 4 rows/cols of padding before, 4/5 after
 constexpr int C2_KSTEPS = dmzx::C2_KSTEPS, C2_MP = dmzx::C2_MAPS_PAD;  // conv2, bf16 variants: see dmz_hip_internal.h
-constexpr int L1_BF16_ELEMS = 4 * 70 * C2_MP;  // [digit][pooled position 10 x 7][map, padded to 56]
+// The CNN runs its two convolutions for XND digits at a time (layer-1 output of two digits: 31 KB instead of 63 KB, which
+// is what lets three workgroups share a CU); the dense layers see all four digits again.
+constexpr int XND = 2;                          // digits per convolution pass
+constexpr int XROWS = 18 * XND;                 // conv2 output rows of a pass (6 x 3 per digit)
+constexpr int XMT = (XROWS + 15) / 16;          // 16-row tiles
+constexpr int L1_BF16_ELEMS = XND * 70 * C2_MP;  // [digit of the pass][pooled position 10 x 7][map, padded to 56]
 struct CatLds {
-  // layer-1 output.  F32 variant: float [digit][map 50][70] (56,000 B).  bf16 variants: the bf16 rounding of the
-  // activations and the bf16 rounding of the remainder, each [digit][position 70][map 56] (2 x 31,360 B), so that
+  // layer-1 output of one pass.  F32 variant: float [digit][map 50][70] (28,000 B).  bf16 variants: the bf16 rounding of the
+  // activations and the bf16 rounding of the remainder, each [digit][position 70][map 56] (2 x 15,680 B), so that
   // the eight k of a matrix-core fragment (eight maps of one tap) are one aligned 16-byte read.  Prep-time
   // scratch and the conv2 partial sums overlay it.
-  __attribute__((aligned(16))) unsigned char l1raw[2 * L1_BF16_ELEMS * 2];  // 62,720 B
+  __attribute__((aligned(16))) unsigned char l1raw[2 * L1_BF16_ELEMS * 2];  // 31,360 B
   // zero-padded, mean-free inputs [digit][24][20]: floats (F32 variant) or three bf16 planes hi / mid / lo whose sum is
   // the float (the A operand of the matrix-core conv1)
   union {
@@ -833,7 +838,8 @@ struct CatLds {
   int n_groups;
 };
 static_assert(4 * 120 + 4 * 176 <= 25 * 50, "l2 + l3 overlay the conv1 weights");
-static_assert(sizeof(CatLds) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(CatLds) <= 163840 / 3, "three workgroups per CU");
+static_assert(4 * XROWS * 40 * 4 <= 2 * L1_BF16_ELEMS * 2, "the conv2 partial sums fit over the layer-1 output");
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -849,12 +855,17 @@ __device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar r
 // xf[nd][176] raw inputs -> scores (global, nd x 10 floats at `out`, row stride 10).  MODE = DMZ_HIP_EXPIRY_CONV_*
 template <int MODE>
 __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, const float *__restrict__ xw, CatLds &S, int nd,
-                                 float *__restrict__ out, int tid) {
+                                 float *__restrict__ out, int tid_in) {
+  int tid = tid_in;
   const float *xm = wts + dmzw::EXPIRY;
   float *const l1f = (float *)S.l1raw;                                     // F32 variant
   unsigned short *const l1h = (unsigned short *)S.l1raw;                   // bf16 variants: high parts ...
   unsigned short *const l1l = l1h + L1_BF16_ELEMS;                         // ... and remainders
-  float *const l2 = S.c1w, *const l3 = S.c1w + 4 * 120;                    // after layer 1
+  // layer-2 output: over the conv1 weights' buffer, which only the F32 variant still needs while the second pass runs
+  // (there: behind the float input planes); hidden layer: over that buffer, after both passes
+  float *const l2 = MODE == DMZ_HIP_EXPIRY_CONV_F32 ? S.xin + 4 * XIN_H * XIN_W : S.c1w;
+  float *const l3 = S.c1w + 4 * 120;
+  static_assert(sizeof(S.xin3) >= sizeof(S.xin) + 4 * 120 * sizeof(float), "F32 variant: l2 behind the float planes");
   if (DMZ_XCAT_STOP == 1) return;
   // modelc_bf4dd6c8.cpp:13459: subtract the mean (sequential 176-term sum)
   if (tid < nd) {
@@ -882,6 +893,17 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     }
   }
   __syncthreads();
+  if constexpr (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
+    for (int i = tid; i < 1250; i += XC_THREADS) {  // (the raw inputs that shared this buffer are consumed)
+      const int k = i / 25, t = i - k * 25;
+      S.c1w[t * 50 + k] = xm[dmzw::X_C1W + i];
+    }
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int d0 = 0; d0 < nd; d0 += XND) {  // ---- the two convolutions, XND digits per pass ----
+  const int ndp = imin(XND, nd - d0);
+  asm volatile("" : "+v"(tid));  // (per pass: keeps the passes' operand fragments and index tables out of the callers' loops)
   if constexpr (MODE != DMZ_HIP_EXPIRY_CONV_F32) {
     // layer 1 on the matrix cores: the "full" 5x5 correlation (20 x 14), pool 2x2 -> 10 x 7, + bias, ReLU as
     // out[p][n] = sum_k patch[p][k] W[k][n], p = pre-pool position, k = tap (25 -> 32), n = map (50 -> 64), on
@@ -908,13 +930,13 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       toff[e] = k < 25 ? ti * XIN_W + (k - 5 * ti) : 0;
     }
     typedef const volatile __attribute__((address_space(3))) unsigned short *lds_vu16;  // (keeps the reads 16-bit)
-    const int nwin = nd * 70;
+    const int nwin = ndp * 70;  // pool windows of this pass: [digit of the pass][10 x 7]
     for (int t = wave; 4 * t < nwin; t += XC_THREADS / 64) {
       int W = 4 * t + (m16 >> 2);
       W = W < nwin ? W : 0;
       const int d = (W * 937) >> 16, pos = W - 70 * d;     // W / 70 for W < 280
       const int pr = (pos * 37) >> 8, pc = pos - 7 * pr;   // pos / 7 for pos < 70
-      const int base = d * XIN_H * XIN_W + (2 * pr + ((m16 >> 1) & 1)) * XIN_W + 2 * pc + (m16 & 1);
+      const int base = (d0 + d) * XIN_H * XIN_W + (2 * pr + ((m16 >> 1) & 1)) * XIN_W + 2 * pc + (m16 & 1);
       uint32_t a[3][4];
 #pragma unroll
       for (int part = 0; part < 3; part++) {
@@ -962,16 +984,11 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       }
     }
   } else {
-  for (int i = tid; i < 1250; i += XC_THREADS) {  // (the raw inputs that shared this buffer are consumed)
-    const int k = i / 25, t = i - k * 25;
-    S.c1w[t * 50 + k] = xm[dmzw::X_C1W + i];
-  }
-  __syncthreads();
   // layer 1, F32 variant: "full" 5x5 correlation (20 x 14 of it), pool 2x2 -> 10 x 7, + bias, ReLU.
   // Work item = (map pair, digit, pooled row): v_pk_fma_f32 carries two maps per instruction;
   // the 6 x 18 input strip of the pooled row sits in registers for its seven outputs.
-  for (int idx = tid; idx < 25 * nd * 10; idx += XC_THREADS) {
-    const int pr = idx / (25 * nd), rem = idx - pr * (25 * nd);
+  for (int idx = tid; idx < 25 * ndp * 10; idx += XC_THREADS) {
+    const int pr = idx / (25 * ndp), rem = idx - pr * (25 * ndp);
     const int d = rem / 25, kp = rem - d * 25;
     f32x2 w[25];
 #pragma unroll
@@ -980,7 +997,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       w[i] = (f32x2){t.x, t.y};
     }
     const f32x2 bias = {xm[dmzw::X_C1B + 2 * kp], xm[dmzw::X_C1B + 2 * kp + 1]};
-    const float *xi = S.xin + d * XIN_H * XIN_W + (2 * pr) * XIN_W;
+    const float *xi = S.xin + (d0 + d) * XIN_H * XIN_W + (2 * pr) * XIN_W;
     float *o0 = l1f + (d * 50 + 2 * kp) * 70 + pr * 7, *o1 = o0 + 70;
 #pragma unroll 1
     for (int pc = 0; pc < 7; pc++) {
@@ -1019,23 +1036,23 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   __syncthreads();
   if (DMZ_XCAT_STOP == 2) return;
   // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU,
-  // as the GEMM  out[p][n] = sum_k patch[p][k] W[k][n]  (p = digit x 18 positions = 72 rows,
-  // n = 40 maps, k = map x 5 x 5 = 1250) on v_mfma_f32_16x16x4_f32: 5 x 3 tiles of 16 x 16, the
+  // as the GEMM  out[p][n] = sum_k patch[p][k] W[k][n]  (p = digit x 18 positions = 36 rows per pass,
+  // n = 40 maps, k = map x 5 x 5 = 1250) on v_mfma_f32_16x16x4_f32: 3 x 3 tiles of 16 x 16, the
   // k range split over the four waves (A gathered from l1, B from the
   // tap-major zero-padded weight copy, prefetched one k-step ahead); the four partial sums meet in
   // LDS (over l1, dead by then) where the 2 x 3 max-pool, bias and ReLU finish the layer.
   {
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
-    f32x4 acc[5][3];
+    f32x4 acc[XMT][3];
 #pragma unroll
-    for (int mt = 0; mt < 5; mt++)
+    for (int mt = 0; mt < XMT; mt++)
 #pragma unroll
       for (int nt = 0; nt < 3; nt++) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
-    int baseA[5];
+    int baseA[XMT];
 #pragma unroll
-    for (int mt = 0; mt < 5; mt++) {
-      const int pp = 16 * mt + m16, pc = pp < 72 ? pp : 0;
+    for (int mt = 0; mt < XMT; mt++) {
+      const int pp = 16 * mt + m16, pc = pp < XROWS ? pp : 0;
       const int d = pc / 18, pos = pc - 18 * d, r = pos / 3, c = pos - 3 * r;
       baseA[mt] = d * 3500 + r * 7 + c;
     }
@@ -1047,7 +1064,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       return k < 1250 ? mp * 70 + i * 7 + (t - 5 * i) : 0;
     };
     // B (global, L2 latency) is fetched one block of four k-steps ahead, A (LDS) one k-step ahead
-    float bnx[4][3], an[5];
+    float bnx[4][3], an[XMT];
 #pragma unroll
     for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -1055,7 +1072,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     {
       const int off = tap_off(4 * ks0 + kk);
 #pragma unroll
-      for (int mt = 0; mt < 5; mt++) an[mt] = l1f[baseA[mt] + off];
+      for (int mt = 0; mt < XMT; mt++) an[mt] = l1f[baseA[mt] + off];
     }
     for (int kb = ks0; kb < ks1; kb += 4) {
       float bc[4][3];
@@ -1070,14 +1087,14 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       for (int u = 0; u < 4; u++) {
         const int ks = kb + u;
         if (ks < ks1) {  // uniform per wave
-          float av[5];
+          float av[XMT];
 #pragma unroll
-          for (int mt = 0; mt < 5; mt++) av[mt] = an[mt];
+          for (int mt = 0; mt < XMT; mt++) av[mt] = an[mt];
           const int off = tap_off(4 * imin(ks + 1, ks1 - 1) + kk);
 #pragma unroll
-          for (int mt = 0; mt < 5; mt++) an[mt] = l1f[baseA[mt] + off];
+          for (int mt = 0; mt < XMT; mt++) an[mt] = l1f[baseA[mt] + off];
 #pragma unroll
-          for (int mt = 0; mt < 5; mt++)
+          for (int mt = 0; mt < XMT; mt++)
 #pragma unroll
             for (int nt = 0; nt < 3; nt++)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bc[u][nt], acc[mt][nt], 0, 0, 0);
@@ -1089,10 +1106,10 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       // k-step: lane (row m16, run kk) of k-step ks holds run R = 4 ks + kk = tap R / 7, maps 8 (R % 7) .. + 7 --
       // one aligned 16-byte LDS read per operand part; B comes fragment-ordered from global memory (L2).
       // BF16X3: a.b ~ al.bh + ah.bl + ah.bh (small terms first), fp32 accumulation.
-      int baseA[5];  // byte offset of (digit, row, column) of the 6 x 3 output grid, tap (0, 0), map 0
+      int baseA[XMT];  // byte offset of (digit, row, column) of the 6 x 3 output grid, tap (0, 0), map 0
 #pragma unroll
-      for (int mt = 0; mt < 5; mt++) {
-        const int pp = 16 * mt + m16, pc = pp < 72 ? pp : 0;
+      for (int mt = 0; mt < XMT; mt++) {
+        const int pp = 16 * mt + m16, pc = pp < XROWS ? pp : 0;
         const int d = pc / 18, pos = pc - 18 * d, r = pos / 3, c = pos - 3 * r;
         baseA[mt] = (d * 70 + r * 7 + c) * C2_MP * 2;
       }
@@ -1119,7 +1136,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       // deterministic in every configuration tried; the other workgroup of the CU hides its bubbles.
 #pragma unroll 1
       for (int ks = ks0; ks < ks0 + kPerWave; ks++) {
-        bf16x8 ah[5], al[5], bh[3], bl[3];
+        bf16x8 ah[XMT], al[XMT], bh[3], bl[3];
         load_b(ks, bh, bl);
         const int R = 4 * ks + kk;
         const int q7 = (R * 9363) >> 16;  // R / 7 for R < 176
@@ -1127,14 +1144,14 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
         const int i5 = (t * 13) >> 6;     // t / 5
         const int offA = ((i5 * 7 + (t - 5 * i5)) * C2_MP + 8 * (R - 7 * q7)) * 2;
 #pragma unroll
-        for (int mt = 0; mt < 5; mt++) {
+        for (int mt = 0; mt < XMT; mt++) {
           ah[mt] = *(const bf16x8 *)(ah_b + baseA[mt] + offA);
           if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) al[mt] = *(const bf16x8 *)(ah_b + L1_BF16_ELEMS * 2 + baseA[mt] + offA);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < 5; mt++)
+        for (int mt = 0; mt < XMT; mt++)
 #pragma unroll
           for (int nt = 0; nt < 3; nt++) {
             if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) {  // small terms first
@@ -1147,32 +1164,33 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       }
     }
     __syncthreads();  // every wave is done with l1
-    float *part = l1f;  // [4 waves][72][40]
+    float *part = l1f;  // [4 waves][XROWS][40]
 #pragma unroll
-    for (int mt = 0; mt < 5; mt++)
+    for (int mt = 0; mt < XMT; mt++)
 #pragma unroll
       for (int nt = 0; nt < 3; nt++)
 #pragma unroll
         for (int v = 0; v < 4; v++) {
           const int pp = 16 * mt + 4 * kk + v, nn = 16 * nt + m16;
-          if (pp < 72 && nn < 40) part[(wave * 72 + pp) * 40 + nn] = acc[mt][nt][v];
+          if (pp < XROWS && nn < 40) part[(wave * XROWS + pp) * 40 + nn] = acc[mt][nt][v];
         }
     __syncthreads();
-    for (int idx = tid; idx < nd * 120; idx += XC_THREADS) {
+    for (int idx = tid; idx < ndp * 120; idx += XC_THREADS) {
       const int d = idx / 120, rem = idx - d * 120, nn = rem / 3, pr = rem - nn * 3;
       float m = 0.0f;
 #pragma unroll
       for (int q = 0; q < 6; q++) {
         const int pp = d * 18 + 6 * pr + q;
-        const float t = (part[(0 * 72 + pp) * 40 + nn] + part[(1 * 72 + pp) * 40 + nn]) +
-                        (part[(2 * 72 + pp) * 40 + nn] + part[(3 * 72 + pp) * 40 + nn]);
+        const float t = (part[(0 * XROWS + pp) * 40 + nn] + part[(1 * XROWS + pp) * 40 + nn]) +
+                        (part[(2 * XROWS + pp) * 40 + nn] + part[(3 * XROWS + pp) * 40 + nn]);
         m = q == 0 ? t : fmaxf(m, t);
       }
       const float v = m + xm[dmzw::X_C2B + nn];
-      l2[idx] = v > 0.0f ? v : 0.0f;
+      l2[d0 * 120 + idx] = v > 0.0f ? v : 0.0f;
     }
   }
-  __syncthreads();
+  __syncthreads();  // (the partial sums over l1 are consumed before the next pass writes l1)
+  }  // pass
   if (DMZ_XCAT_STOP == 3) return;
   // FC 120 -> 176, ReLU and FC 176 -> 10, softmax -- on the matrix core, not for its throughput
   // (four rows of sixteen are real) but because every lane's weight loads are then independent:
@@ -1207,15 +1225,18 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   __syncthreads();
   if (tid < 64) {
     const int m16 = tid & 15, kk = tid >> 4;
-    float a2[44], b2[44];
-#pragma unroll
-    for (int ks = 0; ks < 44; ks++) {
-      a2[ks] = m16 < nd ? l3[m16 * 176 + 4 * ks + kk] : 0.0f;
-      b2[ks] = m16 < 10 ? xm[dmzw::X_LW + m16 * 176 + 4 * ks + kk] : 0.0f;
-    }
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int k0 = 0; k0 < 44; k0 += 22) {  // (two halves: 44 + 44 operand registers at once do not fit three waves per SIMD)
+      float a2[22], b2[22];
 #pragma unroll
-    for (int ks = 0; ks < 44; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ks], b2[ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < 22; ks++) {
+        a2[ks] = m16 < nd ? l3[m16 * 176 + 4 * (k0 + ks) + kk] : 0.0f;
+        b2[ks] = m16 < 10 ? xm[dmzw::X_LW + m16 * 176 + 4 * (k0 + ks) + kk] : 0.0f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 22; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ks], b2[ks], acc, 0, 0, 0);
+    }
     if (kk == 0 && m16 < 10) {
       const float lb = xm[dmzw::X_LB + m16];
 #pragma unroll
@@ -1232,7 +1253,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
+__global__ __launch_bounds__(XC_THREADS, 3) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
                                                            const DmzExpiryTables *__restrict__ tab,
                                                            const uint8_t *__restrict__ cards, size_t card_stride,
                                                            int n, const dmz_hip_frame_result *__restrict__ results,
@@ -1240,7 +1261,7 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__res
                                                            dmz_hip_expiry_result *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   CatLds &S = *(CatLds *)smem_raw;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
   dmz_hip_expiry_result *er = out + f;
   const int n_stripes = er->n_stripes;
@@ -1287,6 +1308,11 @@ __global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_cat(const float *__res
   unsigned char *sm = gp + 4 * 176;                        // 4 x 176 smoothed
   unsigned int *hist = (unsigned int *)(gp + 2 * 4 * 176); // 4 x 256
   for (int g = 0; g < n_groups; g++) {
+    // (the thread index is made opaque per group: hoisted out of this loop, the index arithmetic of all the phases below
+    // is some eighty registers of loop invariants -- more than three waves per SIMD leave)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     // ---- prepare_image_for_cat (expiry_categorize.cpp:35-70): wave d = character d ----
     const int d = wave, ci = d < 2 ? d : d + 1;
     const int left = S.hdr[g][9 + ci], top = S.hdr[g][4 + ci];
@@ -1381,7 +1407,7 @@ __global__ __launch_bounds__(64) void k_slash_model(const float *__restrict__ wt
 
 // applyc_bf4dd6c8 on n inputs, four per workgroup
 template <int MODE>
-__global__ __launch_bounds__(XC_THREADS, 2) void k_expiry_model(const float *__restrict__ wts, const float *__restrict__ xw,
+__global__ __launch_bounds__(XC_THREADS, 3) void k_expiry_model(const float *__restrict__ wts, const float *__restrict__ xw,
                                                              const float *__restrict__ x, int n, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   CatLds &S = *(CatLds *)smem_raw;
