@@ -809,7 +809,10 @@ constexpr int XIN_W = 20, XIN_H = 24;  // zero-padded input: 4 rows/cols of padd
 constexpr int C2_KSTEPS = dmzx::C2_KSTEPS, C2_MP = dmzx::C2_MAPS_PAD;  // conv2, bf16 variants: see dmz_hip_internal.h
 // The CNN runs its two convolutions for XND digits at a time (layer-1 output of two digits: 31 KB instead of 63 KB, which
 // is what lets three workgroups share a CU); the dense layers see all four digits again.
-constexpr int XND = 2;                          // digits per convolution pass
+#ifndef DMZ_XND
+#define DMZ_XND 2
+#endif
+constexpr int XND = DMZ_XND;                          // digits per convolution pass
 constexpr int XROWS = 18 * XND;                 // conv2 output rows of a pass (6 x 3 per digit)
 constexpr int XMT = (XROWS + 15) / 16;          // 16-row tiles
 constexpr int L1_BF16_ELEMS = XND * 70 * C2_MP;  // [digit of the pass][pooled position 10 x 7][map, padded to 56]
@@ -838,7 +841,7 @@ struct CatLds {
   int n_groups;
 };
 static_assert(4 * 120 + 4 * 176 <= 25 * 50, "l2 + l3 overlay the conv1 weights");
-static_assert(sizeof(CatLds) <= 163840 / 3, "three workgroups per CU");
+static_assert(sizeof(CatLds) <= 163840 / (XND == 1 ? 4 : 3), "three (four) workgroups per CU");
 static_assert(4 * XROWS * 40 * 4 <= 2 * L1_BF16_ELEMS * 2, "the conv2 partial sums fit over the layer-1 output");
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1253,7 +1256,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(XC_THREADS, 3) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
+__global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(const float *__restrict__ wts, const float *__restrict__ xw,
                                                            const DmzExpiryTables *__restrict__ tab,
                                                            const uint8_t *__restrict__ cards, size_t card_stride,
                                                            int n, const dmz_hip_frame_result *__restrict__ results,
