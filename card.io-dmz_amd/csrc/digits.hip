@@ -25,6 +25,7 @@
 #include <float.h>
 
 #include "dmz_hip_internal.h"
+#include "dmz_wave.h"
 
 // developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
 #ifndef DMZ_LDS_PAD
@@ -219,11 +220,7 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
     unsigned short *h = hist16 + d * 256;
     const int h0 = h[lane * 4 + 0], h1 = h[lane * 4 + 1], h2 = h[lane * 4 + 2], h3 = h[lane * 4 + 3];
     const int tot = h0 + h1 + h2 + h3;
-    int incl = tot;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
+    const int incl = dmzwave::inclusive_scan_i32(tot);
     const int excl = incl - tot;
     const float scale = 255.f / (19 * 27);
     const int c0 = excl + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;

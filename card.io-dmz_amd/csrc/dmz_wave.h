@@ -41,4 +41,16 @@ __device__ __forceinline__ unsigned long long min_u64(unsigned hi, unsigned lo) 
   return ((unsigned long long)mh << 32) | ml;
 }
 
+// inclusive prefix sum over the 64 lanes: four row_shr steps scan each 16-lane row, row_bcast:15 carries a row's total
+// into the next row (rows 1 and 3), row_bcast:31 the first half's total into rows 2 and 3
+__device__ __forceinline__ int inclusive_scan_i32(int v) {
+  v += DMZ_DPP_SHR0(v, 1);
+  v += DMZ_DPP_SHR0(v, 2);
+  v += DMZ_DPP_SHR0(v, 4);
+  v += DMZ_DPP_SHR0(v, 8);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 }  // namespace dmzwave

@@ -1366,11 +1366,7 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
       unsigned int *h = hist + d * 256;
       const int h0 = (int)h[lane * 4 + 0], h1 = (int)h[lane * 4 + 1], h2 = (int)h[lane * 4 + 2], h3 = (int)h[lane * 4 + 3];
       const int tot = h0 + h1 + h2 + h3;
-      int incl = tot;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-      }
+      const int incl = dmzwave::inclusive_scan_i32(tot);
       const int excl = incl - tot;
       const float scale = 255.f / (TW * TH);
       const int c0 = excl + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
