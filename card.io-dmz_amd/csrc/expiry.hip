@@ -345,29 +345,45 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   __syncthreads();
   XSEG_STOP(1, L.inter[lane])
 
-  // ---- column sums (four columns per lane from dword reads), sliding 9-wide rect sums (456-486) ----
-  for (int d = lane; d < 107; d += 64) {
-    int a[4] = {0, 0, 0, 0}, s2[4], s19[4];
-    uint32_t w0 = *(const uint32_t *)(L.inter + 2 * ISTRIDE + 4 * d);
-    uint32_t w1 = *(const uint32_t *)(L.inter + 3 * ISTRIDE + 4 * d);
+  // ---- column sums (456-486).  colA[c] = sum over window rows k = 3 .. 19 of the Scharr sample v_k (0 outside the ROI),
+  // colB the same over k = 2 .. 18; v_k = 3 inter[k] + 10 inter[k + 1] + 3 inter[k + 2], so both are WEIGHTED SUMS OF THE
+  // INTER ROWS with wave-uniform weights (<= 16) that fold the ROI mask in.  A dword's four columns travel as two packed
+  // pairs of 16-bit fields (even / odd bytes), one v_mad_u32_u24 per pair, row and sum; ten rows per accumulator keep a
+  // field below 2^16 (10 x 16 x 255).  Integer arithmetic throughout: the sums are exact. ----
+  {
+    unsigned ca[24], cb[24];  // uniform (scalar registers)
 #pragma unroll
-    for (int k = 2; k <= 19; k++) {
-      const uint32_t w2 = *(const uint32_t *)(L.inter + (k + 2) * ISTRIDE + 4 * d);
-      const bool ok = (vmask >> k) & 1u;
+    for (int r = 2; r <= 21; r++) {
+      unsigned wa = 0u, wb = 0u;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int v = ok ? 3 * (int)(((w0 >> (8 * q)) & 255u) + ((w2 >> (8 * q)) & 255u)) + 10 * (int)((w1 >> (8 * q)) & 255u) : 0;
-        if (k == 2) s2[q] = v;
-        else a[q] += v;
-        if (k == 19) s19[q] = v;
+      for (int t = 0; t < 3; t++) {  // inter row r is tap t of sample k = r - t (weights 3, 10, 3)
+        const int k = r - t;
+        const unsigned wt = t == 1 ? 10u : 3u, m = (vmask >> (k < 0 ? 0 : k)) & 1u;
+        if (k >= 3 && k <= 19) wa += wt * m;
+        if (k >= 2 && k <= 18) wb += wt * m;
       }
-      w0 = w1;
-      w1 = w2;
+      ca[r] = wa, cb[r] = wb;
     }
+    for (int d = lane; d < 107; d += 64) {
+      uint32_t aE[2] = {0u, 0u}, aO[2] = {0u, 0u}, bE[2] = {0u, 0u}, bO[2] = {0u, 0u};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      L.u.colA[4 * d + q] = a[q];
-      L.colB[4 * d + q] = a[q] + s2[q] - s19[q];
+      for (int r = 2; r <= 21; r++) {
+        const uint32_t w = *(const uint32_t *)(L.inter + r * ISTRIDE + 4 * d);
+        const uint32_t ev = w & 0x00FF00FFu, od = (w >> 8) & 0x00FF00FFu;  // columns (0, 2) and (1, 3) of the dword
+        const int g = r >= 12;
+        aE[g] = __umul24(ev, ca[r]) + aE[g];
+        aO[g] = __umul24(od, ca[r]) + aO[g];
+        bE[g] = __umul24(ev, cb[r]) + bE[g];
+        bO[g] = __umul24(od, cb[r]) + bO[g];
+      }
+      L.u.colA[4 * d + 0] = (int)((aE[0] & 0xffffu) + (aE[1] & 0xffffu));
+      L.u.colA[4 * d + 1] = (int)((aO[0] & 0xffffu) + (aO[1] & 0xffffu));
+      L.u.colA[4 * d + 2] = (int)((aE[0] >> 16) + (aE[1] >> 16));
+      L.u.colA[4 * d + 3] = (int)((aO[0] >> 16) + (aO[1] >> 16));
+      L.colB[4 * d + 0] = (int)((bE[0] & 0xffffu) + (bE[1] & 0xffffu));
+      L.colB[4 * d + 1] = (int)((bO[0] & 0xffffu) + (bO[1] & 0xffffu));
+      L.colB[4 * d + 2] = (int)((bE[0] >> 16) + (bE[1] >> 16));
+      L.colB[4 * d + 3] = (int)((bO[0] >> 16) + (bO[1] >> 16));
     }
   }
   __syncthreads();
