@@ -246,3 +246,22 @@ def test_expiry_on_random_text_cards(ctx, pkg, oracle):
         many += int(want["n_found"] > 1)
     print("random text cards: %d with groups, %d with several" % (found, many))
     assert found >= 8
+
+
+def test_expiry_model_rows_do_not_depend_on_their_position_in_a_workgroup(ctx, pkg):
+    """The CNN runs its convolutions two digits per pass and four inputs per workgroup: an input's scores must be the
+    same bits whether it is evaluated alone, first, last or in the middle of a batch (all three conv variants)."""
+    rng = np.random.default_rng(5)
+    x = (rng.integers(0, 256, (7, 176)) / np.float32(255)).astype(np.float32)
+    try:
+        for mode in (pkg.EXPIRY_CONV_F32, pkg.EXPIRY_CONV_BF16X3, pkg.EXPIRY_CONV_BF16):
+            ctx.set_expiry_conv(mode)
+            whole = ctx.apply_expiry_model(x)
+            for i in range(7):
+                alone = ctx.apply_expiry_model(x[i:i + 1])
+                assert np.array_equal(alone[0].view(np.uint32), whole[i].view(np.uint32)), (mode, i)
+            for n in (2, 3, 5):
+                part = ctx.apply_expiry_model(x[:n])
+                assert np.array_equal(part.view(np.uint32), whole[:n].view(np.uint32)), (mode, n)
+    finally:
+        ctx.set_expiry_conv(pkg.EXPIRY_CONV_BF16X3)
