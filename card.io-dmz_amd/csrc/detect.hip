@@ -686,7 +686,16 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
     for (int e = VERT ? 1 : 0; e < 4; e += 2) {
       DmzBoxParams &bx = q.box[e];
       const int park = (4 * bx.lanes * (kSteps - kRegs) + 15) & ~15, acc = bx.lds_red - bx.lds_acc;
-      const int region = ((park + 2048 > acc ? park + 2048 : acc) + 15) & ~15;
+      int region = ((park + 2048 > acc ? park + 2048 : acc) + 15) & ~15;
+      // the candidate lists take what the workgroups-per-CU count leaves over (busy frames then stay on the list path
+      // instead of the whole-map fallback): the count is the smaller of what LDS and the register budget allow
+      const int tile = bx.lds_map, wps = VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H;
+      int wgs = 163840 / (tile + region + 512);
+      if (wgs > wps * 4 / (kNt / 64)) wgs = wps * 4 / (kNt / 64);
+      if (wgs >= 1) {
+        const int budget = ((163840 / wgs - 1536) & ~15) - tile - 512;  // (1.5 KB short of the limit: the allocation granularity)
+        if (budget > region && budget <= 65536) region = budget;
+      }
       bx.lds_acc = bx.lds_map;
       bx.lds_red = bx.lds_map + region;
       bx.lds_total = bx.lds_red + 512;
