@@ -35,7 +35,7 @@ struct dmz_hip_context {
   std::string err;
 
   float *d_weights = nullptr;  // blob
-  float *d_hidwt = nullptr;    // 16-byte aligned copy of the digit hidden matrices, 3 x [32][320]
+  float *d_hidwt = nullptr;    // the digit hidden matrices in fragment order + the dmzv block (dmz_hip_internal.h)
   float *d_xw = nullptr;       // expiry models re-laid-out for coalesced reads (dmzx:: offsets)
   DmzExpiryTables *d_xtab = nullptr;  // bilateral filter weights
 
@@ -50,6 +50,7 @@ struct dmz_hip_context {
     size_t cap = 0;
   };
   Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc, xstage, stage_exp, stage_sess;
+  Buf patches;  // equalised digit patches between k_digit_patches and k_digits (digits.hip)
 
   int expiry_conv = DMZ_HIP_EXPIRY_CONV_BF16X3;
 
@@ -198,7 +199,9 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
     bp.lds_red = bp.lds_acc + acc_bytes;
     bp.lds_total = bp.lds_red + 512;
     bp.list_cap = acc_bytes / 2;
-    if (bp.lds_total > kDetectMaxLds || bp.nthreads > kDetectMaxThreads || bp.w * bp.h > 65535)
+    // (numrho * kNumAngle < 2^16: the arg-max packs votes and scan position into one 32-bit key; implied by the LDS bound)
+    if (bp.lds_total > kDetectMaxLds || bp.nthreads > kDetectMaxThreads || bp.w * bp.h > 65535 ||
+        bp.numrho * kNumAngle > 65535)
       return fail(ctx, DMZ_HIP_EUNSUPPORTED,
                   "detection box does not fit the LDS-resident detect kernel");
   }
@@ -391,6 +394,16 @@ int run_transform(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_strid
   return DMZ_HIP_OK;
 }
 
+// scratch of the digit stage: zeroed when it grows (its never-written pad entries must be finite bf16 numbers)
+int ensure_patches(dmz_hip_context *ctx, int n) {
+  const size_t need = dmz_digit_patch_bytes() * (size_t)n;
+  if (need <= ctx->patches.cap) return DMZ_HIP_OK;
+  int rc = ensure(ctx, ctx->patches, need);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->patches.p, 0, ctx->patches.cap, ctx->stream));
+  return DMZ_HIP_OK;
+}
+
 int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n, int mode,
              dmz_hip_frame_result *results) {
   {
@@ -406,8 +419,10 @@ int run_scan(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int
     dmz_launch_hseg(ctx->stream, cards, card_stride, n, results);
   }
   {
+    int rc = ensure_patches(ctx, n);
+    if (rc) return rc;
     StageTimer t(ctx, DMZ_HIP_STAGE_DIGITS);
-    dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, cards, card_stride, n, results);
+    dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, cards, card_stride, n, results, ctx->patches.p);
   }
   HIP_TRY(ctx, hipGetLastError());
   return DMZ_HIP_OK;
@@ -499,18 +514,51 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
   }
   const float *w = (const float *)(dmz_weights_blob + 16);
   std::vector<float> hidwt(3 * 320 * 32 + dmzv::WFRAG_FLOATS);
+  // digit hidden matrices in the order k_digits' chunked FC1 loads them (dmz_hip_internal.h)
   for (int m = 0; m < 3; m++)
-    for (int j = 0; j < 32; j++)
-      for (int i = 0; i < 320; i++)
-        hidwt[(size_t)m * 320 * 32 + j * 320 + i] = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + j * 320 + i];
+    for (int pc = 0; pc < 5; pc++)
+      for (int q = 0; q < 4; q++)
+        for (int nt = 0; nt < 2; nt++)
+          for (int lane = 0; lane < 64; lane++)
+            for (int e = 0; e < 4; e++) {
+              const int unit = 16 * nt + (lane & 15), kk = 16 * q + 4 * (lane >> 4) + e;  // kk = map * 8 + pooled row
+              const int k = (kk >> 3) * 40 + (kk & 7) * 5 + pc;
+              hidwt[(((((size_t)m * 5 + pc) * 4 + q) * 2 + nt) * 64 + lane) * 4 + e] =
+                  w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + unit * 320 + k];
+            }
   // vseg hidden layer for v_mfma_f32_16x16x32_bf16 (vseg.hip): W1 / 255 in three bf16 parts, fragment order
   // [wave 4][k-step 7][part 3][lane 64][8]: lane (unit = 16 wave + (lane & 15), run = lane >> 4) of k-step ks
   // holds k = 32 ks + 8 run .. + 7 (zero beyond unit 49 / k 203); and the row sums of W1
   {
-    for (int m = 0; m < 3; m++)
-      for (int i = 0; i < 72; i++)
-        hidwt[dmzv::WFRAG + dmzv::CONVS + m * 72 + i] =
-            w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_CONV_W + i] * (1.0f / 255.0f);
+    // digit conv B fragments (digits.hip): slot s of lane group kg < 3 is tap kSlotTap[parity][s] against bf16 part kg of
+    // weight / 255; group 3 holds the ninth tap (even columns: (2,2) in slots 0, 2, 4; odd columns: (2,0) in slots 1, 3, 5)
+    // against parts hi, mid, lo; everything else is zero
+    {
+      static const int kSlotTap[2][8] = {{0, 1, 3, 4, 6, 7, 2, 5}, {1, 2, 4, 5, 7, 8, 0, 3}};  // tap = ti * 3 + tj
+      uint16_t *cb = (uint16_t *)(hidwt.data() + dmzv::WFRAG + dmzv::DCONV_B);
+      for (int par = 0; par < 2; par++)
+        for (int nt = 0; nt < 2; nt++)
+          for (int lane = 0; lane < 64; lane++)
+            for (int s8 = 0; s8 < 8; s8++) {
+              const int nn = 16 * nt + (lane & 15), kg = lane >> 4;
+              uint16_t v = 0;
+              int tap = -1, part = 0;
+              if (kg < 3) tap = kSlotTap[par][s8], part = kg;
+              else if (s8 < 6 && (s8 & 1) == par) tap = par ? 6 : 8, part = s8 >> 1;
+              if (nn < 24 && tap >= 0) {
+                const float wf = w[dmzw::DIGIT0 + (nn >> 3) * dmzw::DIGIT_STRIDE + dmzw::D_CONV_W + (nn & 7) * 9 + tap] * (1.0f / 255.0f);
+                const uint16_t p0 = bf16_rne(wf);
+                const double r1 = (double)wf - (double)bf16_to_float(p0);
+                const uint16_t p1 = bf16_rne((float)r1);
+                const uint16_t p2 = bf16_rne((float)(r1 - (double)bf16_to_float(p1)));
+                v = part == 0 ? p0 : (part == 1 ? p1 : p2);
+              }
+              cb[(((size_t)par * 2 + nt) * 64 + lane) * 8 + s8] = v;
+            }
+      for (int nn = 0; nn < 32; nn++)
+        hidwt[dmzv::WFRAG + dmzv::DCONV_BIAS + nn] =
+            nn < 24 ? w[dmzw::DIGIT0 + (nn >> 3) * dmzw::DIGIT_STRIDE + dmzw::D_CONV_B + (nn & 7)] : 0.0f;
+    }
     uint16_t *wb = (uint16_t *)(hidwt.data() + dmzv::WFRAG + dmzv::WB3);
     float *rowsum = hidwt.data() + dmzv::WFRAG + dmzv::ROWSUM;
     for (int wv = 0; wv < 4; wv++)
@@ -640,7 +688,7 @@ void dmz_hip_context_destroy(dmz_hip_context *ctx) {
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   dmz_hip_context::Buf *bufs[] = {&ctx->hits, &ctx->mats, &ctx->skip, &ctx->synth, &ctx->stage_in,
                                   &ctx->stage_cb, &ctx->stage_cr, &ctx->stage_cards, &ctx->stage_res,
-                                  &ctx->cards, &ctx->misc, &ctx->xstage, &ctx->stage_exp, &ctx->stage_sess};
+                                  &ctx->cards, &ctx->misc, &ctx->xstage, &ctx->stage_exp, &ctx->stage_sess, &ctx->patches};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
@@ -852,6 +900,7 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
       if (v >= 1 && v <= kMaxChunks && n >= 64 * v) nchunks = v;
     }
     if ((rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * 3 * (size_t)n))) return rc;
+    if ((rc = ensure_patches(ctx, n))) return rc;
     dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_hidwt + dmzv::WFRAG, dcards, card_stride, n, 1, dres);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
@@ -864,7 +913,8 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
                         dexp + first, nullptr, ctx->expiry_conv, 1);
       HIP_TRY(ctx, hipEventRecord(ctx->ev_seg[ck], ctx->aux_stream));
       dmz_launch_hseg(ctx->stream, ccards, card_stride, cn, cres);
-      dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, ccards, card_stride, cn, cres);
+      dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, ccards, card_stride, cn, cres,
+                        (unsigned char *)ctx->patches.p + (size_t)first * dmz_digit_patch_bytes());
       HIP_TRY(ctx, hipEventRecord(ctx->ev_dig[ck], ctx->stream));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_seg[ck], 0));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_dig[ck], 0));

@@ -38,6 +38,7 @@
 // two-walk form (sum pass, NMS pass), which recomputes the gradients instead of
 // parking 44 KB of them per workgroup in LDS (see DMZ_DETECT_SINGLE_H below).
 #include "dmz_hip_internal.h"
+#include "dmz_wave.h"
 
 namespace {
 
@@ -248,7 +249,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   unsigned short *seg = list + wave * seg_cap;
   int ncand = 0;  // wave-uniform
   long long *s_red = (long long *)(lds + bp.lds_red);                    // 16 x 8 B
-  unsigned long long *s_best = (unsigned long long *)(lds + bp.lds_red + 128);  // 16 x 8 B
+  unsigned int *s_best = (unsigned int *)(lds + bp.lds_red + 128);  // 16 x 4 B
   int *s_int = (int *)(lds + bp.lds_red + 256);                          // low, high, ncand, overflow
 
   // ---- A. ROI -> LDS tile in walk space (32-bit global words), replicate 3 lanes ----
@@ -572,30 +573,28 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   static_assert(kNumAngle % 2 == 0, "vote counters are packed in angle pairs");
 
   // ---- F. arg-max with the reference's scan order (hough.cpp:163-176) ----
-  unsigned long long best = 0;
+  // One 32-bit key per cell: votes (< 2^16) above the complement of the scan position (the counters of a box fit 64 KB
+  // of LDS, so there are fewer than 2^16 cells): the maximum key is the first strict maximum of the reference's scan.
+  unsigned int best = 0;
   {
-    for (int p = 0; p < kNumAngle / 2; p++)
+    for (int p = 0; p < kNumAngle / 2; p++) {
+      const unsigned int obase = 0xffffu - (unsigned int)(2 * p);
       for (int rr = tid; rr < numrho; rr += NT) {
         const unsigned int w2 = acc32[p * numrho + rr];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const unsigned int val = k ? w2 >> 16 : w2 & 0xffffu;
-          const unsigned int order = (unsigned int)(rr * kNumAngle + 2 * p + k);  // scan position
-          const unsigned long long key = ((unsigned long long)val << 32) | (0xffffffffu - order);
-          best = key > best ? key : best;
-        }
+        const unsigned int o0 = obase - (unsigned int)(rr * kNumAngle);  // 0xffff - scan position of the low half
+        const unsigned int k0 = (w2 << 16) | o0, k1 = (w2 & 0xffff0000u) | (o0 - 1u);
+        best = k0 > best ? k0 : best;
+        best = k1 > best ? k1 : best;
       }
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_down(best, o, 64);
-    best = other > best ? other : best;
-  }
+  best = dmzwave::max_u32(best);
   if (lane == 0) s_best[wave] = best;
   __syncthreads();
   if (tid == 0) {
     for (int i = 1; i < NT / 64; i++) best = s_best[i] > best ? s_best[i] : best;
-    const int max_val = (int)(best >> 32);
-    const unsigned int order = 0xffffffffu - (unsigned int)(best & 0xffffffffu);
+    const int max_val = (int)(best >> 16);
+    const unsigned int order = 0xffffu - (best & 0xffffu);
     DmzBoxHit hit;
     hit.max_val = max_val;
     hit.found = max_val > bp.threshold;

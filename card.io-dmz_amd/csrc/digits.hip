@@ -8,20 +8,30 @@
 // outputs, 3x3 max-pool, +bias, tanh, FC 320->32 tanh, FC 32->10 softmax) and the
 // (sum - max) / 2 vote.
 //
-// Integer work (gradient, histogram, LUT, labels) is bit-exact.  The CNN arithmetic uses
-// fused multiply-adds, a v_exp_f32-based tanh and the device expf: contract |delta| <= 1e-4
-// on the scores (the reference's own KAT tolerance of 1e-5 is met by the device models).
+// Integer work (gradient, histogram, LUT, labels) is bit-exact.  The CNN arithmetic differs from the
+// reference's float evaluation order (matrix-core accumulation, a v_exp_f32-based tanh, the device
+// expf): contract |delta| <= 1e-4 on the scores (the reference's own KAT tolerance of 1e-5 is met by the
+// device models, tests/test_gpu_stages.py).
 //
-// CDNA4 mapping: one workgroup (4 waves) per card, 37 KB LDS (4 cards per CU).
-//   * equalised digit patches stay u8 in LDS (16 x 513 B); the float input of the CNN is
-//     rebuilt on load (one cvt + one multiply, the reference's own x * (1/255)).
-//   * conv + pool: one thread per (digit, pooled position); the 5x5 patch lives in
-//     registers and is reused by all 8 kernels; two kernels per instruction with
-//     v_pk_fma_f32, conv weights are wave-uniform scalar loads.
-//   * FC 320->32 = [16 digits x 320] x [320 x 32] on v_mfma_f32_16x16x4_f32: wave w owns
-//     output tile (w & 1) and K half (w >> 1), its B operands (10 float4 per lane) come
-//     straight from the row-major weight matrix; A operands are ds_read_b128 from the pooled
-//     activations (row stride 324 floats: conflict-free).
+// CDNA4 mapping (round 3): one workgroup (4 waves) per card, 31 KB of LDS (five cards per CU).
+//   * gradient / histogram / LUT: a wave per digit, 57 lanes x 9 pixels; the gradient bytes stay in
+//     registers, the histogram is wave-private (512 B), the equalised pixel is written ONCE, as the bf16
+//     number the convolution wants (a byte is a bf16 number exactly): xb[digit][27][20].
+//   * the 3x3 convolution of ALL THREE models as one matrix-core product per tile:
+//     v_mfma_f32_16x16x32_bf16 with M = 16 conv positions (2 digits x 8 pooled rows, one conv column and
+//     one (ox, j) offset inside the pool window per tile), N = 2 x 16 >= 24 maps (3 models x 8), and
+//     K = 32 >= 27 = 9 taps x 3 bf16 parts of the weight / 255 (hi + mid + lo = the fp32 weight to 2^-24):
+//     lane group kg = lane >> 4 < 3 holds eight taps against part kg, group 3 the ninth tap against all
+//     three parts.  The eight taps of a lane are three ALIGNED 32-bit LDS reads (horizontal pairs; every
+//     row of a tile has the same conv column, so the pairs' alignment is a compile-time property of the
+//     tile and selects one of two K layouts) and two 16-bit reads -- no conversion, one v_lshl_or to pack.
+//     The max-pool is an elementwise max over the nine tiles of a pool window (v_max3_f32), bias and
+//     tanh run on the accumulators: 8 instead of ~400 VALU instructions per 16 positions x 24 maps.
+//   * FC 320->32 on v_mfma_f32_16x16x4_f32, accumulated per pooled column: the pooled activations of one
+//     column (16 digits x 3 models x 8 maps x 8 rows = 12 KB, XOR-swizzled 16-byte granules) are all
+//     that ever exists in LDS; wave q multiplies K-quarter q of the chunk into its six accumulators
+//     (3 models x 2 tiles of 16 hidden units), the four partial sums meet in LDS at the end.
+//   * hidden tanh, FC 32->10, softmax, vote, arg-max and the usable gate as before.
 #include <float.h>
 
 #include "dmz_hip_internal.h"
@@ -34,8 +44,10 @@
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -46,9 +58,25 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 #endif
 #define DG_STOP(k, expr) if (DMZ_DIGITS_STOP == (k)) { if (tid == 0) res->number_score = (float)(expr); return; }
 
+// developer probe: -DDMZ_DG_TIMING makes thread 0 leave the cycle counter at the phase boundaries in scores[15][..]
+#ifdef DMZ_DG_TIMING
+__device__ long long g_dg_t[16];
+#define DG_T(i) if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_dg_t[i] = clock64();
+#else
+#define DG_T(i)
+#endif
 constexpr int DG_THREADS = 256;
-constexpr int DG_ESTRIDE = 528;  // bytes per equalised digit patch (513 used)
-constexpr int DG_PSTRIDE = 324;  // floats per pooled row (320 used)
+constexpr int XS = 20;                 // xb row stride in elements (19 used; even: horizontal pairs stay dword-aligned)
+constexpr int XD = 27 * XS;            // elements per digit
+constexpr int XPLANE = 16 * XD * 2;    // bytes of one bf16 plane of the 16 digits: 17,280
+constexpr int CHUNK_BYTES = 3 * 16 * 64 * 4;  // pooled activations of one pooled column: [model][digit][map 8 x row 8]
+constexpr int PART_BYTES = 4 * 3 * 16 * 32 * 4;  // FC1 partial sums of the four waves
+constexpr int HID_BYTES = 3 * 16 * 32 * 4;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. every
+// barrier would wait for weight fragments requested ahead of their use and for result stores already on their way;
+// the kernels below exchange data between waves through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32: |error| ~ 2e-7 absolute
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -56,244 +84,413 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-// conv 3x3 valid -> 3x3 max pool -> + bias -> tanh for one pooled position; the 8 kernels
-// share the 5x5 input patch, two kernels per v_pk_fma_f32.
-// cw: the 8 x 9 conv weights (k_digits: pre-multiplied by 1/255, the input patch holds the raw byte values)
-__device__ __forceinline__ void digit_conv_pool(const float (&in)[5][5], const float *__restrict__ mw,
-                                                const float *__restrict__ cw, int pos, float *__restrict__ pooled /* row */) {
-#ifndef DMZ_DIGITS_CONV_UNROLL
-#define DMZ_DIGITS_CONV_UNROLL 2
-#endif
-#pragma unroll DMZ_DIGITS_CONV_UNROLL
-  for (int k = 0; k < 8; k += 2) {
-    f32x2 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const f32x2 w2 = {cw[k * 9 + t], cw[(k + 1) * 9 + t]};
-      const int ti = t / 3, tj = t - 3 * (t / 3);
-#pragma unroll
-      for (int oy = 0; oy < 3; oy++)
-#pragma unroll
-        for (int ox = 0; ox < 3; ox++) {
-          const f32x2 x2 = {in[oy + ti][ox + tj], in[oy + ti][ox + tj]};
-          // (the first tap starts the sum: no zero-initialised accumulators)
-          acc[oy * 3 + ox] = t == 0 ? w2 * x2 : __builtin_elementwise_fma(w2, x2, acc[oy * 3 + ox]);
-        }
-    }
-    f32x2 m = acc[0];
-#pragma unroll
-    for (int o = 1; o < 9; o++) m = __builtin_elementwise_max(m, acc[o]);
-    pooled[k * 40 + pos] = fast_tanh(m.x + mw[dmzw::D_CONV_B + k]);
-    pooled[(k + 1) * 40 + pos] = fast_tanh(m.y + mw[dmzw::D_CONV_B + k + 1]);
-  }
-}
-
-// FC 320 -> 32 for 16 rows of `pooled` on the matrix core; part[khalf][row][32].
-// The B operands (this wave's 16 hidden units x its K half) are fetched early by the caller
-// so that the L2 latency hides behind the convolution.
-struct Fc1B {
-  f32x4 b[10];
+// Lane state of the convolution: byte addresses (LDS) of this lane's reads for row-tile 0, before the
+// tile's compile-time offset.  PAR = parity of the tile's conv column c = 3 pc + ox.
+//   even c, kg < 3: pairs (R + 0/1/2, c .. c+1), singles (R + 0/1, c+2);   kg = 3: the pair (R+2, c+2 .. c+3) three times
+//   odd c,  kg < 3: pairs (R + 0/1/2, c+1 .. c+2), singles (R + 0/1, c);   kg = 3: the pair (R+2, c-1 .. c) three times
+struct ConvLane {
+  const lds_u8 *p[2][3];  // [parity][pair read]
+  const lds_u8 *s[2];     // [parity] first single (the second is one row below)
 };
 
-__device__ __forceinline__ void digit_fc1_load(const float *__restrict__ hw /* [32][320], 16-B aligned */,
-                                               int wave, int lane, Fc1B &w) {
-  const int nt = wave & 1, kh = wave >> 1;
-  const int ii = lane & 15, kk = lane >> 4;
-  const float *bp = hw + (nt * 16 + ii) * 320 + kh * 160 + 4 * kk;
+__device__ __forceinline__ void conv_lane_init(ConvLane &cl, const lds_u8 *xb, int wave, int lane) {
+  const int i = lane & 15, kg = lane >> 4;
+  const int dd = i >> 3, pr = i & 7;
+  const lds_u8 *base = xb + ((4 * wave + dd) * XD + 3 * pr * XS) * 2;
+  const bool k3 = kg == 3;
 #pragma unroll
-  for (int u = 0; u < 10; u++) w.b[u] = *(const f32x4 *)(bp + 16 * u);
+  for (int r = 0; r < 3; r++) {
+    cl.p[0][r] = base + (k3 ? (2 * XS + 2) * 2 : r * XS * 2);
+    cl.p[1][r] = base + (k3 ? (2 * XS - 1) * 2 : (r * XS + 1) * 2);
+  }
+  cl.s[0] = base + (k3 ? 0 : 4);
+  cl.s[1] = base;
 }
 
-__device__ __forceinline__ void digit_fc1(const Fc1B &w, const float *__restrict__ pooled,
-                                          float *__restrict__ part, int wave, int lane) {
-  const int nt = wave & 1, kh = wave >> 1;
-  const int ii = lane & 15, kk = lane >> 4;
-  const float *ap = pooled + ii * DG_PSTRIDE + kh * 160 + 4 * kk;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+// One tile: D[16 positions][2 x 16 maps] for the conv positions (row 3 pr + J, column C) of row-tile T.
+// NPL input planes (1: bytes as bf16; 3: hi / mid / lo planes of a float input, smallest first).
+template <int NPL, int T, int C, int J>
+__device__ __forceinline__ void conv_tile(const ConvLane &cl, const bf16x8 (&bw)[2][2], f32x4 &o0, f32x4 &o1) {
+  constexpr int PAR = C & 1;
+  // (the parity's own +1 / +2 / -1 column shifts are in the lane addresses)
+  constexpr int IMM = (T * 2 * XD + J * XS + C) * 2;
+  o0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  o1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < 10; u += 2) {
-    const f32x4 b0 = w.b[u], b1 = w.b[u + 1];
-    const f32x4 a0 = *(const f32x4 *)(ap + 16 * u), a1 = *(const f32x4 *)(ap + 16 * u + 16);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+  for (int pl = NPL - 1; pl >= 0; pl--) {
+    const int off = IMM + pl * XPLANE;
+    u32x4 a;
+    a.x = *(const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][0] + off);
+    a.y = *(const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][1] + off);
+    a.z = *(const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][2] + off);
+    const uint32_t t0 = *(const __attribute__((address_space(3))) unsigned short *)(cl.s[PAR] + off);
+    const uint32_t t1 = *(const __attribute__((address_space(3))) unsigned short *)(cl.s[PAR] + off + XS * 2);
+    a.w = (t1 << 16) | t0;
+    const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+    o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[PAR][0], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[PAR][1], o1, 0, 0, 0);
   }
-  // D: column (hidden unit) = lane & 15, row (digit) = 4 * (lane >> 4) + v
-  __syncthreads();  // `part` lies over the pooled activations the other waves may still be reading
-#pragma unroll
-  for (int v = 0; v < 4; v++) part[(kh * 16 + 4 * kk + v) * 32 + nt * 16 + ii] = acc0[v] + acc1[v];
 }
 
-// hidden tanh, logistic layer, exp, softmax for `nd` rows (all 256 threads call this)
-__device__ __forceinline__ void digit_head(const float *__restrict__ mw, const float *__restrict__ part,
-                                           float *__restrict__ hid, float *__restrict__ prob /* [16][10] */,
-                                           int nd, int tid) {
-  for (int i = tid; i < 16 * 32; i += DG_THREADS) {
-    const int j = i & 31;
-    hid[i] = fast_tanh((part[i] + part[512 + i]) + mw[dmzw::D_HID_B + j]);
+__device__ __forceinline__ f32x4 max3v(f32x4 a, f32x4 b, f32x4 c) {
+  f32x4 r;
+#pragma unroll
+  for (int v = 0; v < 4; v++) r[v] = __builtin_fmaxf(__builtin_fmaxf(a[v], b[v]), c[v]);
+  return r;
+}
+
+// the nine tiles of the pool windows of pooled column PC, row-tile T: elementwise max
+template <int NPL, int T, int PC>
+__device__ __forceinline__ void conv_pool_column(const ConvLane &cl, const bf16x8 (&bw)[2][2], f32x4 &m0, f32x4 &m1) {
+  f32x4 a0, a1, b0, b1;
+  conv_tile<NPL, T, 3 * PC + 0, 0>(cl, bw, m0, m1);
+  conv_tile<NPL, T, 3 * PC + 1, 0>(cl, bw, a0, a1);
+  conv_tile<NPL, T, 3 * PC + 2, 0>(cl, bw, b0, b1);
+  m0 = max3v(m0, a0, b0), m1 = max3v(m1, a1, b1);
+  conv_tile<NPL, T, 3 * PC + 0, 1>(cl, bw, a0, a1);
+  conv_tile<NPL, T, 3 * PC + 1, 1>(cl, bw, b0, b1);
+  m0 = max3v(m0, a0, b0), m1 = max3v(m1, a1, b1);
+  conv_tile<NPL, T, 3 * PC + 2, 1>(cl, bw, a0, a1);
+  conv_tile<NPL, T, 3 * PC + 0, 2>(cl, bw, b0, b1);
+  m0 = max3v(m0, a0, b0), m1 = max3v(m1, a1, b1);
+  conv_tile<NPL, T, 3 * PC + 1, 2>(cl, bw, a0, a1);
+  conv_tile<NPL, T, 3 * PC + 2, 2>(cl, bw, b0, b1);
+  m0 = max3v(m0, a0, b0), m1 = max3v(m1, a1, b1);
+}
+
+// The three CNNs for the 16 digit patches in xb (NPL bf16 planes): prob[model][digit][10] at the start of `raw`.
+// `raw` is the workgroup's whole LDS block: xb planes first, then the chunk region; the FC1 partial sums,
+// the hidden activations and finally the probabilities overlay it from offset 0 once the convolutions are done.
+// All 256 threads call this; it starts and ends with a barrier of its own.
+// conv weights of a lane: B fragments [parity][n-tile], biases of its two maps (pre-multiplied: see the epilogue)
+constexpr float kTanhK = 2.8853900817779268f;  // 2 log2(e)
+struct ConvWeights {
+  bf16x8 bw[2][2];
+  float bias0, bias1;
+};
+__device__ __forceinline__ void conv_weights_load(ConvWeights &cw, const float *__restrict__ hidw, int lane) {
+  const u32x4 *bf = (const u32x4 *)(hidw + dmzv::WFRAG + dmzv::DCONV_B);
+#pragma unroll
+  for (int par = 0; par < 2; par++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) cw.bw[par][nt] = __builtin_bit_cast(bf16x8, bf[(par * 2 + nt) * 64 + lane]);
+  // tanh(m + b) = 1 - 2 / (exp2(k m + k b) + 1), k = 2 log2(e): the bias enters the exponent's fma
+  cw.bias0 = kTanhK * hidw[dmzv::WFRAG + dmzv::DCONV_BIAS + (lane & 15)];
+  cw.bias1 = kTanhK * hidw[dmzv::WFRAG + dmzv::DCONV_BIAS + 16 + (lane & 15)];
+}
+
+template <int NPL>
+__device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const float *__restrict__ hidw, const ConvWeights &cw,
+                                           unsigned char *raw, int nd, int tid) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const lds_u8 *xb = (const lds_u8 *)raw;
+  float *chunk = (float *)(raw + NPL * XPLANE);
+  const bf16x8 (&bw)[2][2] = cw.bw;
+  const float bias0 = cw.bias0, bias1 = cw.bias1;
+  ConvLane cl;
+  conv_lane_init(cl, xb, wave, lane);
+  // epilogue: this lane's four pooled rows 4 (g & 1) .. + 3 of digit 4 wave + 2 T + (g >> 1), map lane & 15 of n-tile
+  // nt -> one 16-byte granule of chunk[model][digit][map * 8 + row], granule index XORed with the digit
+  const int n16 = lane & 15, g = lane >> 4;
+  int cst[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int n = 16 * nt + n16, m = n >> 3, map = n & 7, digit = 4 * wave + 2 * t + (g >> 1);
+      cst[t][nt] = (m * 16 + digit) * 64 + (((map * 2 + (g & 1)) ^ digit) << 2);
+    }
+  const bool st1 = n16 < 8;  // n-tile 1 holds model 2 in its first eight columns, nothing beyond
+  // FC1: wave q = K-quarter q of every chunk; A granule (4 q + kq) ^ digit of row digit = lane & 15
+  f32x4 fc[3][2];
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) fc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fa = n16 * 64 + (((4 * wave + g) ^ n16) << 2);
+  const f32x4 *fcw = (const f32x4 *)hidw + (size_t)wave * 2 * 64 + lane;  // [m][pc][q][nt][lane]
+
+  auto epilogue = [&](int t, const f32x4 &m0, const f32x4 &m1) {
+    f32x4 v0, v1;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      v0[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(m0[v], kTanhK, bias0)) + 1.0f), -2.0f, 1.0f);
+      v1[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(m1[v], kTanhK, bias1)) + 1.0f), -2.0f, 1.0f);
+    }
+    *(f32x4 *)(chunk + cst[t][0]) = v0;
+    if (st1) *(f32x4 *)(chunk + cst[t][1]) = v1;
+  };
+  // B fragments of column pc are requested before the column's convolutions (L2 latency hidden behind them); the chunk
+  // is read into registers between two barriers that sit close together, so that nobody waits for anybody's
+  // matrix instructions: they drain while the wave convolves the next column.
+  f32x4 fb[3][2];
+  auto fc1_fetch = [&](int pc) {
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) fb[m][nt] = fcw[((size_t)(m * 5 + pc) * 4 * 2 + nt) * 64];
+  };
+  auto fc1_chunk = [&]() {
+    f32x4 a[3];
+    lds_barrier();  // the chunk is complete
+#pragma unroll
+    for (int m = 0; m < 3; m++) a[m] = *(const f32x4 *)(chunk + m * 16 * 64 + fa);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_barrier();  // ... and in everybody's registers: the next column may overwrite it
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          fc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][e], fb[m][nt][e], fc[m][nt], 0, 0, 0);
+  };
+  lds_barrier();  // xb is complete, the chunk region (number strip / histograms until now) is free
+  DG_T(3)
+  {
+    f32x4 m0, m1;
+#ifndef DMZ_DG_FETCH  /* developer probe: where the FC1 weight fragments of a column are requested (0 / 1 / 2) */
+#define DMZ_DG_FETCH 2
+#endif
+#define DG_COLUMN(PC)                                   \
+  if (DMZ_DG_FETCH == 0) fc1_fetch(PC);                 \
+  conv_pool_column<NPL, 0, PC>(cl, bw, m0, m1);         \
+  epilogue(0, m0, m1);                                  \
+  if (DMZ_DG_FETCH == 1) fc1_fetch(PC);                 \
+  conv_pool_column<NPL, 1, PC>(cl, bw, m0, m1);         \
+  epilogue(1, m0, m1);                                  \
+  if (DMZ_DIGITS_STOP == 3 && PC == 0) return;          \
+  if (DMZ_DG_FETCH == 2) fc1_fetch(PC);                 \
+  fc1_chunk();                                          \
+  DG_T(4 + PC)
+    DG_COLUMN(0) DG_COLUMN(1) DG_COLUMN(2) DG_COLUMN(3) DG_COLUMN(4)
+#undef DG_COLUMN
   }
-  __syncthreads();
-  if (tid < nd * 10) {
-    const int d = tid / 10, c = tid - d * 10;
+  // ---- the four partial sums -> hidden tanh -> logistic layer -> softmax ----
+  float *part = (float *)raw;                       // [q][m][digit][32]
+  float *hid = (float *)(raw + PART_BYTES);         // [m][digit][32]
+  // D: column (hidden unit) = lane & 15, row (digit) = 4 (lane >> 4) + v
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) part[((wave * 3 + m) * 16 + 4 * g + v) * 32 + 16 * nt + n16] = fc[m][nt][v];
+  lds_barrier();
+  DG_T(9)
+  if (DMZ_DIGITS_STOP == 4) return;
+  for (int i = tid; i < 3 * 16 * 32; i += DG_THREADS) {
+    const int m = i >> 9, j = i & 31;
+    const float s = (part[i] + part[1536 + i]) + (part[2 * 1536 + i] + part[3 * 1536 + i]);
+    hid[i] = fast_tanh(s + wts[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_B + j]);
+  }
+  lds_barrier();
+  DG_T(10)
+  if (DMZ_DIGITS_STOP == 5) return;
+  float *prob = (float *)raw;  // over the partial sums, which are dead now
+  for (int i = tid; i < 3 * 160; i += DG_THREADS) {
+    const int m = i / 160, r = i - m * 160, d = r / 10, c = r - d * 10;
+    const float *mw = wts + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
     float a = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 32; j++) a = fmaf(mw[dmzw::D_LOG_W + c * 32 + j], hid[d * 32 + j], a);
-    prob[d * 10 + c] = expf(a + mw[dmzw::D_LOG_B + c]);
+    for (int j = 0; j < 32; j++) a = fmaf(mw[dmzw::D_LOG_W + c * 32 + j], hid[(m * 16 + d) * 32 + j], a);
+    prob[i] = d < nd ? expf(a + mw[dmzw::D_LOG_B + c]) : 0.0f;
+  }
+  lds_barrier();
+  DG_T(11)
+  if (DMZ_DIGITS_STOP == 6) return;
+  if (tid < 3 * 16) {
+    const int m = tid >> 4, d = tid & 15;
+    if (d < nd) {
+      float *pp = prob + m * 160 + d * 10;
+      // Eigen 10-element redux tree: ((0+1)+(2+(3+4))) + ((5+6)+(7+(8+9)))
+      const float sum = ((pp[0] + pp[1]) + (pp[2] + (pp[3] + pp[4]))) + ((pp[5] + pp[6]) + (pp[7] + (pp[8] + pp[9])));
+      for (int c = 0; c < 10; c++) pp[c] = pp[c] / sum;
+    }
+  }
+  lds_barrier();
+}
+
+constexpr int DG_LDS = XPLANE + CHUNK_BYTES;  // 29,568 B
+static_assert(PART_BYTES + HID_BYTES <= DG_LDS + 2048, "partial sums + hidden activations overlay xb and the chunk");
+
+// k_digit_patches: the equalised digit patches of a card, as bf16 numbers, [16 digits][27][20] (17,280 B per card in a
+// scratch buffer; column 19 and the sixteenth digit of a 15-digit number are never written: whatever finite values they
+// hold meet zero weights / are never read back).  Its own kernel because this phase is short chains of LDS round trips
+// that need nothing but occupancy (64 registers, 19 KB: 32 waves per CU), which the CNN kernel (128 registers) cannot give.
+// (Measured and rejected: the nine pixels of a lane straight from the card with DPP / ds_bpermute neighbours instead of the
+// LDS strip -- 36 byte loads per lane keep the texture path busier than 180 LDS byte reads keep the LDS: 1.9 vs 0.9 ms
+// per 65 536 cards.)
+constexpr int STRIP_BYTES = 11568;     // 27 x 428 = 11,556, padded to 16
+constexpr int HIST_BYTES = 16 * 512;   // one histogram / LUT per digit
+constexpr int DP_LDS = STRIP_BYTES + HIST_BYTES;  // 19,760 B: eight workgroups per CU
+#ifndef DMZ_DP_WGS
+#define DMZ_DP_WGS 8
+#endif
+#ifndef DMZ_DP_STOP  /* developer ablation: k_digit_patches returns after phase k */
+#define DMZ_DP_STOP 99
+#endif
+__global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const uint8_t *__restrict__ cards, size_t card_stride, int n,
+                                                               const dmz_hip_frame_result *__restrict__ results,
+                                                               unsigned short *__restrict__ patches) {
+  __shared__ __attribute__((aligned(16))) unsigned char raw[DP_LDS];
+  unsigned char *strip_l = raw;  // 27 x 428 bytes
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const dmz_hip_frame_result *res = results + f;
+  if (!(res->flags & DMZ_HIP_FLAG_VSEG_OK)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nd = res->n_offsets;
+  const int y_off = res->vseg_y_offset;
+  const int my_off = res->offsets[lane & 15];  // (one load: lane d holds offsets[d])
+  const uint32_t *strip = (const uint32_t *)(cards + (size_t)f * card_stride + (size_t)y_off * DMZ_CARD_WIDTH);
+  unsigned short *xb = patches + (size_t)f * (XPLANE / 2);
+
+  // ---- number strip -> LDS (2889 aligned dwords) ----
+  for (int i = tid; i < 27 * 107; i += DG_THREADS) ((uint32_t *)strip_l)[i] = strip[i];
+  unsigned int *hd = (unsigned int *)(raw + STRIP_BYTES) + wave * (4 * 128);  // 4 x (256 u16 counters, then the LUT)
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *(u32x4 *)(hd + 8 * lane) = z;
+    *(u32x4 *)(hd + 8 * lane + 4) = z;
   }
   __syncthreads();
-  if (tid < nd) {
-    float *pp = prob + tid * 10;
-    // Eigen 10-element redux tree: ((0+1)+(2+(3+4))) + ((5+6)+(7+(8+9)))
-    const float sum = ((pp[0] + pp[1]) + (pp[2] + (pp[3] + pp[4]))) +
-                      ((pp[5] + pp[6]) + (pp[7] + (pp[8] + pp[9])));
-    for (int c = 0; c < 10; c++) pp[c] = pp[c] / sum;
+  if (DMZ_DP_STOP == 1) return;
+  // ---- per digit, a wave each (wave w owns digits 4 w .. 4 w + 3): cross gradient clamped at the 19x27 ROI edge,
+  // histogram, equalisation LUT (stats.cpp:135-151), equalised pixels as bf16.
+  // Lane l < 57 owns column l % 19 of rows l / 19, l / 19 + 3, ...: pixel index p = 57 k + l in step k, so nine steps
+  // cover the 513 pixels with no per-pixel division and the five taps at constant offsets from one address.
+  // The wave's four digits go through every step together (four histograms per wave). ----
+  {
+    const int rr = lane / 19, c = lane - 19 * rr;
+    const int cl = c > 0 ? -1 : 0, cr = c < 18 ? 1 : 0;
+    int gv[4][9];
+#pragma unroll
+    for (int dj = 0; dj < 4; dj++) {
+      const int d = 4 * wave + dj;
+      const int off = __builtin_amdgcn_readlane(my_off, d);
+      if (d < nd && lane < 57) {
+        const unsigned char *px = strip_l + off + rr * DMZ_CARD_WIDTH + c;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          const int r = 3 * k + rr;
+          const unsigned char *q = px + 3 * k * DMZ_CARD_WIDTH;
+          const int nn = q[r > 0 ? -DMZ_CARD_WIDTH : 0], ww = q[cl], cc = q[0], ee = q[cr],
+                    ss = q[r < 26 ? DMZ_CARD_WIDTH : 0];
+          gv[dj][k] = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
+        }
+      }
+    }
+    if (DMZ_DP_STOP == 2) {
+      int acc = 0;
+      for (int dj = 0; dj < 4; dj++)
+        for (int k = 0; k < 9; k++) acc += gv[dj][k];
+      if (acc == 12345678) xb[0] = 1;
+      return;
+    }
+#pragma unroll
+    for (int dj = 0; dj < 4; dj++)
+      if (4 * wave + dj < nd && lane < 57) {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+          atomicAdd(&hd[dj * 128 + (gv[dj][k] >> 1)], 1u << ((gv[dj][k] & 1) * 16));  // counts <= 513: no carry
+      }
+    __builtin_amdgcn_wave_barrier();
+    if (DMZ_DP_STOP == 3) return;
+    uint2 lut[4];
+#pragma unroll
+    for (int dj = 0; dj < 4; dj++) {
+      const uint2 hh = *(const uint2 *)(hd + dj * 128 + 2 * lane);
+      const int h0 = hh.x & 0xffff, h1 = hh.x >> 16, h2 = hh.y & 0xffff, h3 = hh.y >> 16;
+      const int tot = h0 + h1 + h2 + h3;
+      const int incl = dmzwave::inclusive_scan_i32(tot);
+      const int excl = incl - tot;
+      const float scale = 255.f / (19 * 27);
+      const int c0 = excl + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
+      int l0 = __float2int_rn((float)c0 * scale), l1 = __float2int_rn((float)c1 * scale),
+          l2 = __float2int_rn((float)c2 * scale), l3 = __float2int_rn((float)c3 * scale);
+      l0 = imin(255, imax(0, l0)); l1 = imin(255, imax(0, l1));
+      l2 = imin(255, imax(0, l2)); l3 = imin(255, imax(0, l3));
+      if (lane == 0) l0 = 0;  // lut[0] = 0 (stats.cpp:151)
+      // the LUT holds the equalised value as a bf16 number (the upper half of its float)
+      const uint32_t b0 = __float_as_uint((float)l0) >> 16, b1 = __float_as_uint((float)l1) & 0xffff0000u;
+      const uint32_t b2 = __float_as_uint((float)l2) >> 16, b3 = __float_as_uint((float)l3) & 0xffff0000u;
+      lut[dj] = make_uint2(b0 | b1, b2 | b3);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dj = 0; dj < 4; dj++) *(uint2 *)(hd + dj * 128 + 2 * lane) = lut[dj];
+    __builtin_amdgcn_wave_barrier();
+    if (DMZ_DP_STOP == 4) return;
+#pragma unroll
+    for (int dj = 0; dj < 4; dj++)
+      if (4 * wave + dj < nd && lane < 57) {
+        const unsigned short *h16 = (const unsigned short *)(hd + dj * 128);
+        unsigned short *xd = xb + (4 * wave + dj) * XD + rr * XS + c;
+#pragma unroll
+        for (int k = 0; k < 9; k++) xd[3 * k * XS] = h16[gv[dj][k]];
+      }
   }
-  __syncthreads();
 }
 
 #ifndef DMZ_DIGITS_WGS  /* workgroups per CU the register allocation and the LDS layout aim at */
-#define DMZ_DIGITS_WGS 5
+#define DMZ_DIGITS_WGS 4
 #endif
 __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const float *__restrict__ wts,
-                                                        const float *__restrict__ hidw /* 3 x [32][320] */,
-                                                        const uint8_t *__restrict__ cards,
-                                                        size_t card_stride, int n,
+                                                        const float *__restrict__ hidw /* dmzv layout */,
+                                                        const uint32_t *__restrict__ patches, int n,
                                                         dmz_hip_frame_result *__restrict__ results) {
-  __shared__ __attribute__((aligned(16))) float pooled[16 * DG_PSTRIDE];  // 20,736 B; hist overlays it
-  __shared__ __attribute__((aligned(16))) unsigned char eq[16 * DG_ESTRIDE];  // 8,448 B
-  __shared__ float prob[3 * 16 * 10];
-  // the FC1 partial sums and the hidden activations reuse the first 6 KB of `pooled` (rows 0 .. 4, rewritten by
-  // every model's convolution): 31 KB per workgroup, five workgroups per CU
-  float *part = pooled;               // 2 x 16 x 32
-  float *hid = pooled + 2 * 16 * 32;  // 16 x 32
-  // pooled is dead until the first conv: it first holds the 16 histograms (u16 counters,
-  // 8 KB) and the 27 x 428 number strip (11.6 KB)
-  unsigned int *hist32 = (unsigned int *)pooled;                       // 16 x 128 words
-  unsigned short *hist16 = (unsigned short *)pooled;                   // 16 x 256 counters
-  unsigned char *strip_l = (unsigned char *)pooled + 16 * 256 * 2;     // 27 x 428 bytes
-
+  __shared__ __attribute__((aligned(16))) unsigned char raw[DG_LDS + 2048];
   const int f = blockIdx.x;
   if (f >= n) return;
   dmz_hip_frame_result *res = results + f;
+  DG_T(0)
+  // the card's patches (4320 dwords, fixed address: requested before the record says whether they are needed)
+  constexpr int kStage = (XPLANE / 4 + DG_THREADS - 1) / DG_THREADS;  // 17
+  const int tid = threadIdx.x;
+  uint32_t st[kStage];
+  {
+    const uint32_t *src = patches + (size_t)f * (XPLANE / 4);
+#pragma unroll
+    for (int k = 0; k < kStage; k++) st[k] = tid + k * DG_THREADS < XPLANE / 4 ? src[tid + k * DG_THREADS] : 0u;
+  }
+  ConvWeights cw;
+  conv_weights_load(cw, hidw, tid & 63);
   if (!(res->flags & DMZ_HIP_FLAG_VSEG_OK)) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nd = res->n_offsets;
-  const int y_off = res->vseg_y_offset;
-  const uint32_t *strip = (const uint32_t *)(cards + (size_t)f * card_stride + (size_t)y_off * DMZ_CARD_WIDTH);
+#pragma unroll
+  for (int k = 0; k < kStage; k++)
+    if (tid + k * DG_THREADS < XPLANE / 4) ((uint32_t *)raw)[tid + k * DG_THREADS] = st[k];
+  DG_T(1)
+  DG_STOP(2, raw[0] + raw[100])
+  DG_T(2)
 
-  // ---- number strip -> LDS (2889 aligned dwords), histograms cleared ----
-  for (int i = tid; i < 27 * 107; i += DG_THREADS) ((uint32_t *)strip_l)[i] = strip[i];
-  for (int i = tid; i < 16 * 128; i += DG_THREADS) hist32[i] = 0u;
-  __syncthreads();
-  // ---- per digit: cross gradient clamped at the 19x27 ROI edge, histogram ----
-  // A wave per digit; lane l < 57 owns column l % 19 of rows l / 19, l / 19 + 3, ...: pixel index
-  // p = 57 k + l in step k, so nine steps cover the 513 pixels with no per-pixel division and the
-  // five taps at constant offsets from one address.
-  if (lane < 57) {
-    const int rr = lane / 19, c = lane - 19 * rr;
-    const int cl = c > 0 ? -1 : 0, cr = c < 18 ? 1 : 0;
-    for (int d = wave; d < nd; d += DG_THREADS / 64) {
-      const unsigned char *px = strip_l + res->offsets[d] + rr * DMZ_CARD_WIDTH + c;
-      unsigned char *eqd = eq + d * DG_ESTRIDE + lane;
-      unsigned int *hd = hist32 + d * 128;
-#pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const int r = 3 * k + rr;
-        const unsigned char *q = px + 3 * k * DMZ_CARD_WIDTH;
-        const int nn = q[r > 0 ? -DMZ_CARD_WIDTH : 0], ww = q[cl], cc = q[0], ee = q[cr],
-                  ss = q[r < 26 ? DMZ_CARD_WIDTH : 0];
-        const int gv = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
-        eqd[57 * k] = (unsigned char)gv;
-        atomicAdd(&hd[gv >> 1], 1u << ((gv & 1) * 16));  // counts <= 513: no carry
-      }
-    }
-  }
-  __syncthreads();
-  DG_STOP(1, eq[0] + hist32[3])
-  // ---- equalisation LUT (stats.cpp:135-151): one wave per digit, 4 bins per lane ----
-  for (int d = wave; d < nd; d += DG_THREADS / 64) {
-    unsigned short *h = hist16 + d * 256;
-    const int h0 = h[lane * 4 + 0], h1 = h[lane * 4 + 1], h2 = h[lane * 4 + 2], h3 = h[lane * 4 + 3];
-    const int tot = h0 + h1 + h2 + h3;
-    const int incl = dmzwave::inclusive_scan_i32(tot);
-    const int excl = incl - tot;
-    const float scale = 255.f / (19 * 27);
-    const int c0 = excl + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
-    int l0 = __float2int_rn((float)c0 * scale), l1 = __float2int_rn((float)c1 * scale),
-        l2 = __float2int_rn((float)c2 * scale), l3 = __float2int_rn((float)c3 * scale);
-    l0 = imin(255, imax(0, l0)); l1 = imin(255, imax(0, l1));
-    l2 = imin(255, imax(0, l2)); l3 = imin(255, imax(0, l3));
-    if (lane == 0) l0 = 0;  // lut[0] = 0 (stats.cpp:151)
-    h[lane * 4 + 0] = (unsigned short)l0; h[lane * 4 + 1] = (unsigned short)l1;
-    h[lane * 4 + 2] = (unsigned short)l2; h[lane * 4 + 3] = (unsigned short)l3;
-  }
-  __syncthreads();
-  if (lane < 57)
-    for (int d = wave; d < nd; d += DG_THREADS / 64) {
-      unsigned char *eqd = eq + d * DG_ESTRIDE + lane;
-#pragma unroll
-      for (int k = 0; k < 9; k++) eqd[57 * k] = (unsigned char)hist16[d * 256 + eqd[57 * k]];
-    }
-  __syncthreads();
-  DG_STOP(2, eq[0] + eq[512])
-  // rows of unused digits (nd = 15) must be finite for the matrix core
-  for (int i = tid; i < 16 * DG_PSTRIDE; i += DG_THREADS) pooled[i] = 0.0f;
-  __syncthreads();
+  digits_cnn<1>(wts, hidw, cw, raw, nd, tid);
+  if (DMZ_DIGITS_STOP >= 3 && DMZ_DIGITS_STOP <= 7) return;
 
-  // ---- three CNNs ----
-  for (int m = 0; m < 3; m++) {
-    const float *mw = wts + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
-    const float *cws = hidw + dmzv::WFRAG + dmzv::CONVS + m * 72;
-    Fc1B fcb;
-    if (DMZ_DIGITS_WGS < 5) digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);  // early: 40 registers across the conv
-    for (int i = tid; i < nd * 40; i += DG_THREADS) {
-      const int d = i / 40, pos = i - d * 40;
-      const int pr = pos / 5, pc = pos - pr * 5;
-      // single-byte LDS reads (volatile only so that the compiler does not merge them into 16-bit
-      // reads: at odd addresses those stall the LDS pipe -- SQ_LDS_UNALIGNED_STALL)
-      typedef const volatile __attribute__((address_space(3))) unsigned char *lds_vu8;
-      const lds_vu8 xp = (lds_vu8)eq + d * DG_ESTRIDE + (pr * 3) * 19 + pc * 3;
-      float in[5][5];
-#pragma unroll
-      for (int a = 0; a < 5; a++)
-#pragma unroll
-        for (int b = 0; b < 5; b++) in[a][b] = (float)xp[a * 19 + b];  // the x 1/255 of n_categorize.cpp:99 is in cws
-      digit_conv_pool(in, mw, cws, pos, pooled + d * DG_PSTRIDE);
-    }
-    __syncthreads();
-    DG_STOP(3, pooled[0] + pooled[300])
-    if (DMZ_DIGITS_WGS >= 5) digit_fc1_load(hidw + m * 32 * 320, wave, lane, fcb);
-    digit_fc1(fcb, pooled, part, wave, lane);
-    __syncthreads();
-    DG_STOP(4, part[0] + part[600])
-    digit_head(mw, part, hid, prob + m * 160, nd, tid);
-  }
+  DG_T(12)
   // ---- vote (n_categorize.cpp:69-70), arg-max, usable gate (frame.cpp:63-64) ----
-  float *fin = pooled;  // reuse: 160 floats
+  const float *prob = (const float *)raw;
+  float *fin = (float *)raw + 512;  // 160 floats
+  float myv = 0.0f;
   if (tid < 160) {
-    const int d = tid / 10, c = tid - d * 10;
-    float v = 0.0f;
+    const int d = tid / 10;
     if (d < nd) {
       const float r0 = prob[0 * 160 + tid], r1 = prob[1 * 160 + tid], r2 = prob[2 * 160 + tid];
       float mx = r0 > r1 ? r0 : r1;
       mx = mx > r2 ? mx : r2;
-      v = (((r0 + r1) + r2) - mx) / 2.0f;
+      myv = (((r0 + r1) + r2) - mx) / 2.0f;
     }
-    (void)c;
-    fin[tid] = v;
-    (&res->scores[0][0])[tid] = v;
+    fin[tid] = myv;
   }
-  __syncthreads();
-  if (tid < 16) {
+  lds_barrier();
+  if (tid < 160) (&res->scores[0][0])[tid] = myv;  // (after the barrier: nobody waits for the stores)
+  if (tid >= 64 && tid < 80) {  // (a wave of its own: beside the sequential sum below)
+    const int dgt = tid - 64;
     int best = 0;
     for (int c = 1; c < 10; c++)
-      if (fin[tid * 10 + c] > fin[tid * 10 + best]) best = c;
-    res->digits[tid] = (uint8_t)best;
+      if (fin[dgt * 10 + c] > fin[dgt * 10 + best]) best = c;
+    res->digits[dgt] = (uint8_t)best;
   }
   if (tid == 0) {
     float sum = fin[0];
@@ -301,63 +498,70 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
     const float number_score = (float)nd - sum;
     res->number_score = number_score;
     if (number_score < 3.0f) res->flags = res->flags | DMZ_HIP_FLAG_USABLE;
+#ifdef DMZ_DG_TIMING
+    if (f == n / 2) {
+      g_dg_t[13] = clock64();
+      for (int i = 0; i < 13; i++) res->scores[15][i % 10] = 0;  // (keeps the record valid-looking)
+      for (int i = 1; i < 14; i++) (&res->scores[0][0])[i] = (float)(g_dg_t[i] - g_dg_t[0]);
+    }
+#endif
   }
 }
 
-// Stand-alone digit model entry point (KAT): up to 16 float patches per workgroup through
-// the same conv / matrix-core / head code.
+// Stand-alone digit model entry point (KAT): up to 16 float patches per workgroup through the same
+// convolution / pooling / matrix-core / head code.  A float input x is scaled by 255 (the conv weights
+// carry the 1 / 255 of n_categorize.cpp:99) and split into three bf16 planes hi + mid + lo = 255 x
+// exactly; the tile runs once per plane into the same accumulators.
+constexpr int DGM_LDS = 3 * XPLANE + CHUNK_BYTES;
 __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restrict__ wts,
                                                              const float *__restrict__ hidw, int model,
                                                              const float *__restrict__ xin, int n,
                                                              float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float pooled[16 * DG_PSTRIDE];
-  __shared__ float x[16 * 516];
-  __shared__ float part[2 * 16 * 32];
-  __shared__ float hid[16 * 32];
-  __shared__ float prob[16 * 10];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rawm[];
+  const int tid = threadIdx.x;
   const int base = blockIdx.x * 16;
   const int rows = imin(16, n - base);
   if (rows <= 0) return;
-  const float *mw = wts + dmzw::DIGIT0 + model * dmzw::DIGIT_STRIDE;
+  for (int i = tid; i < 3 * XPLANE / 4; i += DG_THREADS) ((uint32_t *)rawm)[i] = 0u;
+  __syncthreads();
   for (int i = tid; i < rows * 513; i += DG_THREADS) {
-    const int d = i / 513, p = i - d * 513;
-    x[d * 516 + p] = xin[(size_t)(base + d) * 513 + p];
+    const int d = i / 513, p = i - d * 513, r = p / 19, c = p - r * 19;
+    const float xs = xin[(size_t)(base + d) * 513 + p] * 255.0f;
+    const uint32_t hi = __float_as_uint(xs) & 0xffff0000u;  // (truncation: the remainders stay exact)
+    const float r1 = xs - __uint_as_float(hi);
+    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+    unsigned short *xe = (unsigned short *)rawm + d * XD + r * XS + c;
+    xe[0] = (unsigned short)(hi >> 16);
+    xe[XPLANE / 2] = (unsigned short)(mid >> 16);
+    xe[XPLANE] = (unsigned short)(lo >> 16);
   }
-  for (int i = tid; i < 16 * DG_PSTRIDE; i += DG_THREADS) pooled[i] = 0.0f;
-  __syncthreads();
-  for (int i = tid; i < rows * 40; i += DG_THREADS) {
-    const int d = i / 40, pos = i - d * 40;
-    const int pr = pos / 5, pc = pos - pr * 5;
-    const float *xp = x + d * 516 + (pr * 3) * 19 + pc * 3;
-    float in[5][5];
-#pragma unroll
-    for (int a = 0; a < 5; a++)
-#pragma unroll
-      for (int b = 0; b < 5; b++) in[a][b] = xp[a * 19 + b];
-    digit_conv_pool(in, mw, mw + dmzw::D_CONV_W, pos, pooled + d * DG_PSTRIDE);
-  }
-  __syncthreads();
-  Fc1B fcb;
-  digit_fc1_load(hidw + model * 32 * 320, wave, lane, fcb);
-  digit_fc1(fcb, pooled, part, wave, lane);
-  __syncthreads();
-  digit_head(mw, part, hid, prob, rows, tid);
-  if (tid < rows * 10) out[(size_t)base * 10 + tid] = prob[tid];
+  ConvWeights cw;
+  conv_weights_load(cw, hidw, tid & 63);
+  digits_cnn<3>(wts, hidw, cw, rawm, rows, tid);
+  if (tid < rows * 10) out[(size_t)base * 10 + tid] = ((const float *)rawm)[model * 160 + tid];
 }
 
 }  // namespace
 
 void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw, const uint8_t *cards,
-                       size_t card_stride, int n, dmz_hip_frame_result *results) {
-  hipLaunchKernelGGL(k_digits, dim3(n), dim3(DG_THREADS), DMZ_LDS_PAD, s, weights, hidw, cards, card_stride, n,
+                       size_t card_stride, int n, dmz_hip_frame_result *results, void *patches) {
+  hipLaunchKernelGGL(k_digit_patches, dim3(n), dim3(DG_THREADS), 0, s, cards, card_stride, n, results,
+                     (unsigned short *)patches);
+  hipLaunchKernelGGL(k_digits, dim3(n), dim3(DG_THREADS), DMZ_LDS_PAD, s, weights, hidw, (const uint32_t *)patches, n,
                      results);
 }
+size_t dmz_digit_patch_bytes(void) { return (size_t)XPLANE; }
 
 void dmz_launch_digit_model(hipStream_t s, const float *weights, const float *hidw, int model,
                             const float *x, int n, float *out) {
-  hipLaunchKernelGGL(k_digit_model, dim3((n + 15) / 16), dim3(DG_THREADS), 0, s, weights, hidw, model, x,
+  hipLaunchKernelGGL(k_digit_model, dim3((n + 15) / 16), dim3(DG_THREADS), DGM_LDS, s, weights, hidw, model, x,
                      n, out);
 }
 
-int dmz_configure_scan(void) { return dmz_configure_vseg(); }
+int dmz_configure_scan(void) {
+  hipError_t e = hipFuncSetAttribute((const void *)k_digit_model, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS);
+  if (e != hipSuccess) return (int)e;
+  return dmz_configure_vseg();
+}

@@ -148,23 +148,32 @@ void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMa
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride);
-// vseg hidden-layer weights in fragment order, appended to the digit hidden-matrix buffer (float offsets)
+// Digit models' hidden matrices in the fragment order of k_digits' chunked FC1 (digits.hip): f32x4
+// [model 3][pooled column 5][K-quarter 4][n-tile 2][lane 64]: lane (unit = 16 nt + (lane & 15), kq = lane >> 4), element e holds
+// W[unit][map * 40 + row * 5 + column] with map * 8 + row = 16 quarter + 4 kq + e -- 3 x 320 x 32 floats, first in the buffer.
+// vseg hidden-layer weights in fragment order, appended to it (float offsets)
 namespace dmzv {
 constexpr int WFRAG = 3 * 320 * 32;                 // offset of this block in the buffer
 // (offsets below are relative to WFRAG)
 constexpr int WB3 = 0;                              // W1 / 255 in three bf16 parts, fragments of v_mfma_f32_16x16x32_bf16:
                                                     // [wave 4][k-step 7][part 3][lane 64][8 bf16]
 constexpr int ROWSUM = 4 * 7 * 3 * 64 * 4;          // sum_k W1[j][k], 64 floats (zero beyond unit 49)
-constexpr int CONVS = ROWSUM + 64;                  // the digit models' conv weights x 1/255 (the input scaling folded in), 3 x 72
-constexpr int WFRAG_FLOATS = CONVS + 3 * 72;
+// the digit models' 3x3 conv weights x 1/255 (the input scaling of n_categorize.cpp:99 folded in) as B fragments of
+// v_mfma_f32_16x16x32_bf16, [column parity 2][n-tile 2][lane 64][8 bf16]: column n = 16 nt + (lane & 15) = model * 8 + map
+// (zero beyond 23), k = 8 (lane >> 4) + slot; the slot -> (tap, bf16 part) tables are in capi.cpp next to digits.hip's
+// description of the two K layouts
+constexpr int DCONV_B = ROWSUM + 64;                // 2 * 2 * 64 * 4 floats
+constexpr int DCONV_BIAS = DCONV_B + 2 * 2 * 64 * 4;  // conv biases by column n (32, zero beyond 23)
+constexpr int WFRAG_FLOATS = DCONV_BIAS + 32;
 }  // namespace dmzv
 void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag /* dmzv layout */, const uint8_t *cards, size_t card_stride,
                      int n, int mode /* DMZ_HIP_SCAN_* */, dmz_hip_frame_result *results);
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results);
-void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw /* 3 x [32][320] */,
+void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw /* fragment-ordered hidden matrices + dmzv block */,
                        const uint8_t *cards, size_t card_stride, int n,
-                       dmz_hip_frame_result *results);
+                       dmz_hip_frame_result *results, void *patches /* n x dmz_digit_patch_bytes() of device scratch, zeroed once */);
+size_t dmz_digit_patch_bytes(void);
 void dmz_launch_vseg_model(hipStream_t s, const float *weights, const float *x, int n, float *out);
 void dmz_launch_digit_model(hipStream_t s, const float *weights, const float *hidwt, int model,
                             const float *x, int n, float *out);

@@ -192,9 +192,12 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   }
 constexpr int IROWS = 23;    // inter rows: image rows base-4 .. base+18 (clamped to the ROI)
 constexpr int ISTRIDE = 428; // bytes per inter row (107 dwords)
+constexpr int XT_PITCH = 20; // bytes per row of a thresholded character tile (19 used)
 struct SegLds {
-  unsigned char inter[IROWS * ISTRIDE];  // 9,844 B
-  int colB[428];                         // column sums over rows base-1 .. base+15 (regrid_group)
+  // (padded to a multiple of 16 bytes: the compiler merges the column sums' stores into ds_write_b128, and a b64 / b128
+  // LDS access off its natural alignment is replayed at 64 cycles per instruction -- SQ_LDS_UNALIGNED_STALL)
+  __attribute__((aligned(16))) unsigned char inter[IROWS * ISTRIDE + 12];  // 9,856 B
+  __attribute__((aligned(16))) int colB[428];                         // column sums over rows base-1 .. base+15 (regrid_group)
   // three tenants, one after the other (a single wave: its LDS operations execute in program order)
   union {
     int colA[428];                       // column sums over rows base .. base+16, until the rect sums are in registers
@@ -204,7 +207,10 @@ struct SegLds {
       short gstart[66];
     } a;
     struct {                             // per group
-      unsigned char tile[3 * 21 * 19 + 3];  // thresholded tiles of optimize_character_rects
+      // thresholded tiles of optimize_character_rects, [slot][row 21][XT_PITCH]: rows start dword-aligned and the row
+      // sums read aligned dwords (the compiler had turned the byte loop into ds_read_u16 at odd addresses: those and the
+      // misaligned b128 above were SQ_LDS_UNALIGNED_STALL = 1.85 x the kernel's active LDS cycles in round 2)
+      __attribute__((aligned(4))) unsigned char tile[3 * 21 * XT_PITCH + 4];
       // 16-bit: positions and widths < 432, sums of at most 21 bytes (the workgroup's LDS decides how
       // many stripes a CU holds, and the kernel is latency-bound)
       short rL[64];                      // their left edges
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           for (int r = 0; r < 21; r++) {
             const int t = norm_thresh(v[r], scale);
             cs += t;
-            if (c < 19) tile[(sl * 21 + r) * 19 + c] = t;
+            if (c < 19) tile[(sl * 21 + r) * XT_PITCH + c] = t;
           }
         }
         L.u.b.cm[sidx] = cs;
@@ -659,8 +665,15 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
             else rc--;
           }
         int rsm = 0;
-        if (sl < 3)  // lane c is row c here
-          for (int cc = lc; cc <= rc; cc++) rsm += tile[(sl * 21 + c) * 19 + cc];
+        if (sl < 3) {  // lane c is row c here: the eleven bytes lc .. lc + 10 (= rc) of its row, from four aligned dwords
+          typedef const volatile __attribute__((address_space(3))) uint32_t *lds_vu32;  // (volatile: no merging into b64 / b128)
+          const lds_vu32 rowp = (lds_vu32)(tile + (sl * 21 + c) * XT_PITCH + (lc & ~3));
+          const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2], w3 = rowp[3];
+          const uint32_t sh = (uint32_t)(lc & 3);
+          rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), 0u, 0u);
+          rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), 0u, (uint32_t)rsm);
+          rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w3, w2, sh) & 0x00FFFFFFu, 0u, (uint32_t)rsm);
+        }
         __syncthreads();
         L.u.b.cm[sidx] = rsm;  // row sums
         __syncthreads();

@@ -98,7 +98,13 @@ __device__ __forceinline__ RowRaw vseg_row_load(const uint8_t *__restrict__ row,
 
 // n_vseg.cpp:39-43 for one row: gradient, down-sample, and the min-max normalisation
 // constants; writes 4 gradient bytes per lane and (scale, shift) of the row.
-__device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned char *__restrict__ grow,
+// Row i of `grad` is stored with bit 4 of the byte offset flipped when i & 8 (vs_swz): the matrix-core A fragments are
+// ds_read_b64 at row * 224 + 8 kk + 32 ks, a half-wave covers 16 rows x 2 kk, and 224 B = 56 banks sends rows r and
+// r + 8 to the same banks (a two-way conflict on every fragment read: SQ_LDS_BANK_CONFLICT was 1.44 x the kernel's
+// active LDS cycles in round 2); with the flip rows 8..15 of a tile use the other half of each 32-byte group.
+__device__ __forceinline__ int vs_swz(int row) { return (row & 8) << 1; }
+
+__device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned char *__restrict__ grow, int swz,
                                                   float *__restrict__ norm /* 2 */, int lane) {
   int b[12];
 #pragma unroll
@@ -127,7 +133,7 @@ __device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned cha
   vmin = 255 - (int)dmzwave::max_u32((unsigned)(255 - vmin));
   vmax = (int)dmzwave::max_u32((unsigned)vmax);
   if (lane < 56)  // lanes 51..55 write the zero k-tail 204..223
-    *(uint32_t *)(grow + 4 * lane) =
+    *(uint32_t *)(grow + ((4 * lane) ^ swz)) =
         lane < 51 ? (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24) : 0u;
   // the row's (min, max) parked as two integers; vseg_row_norms turns them into (scale, shift) for many rows
   // at once (the fp64 division costs ~30 issue slots whether one lane or 64 need it)
@@ -167,7 +173,7 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
 #pragma unroll
     for (int k = 0; k < VS_RIF; k++) {
       const int i = i0 + k * VS_WAVES;
-      if (i < nrows) vseg_row_features(raw[k], grad + i * VS_GSTRIDE, norm + 2 * i, lane);
+      if (i < nrows) vseg_row_features(raw[k], grad + i * VS_GSTRIDE, vs_swz(i), norm + 2 * i, lane);
     }
   }
   vseg_row_norms(norm, nrows, wave, lane);
@@ -196,7 +202,10 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
   const int ii = lane & 15, kk = lane >> 4;
   const unsigned char *ap[NT];
 #pragma unroll
-  for (int t = 0; t < NT; t++) ap[t] = grad + imin(t * 16 + ii, nrows - 1) * VS_GSTRIDE + 8 * kk;
+  for (int t = 0; t < NT; t++) {
+    const int row = imin(t * 16 + ii, nrows - 1);
+    ap[t] = grad + row * VS_GSTRIDE + ((8 * kk) ^ vs_swz(row));
+  }
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -250,8 +259,8 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
 
 // n_vseg.cpp:49-92, called by one wave.  The reference's ring buffer entry read at step y is the
 // score of row y - 26, so the window is fed from the score arrays directly.  The two running
-// sums (visa / amex) are literal float add / subtract chains -- one lane each (even lanes replay
-// the visa chain, odd lanes the amex chain, writing the same values) -- and the reference's
+// sums (visa / amex) are literal float add / subtract chains -- one lane each (lane 0 the visa chain,
+// lane 1 the amex chain) -- and the reference's
 // scan "first strict maximum of v(26), a(26), v(27), a(27), ..." is an arg-max over the 488
 // window sums with ties to the smallest scan position: exact, and parallel over the wave.
 // Scores live in arrays padded to 288; `wsum` is 2 x 256 floats of scratch.
@@ -262,6 +271,9 @@ __device__ __forceinline__ void vseg_best_segmentation(const float *__restrict__
   const float *src = p ? amx : vis;
   float *w = wsum + p * 256;
   float sum = 0.0f;
+  // (lanes 0 and 1 only: 32 lanes storing the same value to one address are serialised by the LDS -- the two scans of a
+  // card were 90 % of the kernel's SQ_LDS_BANK_CONFLICT cycles in round 2)
+  if (lane < 2) {
   // rows 0..25: the window is not full yet
   for (int y0 = 0; y0 < 26; y0 += 13) {
     float v[13];
@@ -284,6 +296,7 @@ __device__ __forceinline__ void vseg_best_segmentation(const float *__restrict__
       if (y0 + k < 270) w[y0 + k - 26] = sum;
       sum = sum - ov[k];
     }
+  }
   }
   __builtin_amdgcn_wave_barrier();
   float best = 0.0f;

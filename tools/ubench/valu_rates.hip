@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256) void k(double *out, double a, double b, int it
       if (OP == 15) n[i] = max(min(n[i], m), it);                                // v_med3_i32
       if (OP == 16) x[i] = (double)(n[i] + it) + x[i];                           // v_cvt_f64_i32 + add
       if (OP == 17) n[i] = __double2loint(x[i] = x[i] + 6755399441055744.0) + n[i];
+      if (OP == 18) f[i] = __builtin_amdgcn_exp2f(f[i]);
+      if (OP == 19) f[i] = __builtin_amdgcn_rcpf(f[i]);
+      if (OP == 20) { typedef float f2 __attribute__((ext_vector_type(2))); f2 v = {f[i], f[(i + 1) & 7]}; const f2 aa = {(float)a, (float)a}, bb = {(float)b, (float)b}; v = __builtin_elementwise_fma(v, aa, bb); f[i] = v.x; f[(i + 1) & 7] = v.y; }
+      if (OP == 21) f[i] = __builtin_fmaxf(__builtin_fmaxf(f[i], (float)a), (float)it);
+      if (OP == 22) f[i] = __builtin_amdgcn_sqrtf(f[i]);
     }
   }
   double s = 0;
@@ -78,5 +83,10 @@ int main() {
   run<15>("v_med3_i32");
   run<16>("cvt_f64_i32 + add_f64");
   run<17>("add_f64 + add_u32");
+  run<18>("v_exp_f32");
+  run<19>("v_rcp_f32");
+  run<20>("v_pk_fma_f32 (per pk instr, 8 per iter)");
+  run<21>("v_max3_f32");
+  run<22>("v_sqrt_f32");
   return 0;
 }
