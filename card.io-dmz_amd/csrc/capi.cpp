@@ -558,6 +558,15 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
       for (int nn = 0; nn < 32; nn++)
         hidwt[dmzv::WFRAG + dmzv::DCONV_BIAS + nn] =
             nn < 24 ? w[dmzw::DIGIT0 + (nn >> 3) * dmzw::DIGIT_STRIDE + dmzw::D_CONV_B + (nn & 7)] : 0.0f;
+      float *dt = hidwt.data() + dmzv::WFRAG + dmzv::DTAIL;  // (zero-initialised: the padding stays zero)
+      for (int m = 0; m < 3; m++) {
+        const float *mw = w + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
+        for (int j = 0; j < 32; j++) dt[dmzv::DT_HB + m * 32 + j] = mw[dmzw::D_HID_B + j];
+        for (int c = 0; c < 10; c++) {
+          for (int j = 0; j < 32; j++) dt[dmzv::DT_LW + (m * 16 + c) * dmzv::DT_PITCH + j] = mw[dmzw::D_LOG_W + c * 32 + j];
+          dt[dmzv::DT_LB + m * 16 + c] = mw[dmzw::D_LOG_B + c];
+        }
+      }
     }
     uint16_t *wb = (uint16_t *)(hidwt.data() + dmzv::WFRAG + dmzv::WB3);
     float *rowsum = hidwt.data() + dmzv::WFRAG + dmzv::ROWSUM;

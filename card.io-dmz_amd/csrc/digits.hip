@@ -71,7 +71,9 @@ constexpr int XD = 27 * XS;            // elements per digit
 constexpr int XPLANE = 16 * XD * 2;    // bytes of one bf16 plane of the 16 digits: 17,280
 constexpr int CHUNK_BYTES = 3 * 16 * 64 * 4;  // pooled activations of one pooled column: [model][digit][map 8 x row 8]
 constexpr int PART_BYTES = 4 * 3 * 16 * 32 * 4;  // FC1 partial sums of the four waves
-constexpr int HID_BYTES = 3 * 16 * 32 * 4;
+constexpr int HID_PITCH = dmzv::DT_PITCH;     // floats per row of the hidden activations / of the logistic weights
+constexpr int DG_RAW = 31616;                 // xb + chunk (29,568 B), partial sums + hidden activations (31,488 B)
+constexpr int DG_TAILW = dmzv::DT_FLOATS * 4; // 7,488 B
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. every
 // barrier would wait for weight fragments requested ahead of their use and for result stores already on their way;
@@ -181,7 +183,7 @@ __device__ __forceinline__ void conv_weights_load(ConvWeights &cw, const float *
 
 template <int NPL>
 __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const float *__restrict__ hidw, const ConvWeights &cw,
-                                           unsigned char *raw, int nd, int tid) {
+                                           unsigned char *raw, const float *tw /* LDS: dmzv::DTAIL block */, int nd, int tid) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const lds_u8 *xb = (const lds_u8 *)raw;
   float *chunk = (float *)(raw + NPL * XPLANE);
@@ -255,7 +257,9 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
 #define DG_COLUMN(PC)                                   \
   if (DMZ_DG_FETCH == 0) fc1_fetch(PC);                 \
   conv_pool_column<NPL, 0, PC>(cl, bw, m0, m1);         \
+  if (PC == 0) { DG_T(14) }                             \
   epilogue(0, m0, m1);                                  \
+  if (PC == 0) { DG_T(15) }                             \
   if (DMZ_DG_FETCH == 1) fc1_fetch(PC);                 \
   conv_pool_column<NPL, 1, PC>(cl, bw, m0, m1);         \
   epilogue(1, m0, m1);                                  \
@@ -263,56 +267,68 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   if (DMZ_DG_FETCH == 2) fc1_fetch(PC);                 \
   fc1_chunk();                                          \
   DG_T(4 + PC)
+#ifdef DMZ_DG_REVERSE  /* developer probe */
+    DG_COLUMN(4) DG_COLUMN(3) DG_COLUMN(2) DG_COLUMN(1) DG_COLUMN(0)
+#else
     DG_COLUMN(0) DG_COLUMN(1) DG_COLUMN(2) DG_COLUMN(3) DG_COLUMN(4)
+#endif
 #undef DG_COLUMN
   }
-  // ---- the four partial sums -> hidden tanh -> logistic layer -> softmax ----
-  float *part = (float *)raw;                       // [q][m][digit][32]
-  float *hid = (float *)(raw + PART_BYTES);         // [m][digit][32]
-  // D: column (hidden unit) = lane & 15, row (digit) = 4 (lane >> 4) + v
+  // ---- the four partial sums -> hidden tanh -> logistic layer (matrix core) -> exp ----
+  // part[q][m][nt][v][lane]: every store and every load below touches 64 consecutive dwords
+  float *part = (float *)raw;
+  float *hid = (float *)(raw + PART_BYTES);  // [m][digit][HID_PITCH]
 #pragma unroll
   for (int m = 0; m < 3; m++)
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-      for (int v = 0; v < 4; v++) part[((wave * 3 + m) * 16 + 4 * g + v) * 32 + 16 * nt + n16] = fc[m][nt][v];
+      for (int v = 0; v < 4; v++) part[((((wave * 3 + m) * 2 + nt) * 4 + v) << 6) + lane] = fc[m][nt][v];
   lds_barrier();
   DG_T(9)
   if (DMZ_DIGITS_STOP == 4) return;
-  for (int i = tid; i < 3 * 16 * 32; i += DG_THREADS) {
-    const int m = i >> 9, j = i & 31;
-    const float s = (part[i] + part[1536 + i]) + (part[2 * 1536 + i] + part[3 * 1536 + i]);
-    hid[i] = fast_tanh(s + wts[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_B + j]);
+#pragma unroll
+  for (int r = 0; r < 6; r++) {  // i = tid + 256 r = ((m * 2 + nt) * 4 + v) * 64 + lane': m = r >> 1, nt = r & 1
+    const int i = tid + DG_THREADS * r;
+    const int m = r >> 1, nt = r & 1, v = (tid >> 6) & 3, digit = 4 * ((tid >> 4) & 3) + v, j = 16 * nt + (tid & 15);
+    const float sum = (part[i] + part[1536 + i]) + (part[2 * 1536 + i] + part[3 * 1536 + i]);
+    hid[(m * 16 + digit) * HID_PITCH + j] = fast_tanh(sum + tw[dmzv::DT_HB + m * 32 + j]);
   }
   lds_barrier();
   DG_T(10)
   if (DMZ_DIGITS_STOP == 5) return;
-  float *prob = (float *)raw;  // over the partial sums, which are dead now
-  for (int i = tid; i < 3 * 160; i += DG_THREADS) {
-    const int m = i / 160, r = i - m * 160, d = r / 10, c = r - d * 10;
-    const float *mw = wts + dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE;
-    float a = 0.0f;
+  // logistic layer of model m on wave m: [16 digits x 32] x [32 x 16 (10 classes)] as eight v_mfma_f32_16x16x4_f32; lane
+  // (row / column lane & 15, kq = lane >> 4) holds k = 8 kq .. + 7 of its row of A and its column of B (two aligned
+  // 16-byte reads each; rows are 36 floats apart: conflict-free)
+  float *prob = (float *)raw;  // exp(logit) [m][digit][16]: over the partial sums, which are dead now
+  if (wave < 3) {
+    const float *ap = hid + (wave * 16 + n16) * HID_PITCH + 8 * g;
+    const float *bp = tw + dmzv::DT_LW + (wave * 16 + n16) * HID_PITCH + 8 * g;
+    const f32x4 a0 = *(const f32x4 *)ap, a1 = *(const f32x4 *)(ap + 4), b0 = *(const f32x4 *)bp, b1 = *(const f32x4 *)(bp + 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 32; j++) a = fmaf(mw[dmzw::D_LOG_W + c * 32 + j], hid[(m * 16 + d) * 32 + j], a);
-    prob[i] = d < nd ? expf(a + mw[dmzw::D_LOG_B + c]) : 0.0f;
+    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc, 0, 0, 0);
+    // D: column (class) = lane & 15, row (digit) = 4 (lane >> 4) + v
+    const float lb = tw[dmzv::DT_LB + wave * 16 + n16];
+#pragma unroll
+    for (int v = 0; v < 4; v++) prob[(wave * 16 + 4 * g + v) * 16 + n16] = expf(acc[v] + lb);
   }
   lds_barrier();
   DG_T(11)
-  if (DMZ_DIGITS_STOP == 6) return;
-  if (tid < 3 * 16) {
-    const int m = tid >> 4, d = tid & 15;
-    if (d < nd) {
-      float *pp = prob + m * 160 + d * 10;
-      // Eigen 10-element redux tree: ((0+1)+(2+(3+4))) + ((5+6)+(7+(8+9)))
-      const float sum = ((pp[0] + pp[1]) + (pp[2] + (pp[3] + pp[4]))) + ((pp[5] + pp[6]) + (pp[7] + (pp[8] + pp[9])));
-      for (int c = 0; c < 10; c++) pp[c] = pp[c] / sum;
-    }
-  }
-  lds_barrier();
+}
+
+// softmax of model m's row d at class c from the exp(logit) table of digits_cnn (Eigen's 10-element redux tree:
+// ((0+1)+(2+(3+4))) + ((5+6)+(7+(8+9))))
+__device__ __forceinline__ float digit_softmax(const float *__restrict__ prob, int m, int d, int c) {
+  const float *pp = prob + (m * 16 + d) * 16;
+  const float sum = ((pp[0] + pp[1]) + (pp[2] + (pp[3] + pp[4]))) + ((pp[5] + pp[6]) + (pp[7] + (pp[8] + pp[9])));
+  return pp[c] / sum;
 }
 
 constexpr int DG_LDS = XPLANE + CHUNK_BYTES;  // 29,568 B
-static_assert(PART_BYTES + HID_BYTES <= DG_LDS + 2048, "partial sums + hidden activations overlay xb and the chunk");
+static_assert(PART_BYTES + 3 * 16 * HID_PITCH * 4 <= DG_RAW && DG_LDS <= DG_RAW, "partial sums + hidden activations overlay xb and the chunk");
 
 // k_digit_patches: the equalised digit patches of a card, as bf16 numbers, [16 digits][27][20] (17,280 B per card in a
 // scratch buffer; column 19 and the sixteenth digit of a 15-digit number are never written: whatever finite values they
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
                                                         const float *__restrict__ hidw /* dmzv layout */,
                                                         const uint32_t *__restrict__ patches, int n,
                                                         dmz_hip_frame_result *__restrict__ results) {
-  __shared__ __attribute__((aligned(16))) unsigned char raw[DG_LDS + 2048];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[DG_RAW + DG_TAILW];
   const int f = blockIdx.x;
   if (f >= n) return;
   dmz_hip_frame_result *res = results + f;
@@ -456,27 +472,32 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
   }
   ConvWeights cw;
   conv_weights_load(cw, hidw, tid & 63);
+  // the tail's weights (hidden biases, logistic layer): LDS, so that the short serial steps at the end wait for no L2
+  const f32x4 *twsrc = (const f32x4 *)(hidw + dmzv::WFRAG + dmzv::DTAIL);
+  const f32x4 tw0 = twsrc[tid], tw1 = tid + DG_THREADS < DG_TAILW / 16 ? twsrc[tid + DG_THREADS] : (f32x4){0.f, 0.f, 0.f, 0.f};
   if (!(res->flags & DMZ_HIP_FLAG_VSEG_OK)) return;
   const int nd = res->n_offsets;
 #pragma unroll
   for (int k = 0; k < kStage; k++)
     if (tid + k * DG_THREADS < XPLANE / 4) ((uint32_t *)raw)[tid + k * DG_THREADS] = st[k];
+  ((f32x4 *)(raw + DG_RAW))[tid] = tw0;
+  if (tid + DG_THREADS < DG_TAILW / 16) ((f32x4 *)(raw + DG_RAW))[tid + DG_THREADS] = tw1;
   DG_T(1)
   DG_STOP(2, raw[0] + raw[100])
   DG_T(2)
 
-  digits_cnn<1>(wts, hidw, cw, raw, nd, tid);
+  digits_cnn<1>(wts, hidw, cw, raw, (const float *)(raw + DG_RAW), nd, tid);
   if (DMZ_DIGITS_STOP >= 3 && DMZ_DIGITS_STOP <= 7) return;
 
   DG_T(12)
   // ---- vote (n_categorize.cpp:69-70), arg-max, usable gate (frame.cpp:63-64) ----
   const float *prob = (const float *)raw;
-  float *fin = (float *)raw + 512;  // 160 floats
+  float *fin = (float *)raw + 768;  // 160 floats
   float myv = 0.0f;
   if (tid < 160) {
-    const int d = tid / 10;
+    const int d = tid / 10, c = tid - 10 * d;
     if (d < nd) {
-      const float r0 = prob[0 * 160 + tid], r1 = prob[1 * 160 + tid], r2 = prob[2 * 160 + tid];
+      const float r0 = digit_softmax(prob, 0, d, c), r1 = digit_softmax(prob, 1, d, c), r2 = digit_softmax(prob, 2, d, c);
       float mx = r0 > r1 ? r0 : r1;
       mx = mx > r2 ? mx : r2;
       myv = (((r0 + r1) + r2) - mx) / 2.0f;
@@ -502,7 +523,7 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
     if (f == n / 2) {
       g_dg_t[13] = clock64();
       for (int i = 0; i < 13; i++) res->scores[15][i % 10] = 0;  // (keeps the record valid-looking)
-      for (int i = 1; i < 14; i++) (&res->scores[0][0])[i] = (float)(g_dg_t[i] - g_dg_t[0]);
+      for (int i = 1; i < 16; i++) (&res->scores[0][0])[i] = (float)(g_dg_t[i] - g_dg_t[0]);
     }
 #endif
   }
@@ -512,7 +533,8 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
 // convolution / pooling / matrix-core / head code.  A float input x is scaled by 255 (the conv weights
 // carry the 1 / 255 of n_categorize.cpp:99) and split into three bf16 planes hi + mid + lo = 255 x
 // exactly; the tile runs once per plane into the same accumulators.
-constexpr int DGM_LDS = 3 * XPLANE + CHUNK_BYTES;
+constexpr int DGM_RAW = 3 * XPLANE + CHUNK_BYTES;  // (the tail's weights follow)
+constexpr int DGM_LDS = DGM_RAW + DG_TAILW;
 __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restrict__ wts,
                                                              const float *__restrict__ hidw, int model,
                                                              const float *__restrict__ xin, int n,
@@ -539,8 +561,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restr
   }
   ConvWeights cw;
   conv_weights_load(cw, hidw, tid & 63);
-  digits_cnn<3>(wts, hidw, cw, rawm, rows, tid);
-  if (tid < rows * 10) out[(size_t)base * 10 + tid] = ((const float *)rawm)[model * 160 + tid];
+  for (int i = tid; i < DG_TAILW / 4; i += DG_THREADS) ((float *)(rawm + DGM_RAW))[i] = hidw[dmzv::WFRAG + dmzv::DTAIL + i];
+  digits_cnn<3>(wts, hidw, cw, rawm, (const float *)(rawm + DGM_RAW), rows, tid);
+  if (tid < rows * 10) out[(size_t)base * 10 + tid] = digit_softmax((const float *)rawm, model, tid / 10, tid % 10);
 }
 
 }  // namespace

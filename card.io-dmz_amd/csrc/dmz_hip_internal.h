@@ -164,7 +164,13 @@ constexpr int ROWSUM = 4 * 7 * 3 * 64 * 4;          // sum_k W1[j][k], 64 floats
 // description of the two K layouts
 constexpr int DCONV_B = ROWSUM + 64;                // 2 * 2 * 64 * 4 floats
 constexpr int DCONV_BIAS = DCONV_B + 2 * 2 * 64 * 4;  // conv biases by column n (32, zero beyond 23)
-constexpr int WFRAG_FLOATS = DCONV_BIAS + 32;
+// what the tail of the digit CNNs reads, contiguous (k_digits stages it into LDS): hidden biases [model 3][32]; the logistic
+// layer as the B operand of a 16 x 32 x 16 product, [model 3][class 16 (10 used, rest zero)][DT_PITCH floats, 32 used]; its
+// biases [model 3][16]
+constexpr int DT_PITCH = 36;
+constexpr int DT_HB = 0, DT_LW = 96, DT_LB = DT_LW + 3 * 16 * DT_PITCH, DT_FLOATS = DT_LB + 48;  // 1872 floats
+constexpr int DTAIL = DCONV_BIAS + 32;
+constexpr int WFRAG_FLOATS = DTAIL + DT_FLOATS;
 }  // namespace dmzv
 void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag /* dmzv layout */, const uint8_t *cards, size_t card_stride,
                      int n, int mode /* DMZ_HIP_SCAN_* */, dmz_hip_frame_result *results);

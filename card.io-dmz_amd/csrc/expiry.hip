@@ -84,8 +84,10 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   if (nrows > 128 || nrows < 18) return;  // y_offset >= 121 for a card that is not upside down
   const uint8_t *card = cards + (size_t)f * card_stride;
 
-  // sixteen rows per trip: 32 dword loads in flight per lane (the rows come from HBM; the kernel is bound by the
-  // latency of these trips), and two rows per wave reduction (a lane's sum is < 2^11, a 16-lane row's < 2^15)
+  // sixteen rows per trip: 32 dword loads in flight per lane, and two rows per wave reduction (a lane's sum is < 2^11, a
+  // 16-lane row's < 2^15).  The kernel re-reads ~26 KB of every card in 258-byte row pieces (1.8 TB/s of scattered HBM
+  // traffic at 65 536 frames): a four-wave form with every row load of a frame in flight at once (round 3) has the same
+  // run time -- one trip then takes 13 - 16 k cycles -- so it is the memory system, not the wave's latency chain.
   constexpr int kTrip = 16;
   for (int r0 = 0; r0 < nrows; r0 += kTrip) {
     uint32_t a[kTrip], b[kTrip];

@@ -14,4 +14,4 @@ for _ in range(2):
     ctx.pipeline_expiry(y.ptr, B, res.ptr, exp.ptr, cards.ptr)
 ctx.synchronize()
 r = res.download(pkg.RESULT_DTYPE)
-print("cycles since entry:", r[B // 2]["scores"].reshape(-1)[1:14].astype(int).tolist())
+print("cycles since entry:", r[B // 2]["scores"].reshape(-1)[1:16].astype(int).tolist())
