@@ -32,6 +32,7 @@ struct dmz_hip_context {
   hipStream_t aux_stream = nullptr, aux2_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_seg[kMaxChunks] = {}, ev_dig[kMaxChunks] = {};
   bool overlap = true;
+  int dev_chunks = 1;  // developer switch DMZ_HIP_CHUNKS, read once at context creation
   std::string err;
 
   float *d_weights = nullptr;  // blob
@@ -506,6 +507,10 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
     }
   }
   if (getenv("DMZ_HIP_NO_OVERLAP")) ctx->overlap = false;  // developer switch (A/B timing)
+  if (const char *e = getenv("DMZ_HIP_CHUNKS")) {             // developer switch (read here, not on the hot path)
+    const int v = atoi(e);
+    if (v >= 1 && v <= kMaxChunks) ctx->dev_chunks = v;
+  }
   // weights: blob + the two transposed copies the kernels read coalesced
   const size_t blob_bytes = (size_t)(dmz_weights_blob_end - dmz_weights_blob);
   if (blob_bytes < 16 + sizeof(float) * dmzw::TOTAL || memcmp(dmz_weights_blob, "DMZW0001", 8) != 0) {
@@ -903,16 +908,24 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
   } else {
     // (measured at 65 536 frames, ms per step: one queue 25.63; three queues, 1 chunk 25.53, 2 chunks 25.52, 4 chunks
     // 25.96, 8 chunks 26.19 -- the finer the chunks, the more the kernels of one chain thin out each other's occupancy)
-    int nchunks = 1;
-    if (const char *e = getenv("DMZ_HIP_CHUNKS")) {  // developer switch
-      const int v = atoi(e);
-      if (v >= 1 && v <= kMaxChunks && n >= 64 * v) nchunks = v;
-    }
+    const int nchunks = n >= 64 * ctx->dev_chunks ? ctx->dev_chunks : 1;
     if ((rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * 3 * (size_t)n))) return rc;
     if ((rc = ensure_patches(ctx, n))) return rc;
     dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_hidwt + dmzv::WFRAG, dcards, card_stride, n, 1, dres);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    // From the fork to the join work may be in flight on all three queues: a failing call in between must not return
+    // while the other queues still read and write the caller's buffers (dmz_hip_synchronize waits on ctx->stream only).
+    // FORK_TRY drains the two auxiliary queues before it reports the error.
+#define FORK_TRY(expr)                                                            \
+  do {                                                                            \
+    const hipError_t fe__ = (expr);                                               \
+    if (fe__ != hipSuccess) {                                                     \
+      (void)hipStreamSynchronize(ctx->aux_stream);                                \
+      (void)hipStreamSynchronize(ctx->aux2_stream);                               \
+      return fail(ctx, DMZ_HIP_ERUNTIME, #expr, fe__);                            \
+    }                                                                             \
+  } while (0)
+    FORK_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+    FORK_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     for (int ck = 0; ck < nchunks; ck++) {
       const int first = (int)((long long)n * ck / nchunks), cn = (int)((long long)n * (ck + 1) / nchunks) - first;
       dmz_hip_frame_result *cres = dres + first;
@@ -920,20 +933,21 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
       DmzExpiryStage *cstage = (DmzExpiryStage *)ctx->xstage.p + (size_t)3 * first;
       dmz_launch_expiry(ctx->aux_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
                         dexp + first, nullptr, ctx->expiry_conv, 1);
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_seg[ck], ctx->aux_stream));
+      FORK_TRY(hipEventRecord(ctx->ev_seg[ck], ctx->aux_stream));
       dmz_launch_hseg(ctx->stream, ccards, card_stride, cn, cres);
       dmz_launch_digits(ctx->stream, ctx->d_weights, ctx->d_hidwt, ccards, card_stride, cn, cres,
                         (unsigned char *)ctx->patches.p + (size_t)first * dmz_digit_patch_bytes());
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_dig[ck], ctx->stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_seg[ck], 0));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_dig[ck], 0));
+      FORK_TRY(hipEventRecord(ctx->ev_dig[ck], ctx->stream));
+      FORK_TRY(hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_seg[ck], 0));
+      FORK_TRY(hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_dig[ck], 0));
       dmz_launch_expiry(ctx->aux2_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
                         dexp + first, nullptr, ctx->expiry_conv, 2);
     }
-    HIP_TRY(ctx, hipGetLastError());
+    FORK_TRY(hipGetLastError());
     // the main queue continues after the third queue's last kernel (which waited for the second's)
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux2_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    FORK_TRY(hipEventRecord(ctx->ev_join, ctx->aux2_stream));
+    FORK_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+#undef FORK_TRY
   }
   if (with_expiry) {
     if (!exp_dev)

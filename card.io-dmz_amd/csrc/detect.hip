@@ -46,7 +46,16 @@ namespace {
 #ifndef DMZ_DETECT_STOP
 #define DMZ_DETECT_STOP 99
 #endif
+// developer probe: -DDMZ_DT_TIMING leaves the cycle counter at the phase boundaries in the hit record (max_val, r, n, found
+// of the probed workgroup are overwritten: timing runs only)
+#ifdef DMZ_DT_TIMING
+__device__ long long g_dt_t[2][8];
+#define DT_T(i) if (tid == 0 && blockIdx.x == gridDim.x / 2) g_dt_t[VERT ? 1 : 0][i] = clock64();
+#else
+#define DT_T(i)
+#endif
 #define DMZ_STOP_AFTER(k, expr)                                   \
+  DT_T(k)                                                         \
   if (DMZ_DETECT_STOP == (k)) {                                   \
     if (tid == 0) {                                               \
       DmzBoxHit hh__ = {0, 0, 0, (int)(expr)};                    \
@@ -226,6 +235,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
                             DmzBoxHit *__restrict__ hits, unsigned char *lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  DT_T(0)
   const int w = bp.w, h = bp.h;
   const int L = bp.lanes, S = bp.steps, N = L * S;
   const uint32_t inv_L = bp.inv_w;
@@ -606,6 +616,14 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       hit.n = 0;
     }
     hits[frame * 4 + box_id] = hit;
+#ifdef DMZ_DT_TIMING
+    if (blockIdx.x == gridDim.x / 2) {
+      const long long t6 = clock64();
+      printf("detect %s: load %lld walk %lld nms %lld hyst %lld votes %lld argmax %lld\n", VERT ? "vert" : "hz",
+             g_dt_t[VERT][1] - g_dt_t[VERT][0], g_dt_t[VERT][2] - g_dt_t[VERT][1], g_dt_t[VERT][3] - g_dt_t[VERT][2],
+             g_dt_t[VERT][4] - g_dt_t[VERT][3], g_dt_t[VERT][5] - g_dt_t[VERT][4], t6 - g_dt_t[VERT][5]);
+    }
+#endif
   }
 }
 
@@ -680,26 +698,60 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
     // Parked form: the edge map lies over the tile, so what follows the tile is ONE region with two tenants -- the parked
     // gradients + the candidate lists until the hysteresis is done, then the vote counters: tile | region | scratch
     // (21.6 KB instead of 30 KB for the left/right boxes of a 640 x 480 frame).
+    // What the device holds, asked once: LDS per CU, and how many workgroups of this kernel the register file and the wave
+    // slots admit (the occupancy query with no dynamic LDS).  No literals: a different part or compiler changes the answer.
+    static int lds_cu = 0, wgs_regs = 0;
+    const void *kfn = (const void *)k_detect_walk<VERT, kNt, kSteps, kRegs>;
+    if (lds_cu == 0) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || v <= 0)
+        v = 65536;  // the architectural minimum: the lists then keep their minimal size
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, kNt, 0) != hipSuccess || nb < 1) nb = 1;
+      (void)hipGetLastError();  // (a failed query must not surface as the launch's error)
+      lds_cu = v, wgs_regs = nb;
+    }
     DmzDetectParams q = p;
     int total = 0;
-    for (int e = VERT ? 1 : 0; e < 4; e += 2) {
-      DmzBoxParams &bx = q.box[e];
-      const int park = (4 * bx.lanes * (kSteps - kRegs) + 15) & ~15, acc = bx.lds_red - bx.lds_acc;
-      int region = ((park + 2048 > acc ? park + 2048 : acc) + 15) & ~15;
-      // the candidate lists take what the workgroups-per-CU count leaves over (busy frames then stay on the list path
-      // instead of the whole-map fallback): the count is the smaller of what LDS and the register budget allow
-      const int tile = bx.lds_map, wps = VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H;
-      int wgs = 163840 / (tile + region + 512);
-      if (wgs > wps * 4 / (kNt / 64)) wgs = wps * 4 / (kNt / 64);
-      if (wgs >= 1) {
-        const int budget = ((163840 / wgs - 1536) & ~15) - tile - 512;  // (1.5 KB short of the limit: the allocation granularity)
-        if (budget > region && budget <= 65536) region = budget;
+    auto layout = [&](bool grow_lists) {
+      q = p;
+      total = 0;
+      int wgs_min = 1 << 20;
+      for (int e = VERT ? 1 : 0; e < 4; e += 2) {
+        DmzBoxParams &bx = q.box[e];
+        const int park = (4 * bx.lanes * (kSteps - kRegs) + 15) & ~15, acc = bx.lds_red - bx.lds_acc;
+        int region = ((park + 2048 > acc ? park + 2048 : acc) + 15) & ~15;
+        // the candidate lists take what the workgroups-per-CU count leaves over (busy frames then stay on the list path
+        // instead of the whole-map fallback): the count is the smaller of what LDS and the registers / wave slots allow
+        const int tile = bx.lds_map;
+        int wgs = lds_cu / (tile + region + 512);
+        if (wgs > wgs_regs) wgs = wgs_regs;
+        if (grow_lists && wgs >= 1) {
+          // (1.5 KB short of an equal share: a kernel allocated to within 16 bytes of it lost a workgroup, tools/ubench/lds_granularity.hip)
+          const int budget = ((lds_cu / wgs - 1536) & ~15) - tile - 512;
+          if (budget > region && budget <= 65536) region = budget;
+        }
+        wgs_min = wgs < wgs_min ? wgs : wgs_min;
+        bx.lds_acc = bx.lds_map;
+        bx.lds_red = bx.lds_map + region;
+        bx.lds_total = bx.lds_red + 512;
+        total = bx.lds_total > total ? bx.lds_total : total;
       }
-      bx.lds_acc = bx.lds_map;
-      bx.lds_red = bx.lds_map + region;
-      bx.lds_total = bx.lds_red + 512;
-      total = bx.lds_total > total ? bx.lds_total : total;
+      return wgs_min;
+    };
+    // the grown layout must not cost a workgroup: checked against the occupancy query once per geometry, else the minimal one
+    static int checked_total = -1, checked_ok = 0;
+    const int want = layout(true);
+    if (total != checked_total) {
+      int nb = 0;
+      // (the query needs the kernel's dynamic-LDS limit raised first, as the launch does)
+      checked_ok = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, total) == hipSuccess &&
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, kNt, (size_t)total) == hipSuccess && nb >= want;
+      (void)hipGetLastError();
+      checked_total = total;
     }
+    if (!checked_ok) (void)layout(false);
     return launch_pair<VERT, kNt, kSteps, kRegs>(s, planes, frame_stride, row_stride, n, q, hits, skip_mask, total);
   }
   if (nt <= 256) return launch_pair<VERT, 256, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);

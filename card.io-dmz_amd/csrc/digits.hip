@@ -338,7 +338,10 @@ static_assert(PART_BYTES + 3 * 16 * HID_PITCH * 4 <= DG_RAW && DG_LDS <= DG_RAW,
 // LDS strip -- 36 byte loads per lane keep the texture path busier than 180 LDS byte reads keep the LDS: 1.9 vs 0.9 ms
 // per 65 536 cards.)
 constexpr int STRIP_BYTES = 11568;     // 27 x 428 = 11,556, padded to 16
-constexpr int HIST_BYTES = 16 * 512;   // one histogram / LUT per digit
+#ifndef DMZ_DP_U32
+#define DMZ_DP_U32 0
+#endif
+constexpr int HIST_BYTES = 16 * 512 * (DMZ_DP_U32 ? 2 : 1);   // one histogram / LUT per digit
 constexpr int DP_LDS = STRIP_BYTES + HIST_BYTES;  // 19,760 B: eight workgroups per CU
 #ifndef DMZ_DP_WGS
 #define DMZ_DP_WGS 8
@@ -364,11 +367,11 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
 
   // ---- number strip -> LDS (2889 aligned dwords) ----
   for (int i = tid; i < 27 * 107; i += DG_THREADS) ((uint32_t *)strip_l)[i] = strip[i];
-  unsigned int *hd = (unsigned int *)(raw + STRIP_BYTES) + wave * (4 * 128);  // 4 x (256 u16 counters, then the LUT)
+  constexpr int HW = DMZ_DP_U32 ? 256 : 128;  // dwords per histogram
+  unsigned int *hd = (unsigned int *)(raw + STRIP_BYTES) + wave * (4 * HW);  // 4 x (256 counters, then the LUT)
   {
     const u32x4 z = {0u, 0u, 0u, 0u};
-    *(u32x4 *)(hd + 8 * lane) = z;
-    *(u32x4 *)(hd + 8 * lane + 4) = z;
+    for (int i = 0; i < HW / 64; i++) *(u32x4 *)(hd + (HW / 16) * lane + 4 * i) = z;
   }
   __syncthreads();
   if (DMZ_DP_STOP == 1) return;
@@ -409,15 +412,22 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
       if (4 * wave + dj < nd && lane < 57) {
 #pragma unroll
         for (int k = 0; k < 9; k++)
-          atomicAdd(&hd[dj * 128 + (gv[dj][k] >> 1)], 1u << ((gv[dj][k] & 1) * 16));  // counts <= 513: no carry
+          if (DMZ_DP_U32) atomicAdd(&hd[dj * HW + gv[dj][k]], 1u);
+          else atomicAdd(&hd[dj * HW + (gv[dj][k] >> 1)], 1u << ((gv[dj][k] & 1) * 16));  // counts <= 513: no carry
       }
     __builtin_amdgcn_wave_barrier();
     if (DMZ_DP_STOP == 3) return;
     uint2 lut[4];
 #pragma unroll
     for (int dj = 0; dj < 4; dj++) {
-      const uint2 hh = *(const uint2 *)(hd + dj * 128 + 2 * lane);
-      const int h0 = hh.x & 0xffff, h1 = hh.x >> 16, h2 = hh.y & 0xffff, h3 = hh.y >> 16;
+      int h0, h1, h2, h3;
+      if (DMZ_DP_U32) {
+        const u32x4 hh = *(const u32x4 *)(hd + dj * HW + 4 * lane);
+        h0 = (int)hh.x, h1 = (int)hh.y, h2 = (int)hh.z, h3 = (int)hh.w;
+      } else {
+        const uint2 hh = *(const uint2 *)(hd + dj * HW + 2 * lane);
+        h0 = hh.x & 0xffff, h1 = hh.x >> 16, h2 = hh.y & 0xffff, h3 = hh.y >> 16;
+      }
       const int tot = h0 + h1 + h2 + h3;
       const int incl = dmzwave::inclusive_scan_i32(tot);
       const int excl = incl - tot;
@@ -435,13 +445,13 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int dj = 0; dj < 4; dj++) *(uint2 *)(hd + dj * 128 + 2 * lane) = lut[dj];
+    for (int dj = 0; dj < 4; dj++) *(uint2 *)(hd + dj * HW + 2 * lane) = lut[dj];
     __builtin_amdgcn_wave_barrier();
     if (DMZ_DP_STOP == 4) return;
 #pragma unroll
     for (int dj = 0; dj < 4; dj++)
       if (4 * wave + dj < nd && lane < 57) {
-        const unsigned short *h16 = (const unsigned short *)(hd + dj * 128);
+        const unsigned short *h16 = (const unsigned short *)(hd + dj * HW);
         unsigned short *xd = xb + (4 * wave + dj) * XD + rr * XS + c;
 #pragma unroll
         for (int k = 0; k < 9; k++) xd[3 * k * XS] = h16[gv[dj][k]];
