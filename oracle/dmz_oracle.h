@@ -154,6 +154,9 @@ void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets
                        float scores[160]);                                  /* n_categorize.cpp:75-107 */
 void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res); /* frame.cpp:24-81 (number path) */
 void orc_scan_card_image_ex(const uint8_t *card, int stride, int collect_card_number, orc_frame_result *res);
+/* test infrastructure: the stages after vseg at a GIVEN (y_offset, pattern, score) -- see orc_scan.c */
+void orc_scan_card_image_at(const uint8_t *card, int stride, int y_off, int pattern, float score,
+                            int collect_card_number, orc_frame_result *res);
 
 /* ---- expiry path: scan/expiry_seg.cpp, scan/expiry_categorize.cpp.
  * Per-frame part only: segmentation into MM/YY groups and the four digit score rows of each

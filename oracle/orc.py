@@ -289,6 +289,18 @@ class Oracle:
                                         res.ctypes.data_as(C.c_void_p))
         return res[0]
 
+    def scan_card_image_at(self, card, y_off, pattern, score, base=None, collect_card_number=True):
+        """the stages after vseg at a given segmentation (parity tests: downstream of a proven vseg near-tie)"""
+        card = np.ascontiguousarray(card, np.uint8)
+        res = np.zeros(1, RESULT_DTYPE)
+        if base is not None:
+            res[0] = base
+        else:
+            res["flags"] = FLAG_WARPED
+        self.lib.orc_scan_card_image_at(_p(card, _u8p), card.shape[1], int(y_off), int(pattern), C.c_float(float(score)),
+                                        int(collect_card_number), res.ctypes.data_as(C.c_void_p))
+        return res[0]
+
     def scan_frame(self, y, orientation=3, truncate=False, want_card=True):
         y = np.ascontiguousarray(y, np.uint8)
         res = np.zeros(1, RESULT_DTYPE)

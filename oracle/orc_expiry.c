@@ -301,7 +301,7 @@ static void find_character_groups_for_stripe(const int16_t *sobel, int stripe_ba
   float summation_threshold = (float)(rect_average / 5);
 
   /* [1] sliding 9-wide sums of rows stripe_base_row .. stripe_base_row + expanded_h - 1 */
-  static char_rect rect_list[W];
+  static __thread char_rect rect_list[W]; /* (thread-local: the parity tests call the oracle from several threads) */
   int n_rects = 0;
   float rect_sum_total = 0;
   long rect_sum = 0;
@@ -327,7 +327,7 @@ static void find_character_groups_for_stripe(const int16_t *sobel, int stripe_ba
 
   /* [2]+[3] descending by sum (ties: ascending left), greedy non-overlapping pick.  Visiting
    * the sorted list and skipping masked rects == repeatedly taking the best unmasked rect. */
-  static grouped_rects items[W / kSmallCharacterWidth + 2];
+  static __thread grouped_rects items[W / kSmallCharacterWidth + 2];
   int n_items = 0;
   uint8_t mask[W + 16];
   uint8_t used[W];
@@ -356,7 +356,7 @@ static void find_character_groups_for_stripe(const int16_t *sobel, int stripe_ba
   }
 
   /* [4] local groups */
-  static grouped_rects groups[W / kSmallCharacterWidth + 2];
+  static __thread grouped_rects groups[W / kSmallCharacterWidth + 2];
   int n_groups = gather_into_groups(items, n_items, groups);
 
   /* expiry_seg.cpp:566-573: keep groups of >= 4, regrid, optimise (dropping emptied groups),
@@ -382,7 +382,7 @@ static void find_character_groups_for_stripe(const int16_t *sobel, int stripe_ba
 /* expiry_seg.cpp:707-902 */
 void orc_best_expiry_seg(const uint8_t *card, int stride, int starting_y_offset, orc_expiry_result *out) {
   memset(out, 0, sizeof(*out));
-  static int16_t sobel[H * W];
+  static __thread int16_t sobel[H * W];
   memset(sobel, 0, sizeof(sobel));
   const int y0 = starting_y_offset + ORC_NUM_H;
   if (y0 >= H) return;
@@ -528,7 +528,7 @@ void orc_scan_card_expiry(const uint8_t *card, int stride, const orc_frame_resul
 int orc_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *sums, int top, int height,
                                   int *group_n, int *group_left, int *group_width, int *rect_left,
                                   int64_t *rect_sum) {
-  static grouped_rects items[64], groups[64];
+  static __thread grouped_rects items[64], groups[64];
   if (n_items > 64) n_items = 64;
   for (int i = 0; i < n_items; i++) {
     items[i].top = top, items[i].left = lefts[i], items[i].width = kSmallCharacterWidth;
@@ -546,7 +546,7 @@ int orc_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *
 
 void orc_expiry_regrid_group(const int16_t *sobel, int top, int height, int *left, int *width, int *character_width,
                              int *n, int *rect_left, int64_t *rect_sum) {
-  static grouped_rects g;
+  static __thread grouped_rects g;
   g.top = top, g.height = height, g.left = *left, g.width = *width, g.character_width = *character_width, g.n = 0;
   regrid_group(sobel, &g);
   *left = g.left, *width = g.width, *character_width = g.character_width, *n = g.n;

@@ -175,7 +175,7 @@ void orc_applyc_expiry(const float xin[16 * 11], float out[10], float *l1_out, f
   for (int i = 0; i < 176; i++) x[i] = xin[i] - mean;
   const float *c1w = w, *c1b = c1w + 1250, *c2w = c1b + 50, *c2b = c2w + 50000;
   const float *hw = c2b + 40, *hb = hw + 21120, *lw = hb + 176, *lb = lw + 1760;
-  static float l1[50 * 70];
+  static __thread float l1[50 * 70];
   float l2[120], l3[176];
   /* layer 1: correlation with zero padding 4 on every side, outputs 20 x 14 of the
    * 20 x 15 "full" result are pooled 2x2 -> 10 x 7 */
@@ -424,6 +424,31 @@ void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets
   }
 }
 
+/* frame.cpp:49-81 once the vseg gates have passed: res->vseg_y_offset / pattern_type are set */
+static void scan_number_from_vseg(const uint8_t *card, int stride, int collect_card_number, orc_frame_result *res) {
+  const int y_off = res->vseg_y_offset, pattern = res->pattern_type;
+  res->flags |= ORC_FLAG_VSEG_OK;
+  if (!collect_card_number) {
+    res->flags |= ORC_FLAG_USABLE;
+    return;
+  }
+  const uint8_t *strip = card + (size_t)y_off * stride;
+  orc_best_n_hseg(strip, stride, pattern, res);
+  orc_number_scores(strip, stride, res->offsets, res->n_offsets, &res->scores[0][0]);
+  /* scores.sum(): 160 floats, sequential row-major in scalar mode (Redux.h:168-184) */
+  const float *sc = &res->scores[0][0];
+  float sum = sc[0];
+  for (int i = 1; i < 160; i++) sum = sum + sc[i];
+  res->number_score = res->n_offsets - sum;
+  if (res->number_score < 3) res->flags |= ORC_FLAG_USABLE; /* kMaxNumberScoreDelta */
+  for (int d = 0; d < 16; d++) {
+    int best = 0;
+    for (int k = 1; k < 10; k++)
+      if (res->scores[d][k] > res->scores[d][best]) best = k;
+    res->digits[d] = (uint8_t)best;
+  }
+}
+
 /* frame.cpp:24-81, number path (expiry handled elsewhere).  collect_card_number = 0 is what
  * scanner_add_frame_with_expiry passes once the session's number is accepted (scan.cpp:43-48): a frame
  * that passes the vseg gates is usable as it is (frame.cpp:43-49), hseg and the digit CNNs do not run. */
@@ -448,26 +473,32 @@ void orc_scan_card_image_ex(const uint8_t *card, int stride, int collect_card_nu
     return;
   }
   if (!(score > 15)) return; /* kMinVSegScore */
-  res->flags |= ORC_FLAG_VSEG_OK;
-  if (!collect_card_number) {
-    res->flags |= ORC_FLAG_USABLE;
+  scan_number_from_vseg(card, stride, collect_card_number, res);
+}
+
+/* Test infrastructure only (no counterpart in the reference): frame.cpp:38-81 downstream of a GIVEN vertical
+ * segmentation.  Where the device's y_offset differs from the oracle's by a proven float near-tie of two window sums, the
+ * parity tests re-run the oracle's later stages at the device's choice, so that a tie cannot hide a second difference. */
+void orc_scan_card_image_at(const uint8_t *card, int stride, int y_off, int pattern, float score,
+                            int collect_card_number, orc_frame_result *res) {
+  res->flags &= ORC_FLAG_WARPED;
+  res->n_offsets = 0;
+  memset(res->offsets, 0, sizeof(res->offsets));
+  res->hseg_score = 0;
+  res->number_width = 0;
+  res->pattern_offset = 0;
+  res->number_score = 0;
+  memset(res->digits, 0, sizeof(res->digits));
+  memset(res->scores, 0, sizeof(res->scores));
+  res->vseg_score = score;
+  res->vseg_y_offset = y_off;
+  res->pattern_type = pattern;
+  if (y_off < (ORC_CARD_H - ORC_NUM_H) / 2) {
+    res->flags |= ORC_FLAG_UPSIDE_DOWN;
     return;
   }
-  const uint8_t *strip = card + (size_t)y_off * stride;
-  orc_best_n_hseg(strip, stride, pattern, res);
-  orc_number_scores(strip, stride, res->offsets, res->n_offsets, &res->scores[0][0]);
-  /* scores.sum(): 160 floats, sequential row-major in scalar mode (Redux.h:168-184) */
-  const float *sc = &res->scores[0][0];
-  float sum = sc[0];
-  for (int i = 1; i < 160; i++) sum = sum + sc[i];
-  res->number_score = res->n_offsets - sum;
-  if (res->number_score < 3) res->flags |= ORC_FLAG_USABLE; /* kMaxNumberScoreDelta */
-  for (int d = 0; d < 16; d++) {
-    int best = 0;
-    for (int k = 1; k < 10; k++)
-      if (res->scores[d][k] > res->scores[d][best]) best = k;
-    res->digits[d] = (uint8_t)best;
-  }
+  if (!(score > 15)) return;
+  scan_number_from_vseg(card, stride, collect_card_number, res);
 }
 
 void orc_scan_card_image(const uint8_t *card, int stride, orc_frame_result *res) {

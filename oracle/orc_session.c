@@ -172,7 +172,7 @@ void orc_scan_session(const orc_frame_result *frames, const orc_expiry_result *e
   memset(agg16, 0, sizeof(agg16));
   long t_number = 0;
   int st_scan_expiry = 0, em = 0, ey = 0;
-  static agg_group groups[MAX_AGG];
+  static __thread agg_group groups[MAX_AGG];
   int n_groups = 0;
   const orc_frame_result *recent = NULL;
   orc_session_result success; /* successfulCardNumberResult */

@@ -52,6 +52,14 @@ def test_expiry_models_match_oracle_on_random_batches(ctx, oracle):
     # default conv2 arithmetic is BF16X3 (split bf16 operands, fp32 accumulation): measured 1.5e-5 here, inside
     # the 1e-4 contract; the fp32 variant meets the KAT bound 1e-5 (test_expiry_conv_variants_against_fp32)
     assert np.abs(got - want).max() <= 3e-5
+    # ... and the fp32 variant keeps the reference's own KAT tolerance on the same random batch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    try:
+        ctx.set_expiry_conv(pkg.EXPIRY_CONV_F32)
+        assert np.abs(ctx.apply_expiry_model(x) - want).max() <= 1e-5
+    finally:
+        ctx.set_expiry_conv(pkg.EXPIRY_CONV_BF16X3)
 
 
 def test_expiry_conv_variants_against_fp32(ctx, pkg, oracle):

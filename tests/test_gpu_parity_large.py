@@ -1,14 +1,17 @@
-"""Parity statistics on a larger seeded corpus (1024 frames): every integer/index output
+"""Parity statistics on a larger seeded corpus (4096 frames by default): every integer/index output
 must match the oracle; float scores within 1e-4.  An index may differ only where the reference's own
 decision hangs on a float comparison closer than the score tolerance, and every such event must be
 PROVEN from the oracle's values (no blanket allowance):
   * a digit label: the oracle's top two vote scores of that digit are within 2e-4 (|delta| <= 1e-4 on
     every class and a different arg-max imply a top-two gap <= 2e-4);
   * the usable flag: the oracle's number_score is within 1e-3 of the gate value 3 (160 scores summed);
-  * y_offset / pattern: the oracle's window sums of the two (offset, pattern) choices are within 1e-4,
-    or -- when the coarse-pass tie moved the fine-pass rows -- the two winning scores are.
-Anything else counts as `unexplained` and fails the test."""
+  * y_offset / pattern: the oracle's OWN window sums of the two (offset, pattern) choices are within 1e-4.
+    A proven tie does not end the frame's check: the oracle's later stages (hseg, digit models, expiry) are re-run at the
+    device's segmentation and compared like everything else, so a tie cannot hide a second difference.
+Anything else counts as `unexplained` and fails the test.
+The oracle runs on a thread pool (its C code holds no shared mutable state; ctypes releases the GIL)."""
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
@@ -26,32 +29,59 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
     ctx.synchronize()
     got = res.download(pkg.RESULT_DTYPE, n)
     gexp = exp.download(pkg.EXPIRY_DTYPE, n)
-    gcards = cards.download(np.uint8).reshape(n, 270, 428)
-    frames = y.download(np.uint8).reshape(n, 480, 640)
-    for b in (res, cards, exp):
-        b.free()
     stats = dict(found_all=int(got["found_all"].astype(bool).sum()),
                  vseg_ok=int(((got["flags"] & pkg.FLAG_VSEG_OK) != 0).sum()) if hasattr(pkg, "FLAG_VSEG_OK") else -1,
                  card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
                  label_diff=0, flag_diff=0, unexplained=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
                  expiry_slash_flips=0, max_expiry_err=0.0)
-    for i in range(n):
-        w, wcard = oracle.scan_frame(frames[i])
-        g = got[i]
+    nthreads = max(1, min(64, (os.cpu_count() or 2) // 2))
+
+    def slice_to_host(buf, first, count, item_bytes):  # frames / cards of one chunk (a sweep's whole batch is tens of GB)
+        out = np.empty(count * item_bytes, np.uint8)
+        ctx._check(ctx.lib.dmz_hip_memcpy_d2h(ctx.h, out.ctypes.data, buf.ptr + first * item_bytes, out.nbytes))
+        return out
+
+    chunk = 4096
+    with ThreadPoolExecutor(nthreads) as pool:
+        for c0 in range(0, n, chunk):
+            cn = min(chunk, n - c0)
+            frames = slice_to_host(y, c0, cn, pkg.FRAME_BYTES).reshape(cn, 480, 640)
+            gcards = slice_to_host(cards, c0, cn, pkg.CARD_BYTES).reshape(cn, 270, 428)
+
+            def oracle_frame(j):
+                w, wcard = oracle.scan_frame(frames[j])
+                return w, wcard, oracle.scan_card_expiry(wcard, w)
+
+            oracle_out = list(pool.map(oracle_frame, range(cn), chunksize=8))
+            for j in range(cn):
+                _compare_frame(pkg, oracle, stats, got[c0 + j], gexp[c0 + j], gcards[j], *oracle_out[j])
+    for b in (res, cards, exp):
+        b.free()
+    return stats
+
+
+def _compare_frame(pkg, oracle, stats, g, ge, gcard, w, wcard, we):
+    """one frame's device records against the oracle's; counts into stats"""
+    for _ in (0,):  # (a one-pass loop: `continue` ends the frame's check as in the original flat loop)
         if not (np.array_equal(g["found"], w["found"]) and g["found_all"] == w["found_all"]
                 and np.array_equal(g["corners"].view(np.uint32), w["corners"].view(np.uint32))):
             stats["det_diff"] += 1
             continue
-        stats["card_bytes_diff"] += int((gcards[i] != wcard).sum())
+        stats["card_bytes_diff"] += int((gcard != wcard).sum())
         if g["vseg_y_offset"] != w["vseg_y_offset"] or g["pattern_type"] != w["pattern_type"]:
             _, _, _, vis, amx = oracle.best_n_vseg(wcard)
             def wsum(y, p):
                 return float((vis if p == 1 else amx)[y:y + 27].astype(np.float64).sum()) if p else 0.0
             near = abs(wsum(int(g["vseg_y_offset"]), int(g["pattern_type"])) -
                        wsum(int(w["vseg_y_offset"]), int(w["pattern_type"]))) < 1e-4
-            near = near or abs(float(g["vseg_score"]) - float(w["vseg_score"])) < 1e-4
-            stats["ties" if near else "unexplained"] += 1
-            continue
+            if not near:
+                stats["unexplained"] += 1
+                continue
+            stats["ties"] += 1
+            # downstream of the tie: the oracle's later stages at the device's segmentation
+            w = oracle.scan_card_image_at(wcard, int(g["vseg_y_offset"]), int(g["pattern_type"]), float(g["vseg_score"]),
+                                          base=w)
+            we = oracle.scan_card_expiry(wcard, w)
         stats["max_vseg_err"] = max(stats["max_vseg_err"], abs(float(g["vseg_score"]) - float(w["vseg_score"])))
         if not (np.array_equal(g["offsets"], w["offsets"]) and g["pattern_offset"] == w["pattern_offset"]
                 and g["hseg_score"].view(np.uint32) == w["hseg_score"].view(np.uint32)):
@@ -67,7 +97,6 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
             stats["flag_diff" if near else "unexplained"] += 1
             continue
         # ---- expiry: stripes, groups and rects exact; scores 1e-4 ----
-        we, ge = oracle.scan_card_expiry(wcard, w), gexp[i]
         ns = int(we["n_stripes"])
         if not (ge["n_stripes"] == ns and np.array_equal(ge["stripe_base_row"][:ns], we["stripe_base_row"][:ns])
                 and np.array_equal(ge["stripe_sum"][:ns], we["stripe_sum"][:ns])
@@ -88,11 +117,10 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
             continue
         if k:
             stats["max_expiry_err"] = max(stats["max_expiry_err"], float(np.abs(a["scores"] - b["scores"]).max()))
-    return stats
 
 
 def test_1024_frames_against_oracle(ctx, pkg, oracle):
-    n = int(os.environ.get("DMZ_PARITY_FRAMES", "1024"))  # raise for a one-off sweep (the oracle does ~215 frames/s)
+    n = int(os.environ.get("DMZ_PARITY_FRAMES", "4096"))  # raise for a one-off sweep (the oracle does ~215 frames/s per core)
     y = ctx.alloc(n * pkg.FRAME_BYTES)
     ctx.synth_frames(SEED, 1000, n, y.ptr)
     stats = compare_with_oracle(ctx, pkg, oracle, y, n)

@@ -55,10 +55,17 @@ def test_full_pipeline_matches_oracle(ctx, pkg, oracle):
         assert np.array_equal(gcards[i], wcards[i]), "card %d: %d bytes differ" % (i, (gcards[i] != wcards[i]).sum())
         # scan: indices exact, float scores within 1e-4
         if g["vseg_y_offset"] != w["vseg_y_offset"] or g["pattern_type"] != w["pattern_type"]:
-            # only acceptable as a float near-tie of two window sums
-            assert abs(float(g["vseg_score"]) - float(w["vseg_score"])) < 1e-4, i
+            # only acceptable as a float near-tie of the ORACLE'S two window sums; the later stages are then checked
+            # against the oracle re-run at the device's segmentation
+            _, _, _, vis, amx = oracle.best_n_vseg(wcards[i])
+
+            def wsum(yy, p):
+                return float((vis if p == 1 else amx)[yy:yy + 27].astype(np.float64).sum()) if p else 0.0
+            assert abs(wsum(int(g["vseg_y_offset"]), int(g["pattern_type"])) -
+                       wsum(int(w["vseg_y_offset"]), int(w["pattern_type"]))) < 1e-4, i
             near_ties += 1
-            continue
+            w = oracle.scan_card_image_at(wcards[i], int(g["vseg_y_offset"]), int(g["pattern_type"]),
+                                          float(g["vseg_score"]), base=w)
         assert g["flags"] == w["flags"], (i, g["flags"], w["flags"])
         assert abs(float(g["vseg_score"]) - float(w["vseg_score"])) <= 1e-4
         assert g["n_offsets"] == w["n_offsets"]

@@ -95,3 +95,38 @@ def test_two_queue_schedule_gives_the_same_bytes_as_one_queue(ctx, pkg):
             assert np.array_equal(a, b)
     got = outs[0][0].view(pkg.RESULT_DTYPE)
     assert (got["flags"] & pkg.FLAG_USABLE).astype(bool).sum() > n // 2  # the batch does exercise the expiry CNN
+
+
+def test_matrix_core_loops_are_run_to_run_identical(ctx, pkg):
+    """Gate for the unfenced load -> matrix-instruction loops (expiry conv1, the digit convolution and its chunked FC1):
+    a batch large enough to keep several workgroups resident on every CU is run repeatedly under every schedule that
+    changes which kernels share a CU (one queue / three queues) and with every expiry conv variant; all records must be
+    the same BYTES from run to run within a variant (an operand hazard between co-resident workgroups showed up in round 2
+    as accumulators that differed from run to run; the 1e-4 parity tolerance would not see it)."""
+    n = 8192
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 20000, n, y.ptr)
+    res = ctx.alloc(n * 1024)
+    cards = ctx.alloc(n * pkg.CARD_BYTES)
+    exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
+    try:
+        for mode in (pkg.EXPIRY_CONV_BF16X3, pkg.EXPIRY_CONV_F32, pkg.EXPIRY_CONV_BF16):
+            ctx.set_expiry_conv(mode)
+            first = None
+            for run, two in enumerate((True, False, True, False)):
+                ctx.set_two_queues(two)
+                ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
+                ctx.synchronize()
+                got = (res.download(np.uint8).copy(), exp.download(np.uint8).copy())
+                if first is None:
+                    first = got
+                    e = got[1].view(pkg.EXPIRY_DTYPE)
+                    assert (e["categorised"] > 0).sum() > n // 4 and (e["n_groups"] > 0).sum() > n // 4
+                else:
+                    assert np.array_equal(first[0], got[0]), ("frame records", mode, run)
+                    assert np.array_equal(first[1], got[1]), ("expiry records", mode, run)
+    finally:
+        ctx.set_expiry_conv(pkg.EXPIRY_CONV_BF16X3)
+        ctx.set_two_queues(True)
+        for b in (y, res, cards, exp):
+            b.free()
