@@ -261,6 +261,16 @@ void dmz_YCbCr_to_RGB(IplImage *y, IplImage *cb, IplImage *cr, IplImage **rgb);
 float dmz_focus_score(IplImage *image, bool use_full_image);
 float dmz_brightness_score(IplImage *image, bool use_full_image);
 
+// scan/frame.h:30-46: one rectified card through the number (and expiry) path on the calling thread's default context;
+// the Cython flavour's wrapper keeps usable / hseg / vseg only
+void scan_card_image(IplImage *y, bool collect_card_number, bool scan_expiry, FrameScanResult *result);
+typedef struct {
+  NHorizontalSegmentation hseg;
+  NVerticalSegmentation vseg;
+  bool usable;
+} CythonFrameScanResult;
+void cython_scan_card_image(IplImage *y, CythonFrameScanResult *result);
+
 // scanning (scan/scan.h:51-72)
 void scanner_initialize(ScannerState *state);
 void scanner_reset(ScannerState *state);

@@ -608,19 +608,18 @@ static void fill_expiry_groups(const dmz_hip_expiry_result &x, GroupedRectsList 
   }
 }
 
-void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_expiry,
-                                   FrameScanResult *result) {
-  const bool need_number = state->timeOfCardNumberCompletionInMilliseconds == 0;
-  const bool need_expiry = scan_expiry && (state->expiry_month == 0 || state->expiry_year == 0);  // scan.cpp:44
+// scan_card_image (scan/frame.cpp:24-81) on the device: the number path, and the expiry path of frame.cpp:71-73 when asked.
+// Returns false where the reference asserts (frame.cpp:25-29) or when the device call fails.
+static bool scan_card_image_on(dmz_hip_context *ctx, IplImage *y, bool collect_card_number, bool scan_expiry,
+                               FrameScanResult *result) {
   result->usable = false;
   result->upside_down = false;
   result->expiry_groups.clear();
   result->name_groups.clear();
-  dmz_hip_context *ctx = hip_of(state->dmz);
   if (!ctx || !y || y->roi || y->width != kCreditCardTargetWidth || y->height != kCreditCardTargetHeight ||
       y->nChannels != 1)
-    return;  // frame.cpp:25-29 asserts these
-  // scan_card_image (frame.cpp:24-81) on the device; rows must be 428 bytes apart
+    return false;  // frame.cpp:25-29 asserts these
+  // rows must be 428 bytes apart
   const uint8_t *cards = (const uint8_t *)y->imageData;
   uint8_t *packed = NULL;
   if (y->widthStep != kCreditCardTargetWidth) {
@@ -632,18 +631,48 @@ void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_e
   const size_t card_stride = (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight;
   dmz_hip_frame_result r;
   memset(&r, 0, sizeof(r));
-  // scan_card_image(y, still_need_to_collect_card_number, ...), scan.cpp:48
-  int rc = dmz_hip_scan_cards_batch(ctx, cards, card_stride, 1, need_number ? 0 : DMZ_HIP_SCAN_SKIP_NUMBER, &r);
+  int rc = dmz_hip_scan_cards_batch(ctx, cards, card_stride, 1, collect_card_number ? 0 : DMZ_HIP_SCAN_SKIP_NUMBER, &r);
   dmz_hip_expiry_result x;
   memset(&x, 0, sizeof(x));
-  if (rc == DMZ_HIP_OK && need_expiry) rc = dmz_hip_scan_expiry_batch(ctx, cards, card_stride, 1, &r, &x);  // frame.cpp:71-73
+  if (rc == DMZ_HIP_OK && scan_expiry) rc = dmz_hip_scan_expiry_batch(ctx, cards, card_stride, 1, &r, &x);  // frame.cpp:71-73
   free(packed);
   if (rc != DMZ_HIP_OK) {
     fprintf(stderr, "dmz (HIP): scan failed: %s\n", dmz_hip_last_error(ctx));
-    return;
+    return false;
   }
   fill_frame_result(r, result);
-  if (need_expiry) fill_expiry_groups(x, &result->expiry_groups);
+  if (scan_expiry) fill_expiry_groups(x, &result->expiry_groups);
+  return true;
+}
+
+void scan_card_image(IplImage *y, bool collect_card_number, bool scan_expiry, FrameScanResult *result) {
+  (void)scan_card_image_on(hip_of(NULL), y, collect_card_number, scan_expiry, result);
+}
+
+// scan/frame.cpp:84-98 (the Cython flavour's entry point; the sequence BASELINE configs[0] ends in)
+void cython_scan_card_image(IplImage *y, CythonFrameScanResult *result) {
+  FrameScanResult frameScanResult;
+  frameScanResult.focus_score = 666;
+  frameScanResult.brightness_score = 150;
+  frameScanResult.iso_speed = 400;
+  frameScanResult.shutter_speed = 5;
+  frameScanResult.torch_is_on = 0;
+  frameScanResult.flipped = 0;
+  memset(&frameScanResult.hseg, 0, sizeof(frameScanResult.hseg));
+  memset(&frameScanResult.vseg, 0, sizeof(frameScanResult.vseg));
+  // (the reference also segments the expiry here and drops it: only usable / hseg / vseg leave the call)
+  scan_card_image(y, true, false, &frameScanResult);
+  result->usable = frameScanResult.usable;
+  result->hseg = frameScanResult.hseg;
+  result->vseg = frameScanResult.vseg;
+}
+
+void scanner_add_frame_with_expiry(ScannerState *state, IplImage *y, bool scan_expiry,
+                                   FrameScanResult *result) {
+  const bool need_number = state->timeOfCardNumberCompletionInMilliseconds == 0;
+  const bool need_expiry = scan_expiry && (state->expiry_month == 0 || state->expiry_year == 0);  // scan.cpp:44
+  // scan_card_image(y, still_need_to_collect_card_number, ...), scan.cpp:48
+  if (!scan_card_image_on(hip_of(state->dmz), y, need_number, need_expiry, result)) return;
   if (result->upside_down) return;                     // scan.cpp:49-51
   {                                                    // scan_analytics_record_frame (scan.cpp:53): frame counter + ring
     ScanSessionAnalytics *sa = &state->session_analytics;

@@ -65,6 +65,27 @@ int main(int argc, char **argv) {
   printf("expiry scan_expiry %d aggregated %d seen", state.scan_expiry, (int)state.expiry_groups.size());
   for (size_t g = 0; g < state.expiry_groups.size(); g++) printf(" %d", state.expiry_groups[g].total_seen_count);
   printf(" month %d year %d\n", state.expiry_month, state.expiry_year);
+  {  // the Cython flavour's entry (scan/frame.cpp:84-98) on the first frame's card: the call configs[0]'s sequence ends in
+    IplImage y;
+    memset(&y, 0, sizeof(y));
+    y.nSize = sizeof(y); y.nChannels = 1; y.depth = IPL_DEPTH_8U; y.width = 640; y.height = 480;
+    y.widthStep = 640; y.imageData = (char *)buf.data(); y.imageSize = 640 * 480;
+    dmz_edges edges;
+    dmz_corner_points corners;
+    memset(&corners, 0, sizeof(corners));
+    CythonFrameScanResult cr;
+    memset(&cr, 0, sizeof(cr));
+    if (dmz_detect_edges(&y, NULL, NULL, FrameOrientationLandscapeRight, &edges, &corners)) {
+      IplImage *card = NULL;
+      dmz_transform_card(dmz, &y, corners, FrameOrientationLandscapeRight, false, &card);
+      cython_scan_card_image(card, &cr);
+      dmz_release_image(&card);
+    }
+    printf("cython usable %d y_offset %d pattern %d n_offsets %d offsets", cr.usable, cr.vseg.y_offset, (int)cr.vseg.pattern_type,
+           cr.hseg.n_offsets);
+    for (int d = 0; d < cr.hseg.n_offsets; d++) printf(" %d", cr.hseg.offsets[d]);
+    printf("\n");
+  }
   float m[9];
   dmz_point s[4] = {{106, 105}, {533, 105}, {106, 374}, {533, 374}}, d[4];
   dmz_rect_get_points(dmz_create_rect(0, 0, 427, 269), d);

@@ -56,8 +56,13 @@ def test_sdk_style_call_sequence(tmp_path, oracle, ctx):
         # five identical frames: every group of the frame has been seen five times
         decided = int(ex[-3]) > 0
         assert int(ex[4]) >= 1 and all(int(v) == n or (decided and int(v) >= 3) for v in ex[6:6 + int(ex[4])])
+    # cython_scan_card_image (frame.cpp:84-98): usable / vseg / hseg of the first frame's card
+    cy = out[n + 2].split()
+    assert cy[0] == "cython" and int(cy[2]) == usable and int(cy[4]) == int(want["vseg_y_offset"])
+    assert int(cy[6]) == int(want["pattern_type"]) and int(cy[8]) == int(want["n_offsets"])
+    assert [int(v) for v in cy[10:]] == [int(v) for v in want["offsets"][: int(want["n_offsets"])]]
     m = oracle.calc_persp_transform([106, 105, 533, 105, 106, 374, 533, 374], [0, 0, 427, 0, 0, 269, 427, 269])
-    p = out[n + 2].split()
+    p = out[n + 3].split()
     assert np.float32(p[1]) == m[0] and np.float32(p[2]) == m[2] and np.float32(p[3]) == m[5]
 
 
@@ -77,5 +82,7 @@ def test_host_library_exports_reference_names(pkg):
                  "dmz_scale_point(", "dmz_guide_frame(", "dmz_opposite_orientation(", "dmz_has_opencv()",
                  "dmz_has_neon_runtime()", "dmz_use_vfp3_16()", "dmz_use_gles_warp()", "dmz_set_gles_warp(int)",
                  "dmz_deinterleave_uint8_c2(", "dmz_deinterleave_RGBA_to_R(", "dmz_YCbCr_to_RGB(", "dmz_focus_score(",
-                 "dmz_brightness_score(", "dmz_blur_card(", "dmz_create_point(", "dmz_create_rect(", "dmz_rect_get_points("):
+                 "dmz_brightness_score(", "dmz_blur_card(", "dmz_create_point(", "dmz_create_rect(", "dmz_rect_get_points(",
+                 # scan/frame.h:30-46
+                 "scan_card_image(", "cython_scan_card_image("):
         assert name in syms, name
