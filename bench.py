@@ -46,6 +46,10 @@ import __graft_entry__ as entry  # noqa: E402
 SEED = 0xCA4D10
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # vector == f32-MFMA peak
+# VALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles and SIMD at the 2.4 GHz peak clock
+# (tools/ubench/valu_rates.hip: integer / fp64 / logic instructions issue at 4.5 - 5.3 "2.4 GHz cycles", plain f32 at 2.9,
+# transcendentals at 9.3; the sustained clock under these kernels is 1.8 - 2.2 GHz) -- in wave-instructions ("slots") per s
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
 # ALGORITHMIC bytes / flops per frame and per kernel.
 ALGO = {
     #            bytes/frame                flop/frame
@@ -67,7 +71,7 @@ ALGO = {
 STAGE_KERNELS = {
     "detect": ("k_detect_walk",), "geometry": ("k_homography", "k_geometry"),
     "warp": ("k_warp", "k_warp_windows"), "vseg": ("k_vseg",), "hseg": ("k_hseg",),
-    "digits": ("k_digits",), "expiry_seg": ("k_expiry_seg", "k_expiry_stripes", "k_expiry_slash"),
+    "digits": ("k_digits", "k_digit_patches"), "expiry_seg": ("k_expiry_seg", "k_expiry_stripes", "k_expiry_slash"),
     "expiry_cat": ("k_expiry_cat",),
 }
 # algorithmic bytes per unit of each configuration
@@ -118,6 +122,44 @@ def load_pmc_traffic():
             ent = out.setdefault(name, [0.0, 0.0])
             ent[slot] += mul * mean_kb * 1024.0 / b0  # template instances of one kernel add up
     return out, tag
+
+
+def load_pmc_valu():
+    """{kernel base name: wave64 VALU instructions per frame} from the committed SQ_INSTS_VALU pass named by
+    profiles/CURRENT (rocprofv3 --pmc, kernel-trace only, tools/profile_round.sh; template instances add up)."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        tag = open(os.path.join(pdir, "CURRENT")).read().split()[0]
+    except OSError:
+        return None
+    files = glob.glob(os.path.join(pdir, "%s_pmc_SQ_insts_batch*.txt" % tag))
+    if not files:
+        return None
+    b0 = int(re.search(r"batch(\d+)\.txt$", files[0]).group(1))
+    out, col = {}, None
+    for line in open(files[0]):
+        if line.startswith("#"):
+            continue
+        toks = line.split()
+        if toks and toks[0] == "kernel":
+            col = toks[1:].index("SQ_INSTS_VALU") - len(toks[1:])  # counted from the right: names may contain blanks
+            continue
+        if col is None or len(toks) < 2:
+            continue
+        try:
+            v = float(toks[col])
+        except ValueError:
+            continue
+        name = line[:34].strip().split("<")[0].split("(")[0]
+        out[name] = out.get(name, 0.0) + v / b0
+    return out
+
+
+def stage_valu(valu, stage):
+    if not valu:
+        return None
+    hit = [valu[k] for k in STAGE_KERNELS[stage] if k in valu]
+    return sum(hit) if hit else None
 
 
 def stage_traffic(pmc, stage):
@@ -219,6 +261,30 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def mixed_kind(idx):
+    """kind of frame `idx` (an integer array / tensor of corpus indices) in the mixed corpus: 0-3 no card, 4 upside down,
+    5-9 a card as generated"""
+    return ((idx * 2654435761) % (1 << 32)) % 10
+
+
+def make_mixed_corpus(torch, frames, first_index, seed):
+    """In place: frame i of the corpus (global index first_index + j) by mixed_kind(i) --
+    0-3: no card (dark noise only), 4: the card upside down (the frame rotated by 180 degrees), 5-9: as generated.
+    tests/test_gpu_full_size.py checks frames of each kind, built by the same rule, against the oracle."""
+    dev, n = frames.device, frames.shape[0]
+    idx = torch.arange(first_index, first_index + n, device=dev, dtype=torch.int64)
+    kind = mixed_kind(idx)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    for c0 in range(0, n, 4096):  # (in chunks: bounded temporaries)
+        sl = slice(c0, min(n, c0 + 4096))
+        k = kind[sl]
+        noise = torch.randint(18, 58, frames[sl].shape, generator=g, device=dev, dtype=torch.uint8)
+        frames[sl] = torch.where((k < 4)[:, None, None], noise, frames[sl])
+        frames[sl] = torch.where((k == 4)[:, None, None], torch.flip(frames[sl], dims=(1, 2)), frames[sl])
+    return kind
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +293,12 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="units (frames / crops) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus", choices=("cards", "mixed"), default="cards",
+                    help="cards: every frame shows a card (the metric's corpus); mixed: 40 %% card-less, 10 %% upside-down, "
+                         "50 %% cards (config 4 only; a second line for the gated throughput, not the headline metric)")
+    ap.add_argument("--gather", choices=("auto", "capi", "torch"), default="auto",
+                    help="N > 1: gather of the records on rank 0 through the C-ABI (dmz_hip_gather_records over RCCL) or "
+                         "through torch.distributed; auto = capi when librccl loads and the communicator comes up")
     ap.add_argument("--dry-run", action="store_true", help="no device: shard / gather / timing logic on CPU over gloo")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -278,6 +350,39 @@ def main():
     results_b = [torch.zeros((B, 1024), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     expiry_b = [torch.zeros((B, XB), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if with_expiry else None
     gatherer = sharding.RootGatherer(world) if world > 1 else None
+    # N > 1: the records travel through the C-ABI's gather (dmz_hip_gather_records: ncclSend / ncclRecv into the root on
+    # the context's communication queue) when librccl loads and the communicator comes up; the torch.distributed gather
+    # (same ranges, same asynchrony) otherwise.  At N = 1 there is nothing to gather.
+    use_capi = False
+    root_dst = None
+    if world > 1 and ctx is not None and args.gather in ("auto", "capi"):
+        uid = [None]
+        try:
+            if rank == 0:
+                uid[0] = pkg.comm_unique_id()
+        except pkg.DmzHipError:
+            uid[0] = None
+        dist.broadcast_object_list(uid, src=0)
+        ok = torch.zeros(1, dtype=torch.int32, device=dev)
+        if uid[0] is not None:
+            try:
+                ctx.comm_init(world, rank, uid[0])
+                ok += 1
+            except pkg.DmzHipError as e:
+                print("bench.py: rank %d: C-ABI communicator failed (%s)" % (rank, e), file=sys.stderr)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        use_capi = bool(ok.item())
+        if not use_capi:
+            if args.gather == "capi":
+                sys.exit("bench.py: --gather capi: no RCCL communicator")
+            try:
+                ctx.comm_destroy()
+            except pkg.DmzHipError:
+                pass
+        elif rank == 0:
+            root_dst = [(torch.empty((world * B, 1024), dtype=torch.uint8, device=dev),
+                         torch.empty((world * B, XB), dtype=torch.uint8, device=dev) if with_expiry else None)
+                        for _ in range(nbuf)]
     # every rank scans its own contiguous slice of the synthetic corpus (weak scaling:
     # the corpus is world*B units, rank g owns [g*B, (g+1)*B))
     lo, hi = sharding.shard_range(world * B, rank, world)
@@ -292,6 +397,11 @@ def main():
         if args.config == 3:
             ctx.synth_cards(SEED, lo, B, cards)
         torch.cuda.synchronize(dev)
+        if args.corpus == "mixed":
+            if args.config != 4:
+                sys.exit("bench.py: --corpus mixed goes with --config 4")
+            make_mixed_corpus(torch, frames, lo, SEED + 17 + rank)
+            torch.cuda.synchronize(dev)
 
     def hot_path(k):
         if ctx is None:  # dry run: a pattern rank 0 can verify after the gather
@@ -311,6 +421,16 @@ def main():
     def step():
         k = step_no[0] % nbuf
         step_no[0] += 1
+        if world > 1 and use_capi:
+            # one communication queue per context: its transfers run in order, so waiting for the last gather submitted
+            # also covers the older one that read this pair of buffers
+            if step_no[0] > nbuf:
+                ctx.gather_wait(host_sync=False)
+            hot_path(k)
+            ctx.gather_records(results_b[k], 1024, world * B, 0, root_dst[k][0] if rank == 0 else None)
+            if with_expiry:
+                ctx.gather_records(expiry_b[k], XB, world * B, 0, root_dst[k][1] if rank == 0 else None)
+            return
         if world > 1:
             gatherer.wait(slots=(2 * k, 2 * k + 1))  # only the gathers that still read this pair of buffers
         hot_path(k)
@@ -323,10 +443,15 @@ def main():
         if ctx is not None:
             torch.cuda.synchronize(dev)
 
+    def gather_drain():
+        if world > 1 and use_capi:
+            ctx.gather_wait(host_sync=True)
+        elif world > 1:
+            gatherer.wait()
+
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        gatherer.wait()
+    gather_drain()
     sync()
     if world > 1:
         dist.barrier()
@@ -336,8 +461,7 @@ def main():
         ev0.record(stream)
     for _ in range(args.steps):
         step()
-    if world > 1:
-        gatherer.wait()  # the timed region includes the last exchange
+    gather_drain()  # the timed region includes the last exchange
     if ctx is not None:
         ev1.record(stream)
     sync()
@@ -408,6 +532,7 @@ def main():
         gates = {"found_all": float((res["found_all"] != 0).mean())} if args.config != 3 else {}
         if args.config != 2:
             gates["vseg_ok"] = float(((res["flags"] & pkg.FLAG_VSEG_OK) != 0).mean())
+            gates["upside_down"] = float(((res["flags"] & pkg.FLAG_UPSIDE_DOWN) != 0).mean())
             gates["usable"] = float(((res["flags"] & pkg.FLAG_USABLE) != 0).mean())
         if with_expiry:
             ex = expiry_b[0].cpu().numpy().view(pkg.EXPIRY_DTYPE).reshape(-1)
@@ -430,15 +555,31 @@ def main():
                 ent["hbm_write_B_per_unit"] = round(tr[1])
                 ent["traffic_over_algorithmic"] = round((tr[0] + tr[1]) / by, 3)
             per_stage[name] = ent
+        valu = load_pmc_valu()
+        for name, ent in per_stage.items():
+            sv = stage_valu(valu, name)
+            if sv is not None:
+                ent["valu_slots_per_unit"] = round(sv)
+                ent["valu_issue_frac"] = round(sv * B / (ent["ms_per_step"] * 1e-3) / VALU_ISSUE_PEAK, 4)
+            # stages whose matrix work runs on bf16 operand splits (vseg, slash MLP, digit and expiry convolutions): the
+            # flop figure counts the fp32 product they reproduce, not the bf16 instructions issued
+            ent["TFLOPs_is"] = "fp32-equivalent algorithmic flops"
         dom = max(per_stage, key=lambda k: per_stage[k]["ms_per_step"])
         hbm_frac = per_stage[dom]["GBps"] / HBM_PEAK_GBPS
         fl_frac = per_stage[dom]["TFLOPs"] / FP32_PEAK_TFLOPS
+        vi_frac = per_stage[dom].get("valu_issue_frac", 0.0)
         if hbm_frac >= fl_frac:
             roof = {"bound": "hbm", "achieved": per_stage[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": None}
         else:
             roof = {"bound": "mfma", "achieved": per_stage[dom]["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(fl_frac, 5), "traffic": None}
+        # The contract's two roofs (HBM bytes, matrix flops) are reported as `achieved / peak / frac`; the roof that
+        # actually binds these kernels is VALU instruction issue: reported beside them, and named in `bound` when it is the
+        # largest of the three fractions.
+        if vi_frac > max(hbm_frac, fl_frac):
+            roof["bound_of_contract_roofs"] = roof["bound"]
+            roof["bound"] = "valu_issue"
         roof["kernel"] = STAGE_KERNELS[dom][0]
         roof["launch_ms"] = per_stage[dom]["ms_per_step"]
         roof["algorithmic_bytes_per_launch"] = ALGO[dom][0] * B
@@ -456,7 +597,17 @@ def main():
             if all(t is not None for t in tot):
                 roof["pipeline_traffic_B_per_unit"] = round(sum(t[0] + t[1] for t in tot))
                 roof["pipeline_traffic_over_algorithmic"] = round(sum(t[0] + t[1] for t in tot) / cfg["bytes"], 3)
-
+        if valu:
+            sv_all = [stage_valu(valu, s) for s in per_stage]
+            if all(v is not None for v in sv_all):
+                slots = sum(sv_all)
+                roof["valu_issue"] = {
+                    "slots_per_unit": round(slots), "achieved": round(value / world * slots, 1), "peak": VALU_ISSUE_PEAK,
+                    "unit": "wave64 VALU instructions/s", "frac": round(value / world * slots / VALU_ISSUE_PEAK, 4),
+                    "dominant_kernel": {"kernel": STAGE_KERNELS[dom][0], "slots_per_unit": per_stage[dom].get("valu_slots_per_unit"),
+                                        "frac": per_stage[dom].get("valu_issue_frac")},
+                    "source": "profiles/%s_pmc_SQ_insts_*.txt (SQ_INSTS_VALU per kernel / batch); peak = 1024 SIMDs x 2.4 GHz / 4 "
+                              "cycles per wave64 instruction" % pmc_tag}
         out = {
             "metric": cfg["metric"],
             "value": round(value, 1),
@@ -474,6 +625,9 @@ def main():
                 "workload": "%s, %d synthetic %s per GPU resident in HBM"
                             % (cfg["workload"], B, "640x480 Y frames" if args.config != 3 else "428x270 card crops"),
                 "baseline_config": cfg["name"],
+                **({"corpus": "mixed: 40 % card-less frames, 10 % upside-down cards, 50 % cards (not the metric's corpus: the gated "
+                              "throughput line of SURVEY section 7)"} if args.corpus == "mixed" else {}),
+                **({"gather": "C-ABI dmz_hip_gather_records (RCCL send/recv)" if use_capi else "torch.distributed gather"} if world > 1 else {}),
                 "units_per_gpu": B,
                 "algorithmic_bytes_per_unit": cfg["bytes"],
                 "parallelism": "frame-sharded x%d, asynchronous gather of the 1 KiB result%s records on rank 0"

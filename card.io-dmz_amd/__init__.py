@@ -85,11 +85,29 @@ EXPORTS = (
     "dmz_hip_apply_slash_model", "dmz_hip_apply_expiry_model", "dmz_hip_scan_sessions_batch",
     "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
     "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv", "dmz_hip_set_two_queues",
+    "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
+    "dmz_hip_gather_records", "dmz_hip_gather_wait",
 )
 
 
 class DmzHipError(RuntimeError):
     pass
+
+
+def shard_range(n_total, world, rank):
+    """[first, first + count) of `rank` (dmz_hip_shard_range: the C-ABI's split, no device needed)"""
+    first, count = C.c_int64(), C.c_int64()
+    load_library().dmz_hip_shard_range(n_total, world, rank, C.byref(first), C.byref(count))
+    return first.value, count.value
+
+
+def comm_unique_id():
+    """the 128-byte RCCL id rank 0 hands to every rank's Context.comm_init"""
+    buf = (C.c_char * 128)()
+    rc = load_library().dmz_hip_comm_unique_id(buf)
+    if rc != 0:
+        raise DmzHipError("dmz_hip_comm_unique_id failed with %d (librccl not loadable?)" % rc)
+    return bytes(buf)
 
 
 def build(force=False):
@@ -148,6 +166,13 @@ def load_library():
     lib.dmz_hip_free.argtypes = [vp, vp]
     lib.dmz_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     lib.dmz_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    lib.dmz_hip_shard_range.argtypes = [C.c_int64, i, i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.dmz_hip_shard_range.restype = None
+    lib.dmz_hip_comm_unique_id.argtypes = [vp]
+    lib.dmz_hip_comm_init.argtypes = [vp, vp, i, i]
+    lib.dmz_hip_comm_destroy.argtypes = [vp]
+    lib.dmz_hip_gather_records.argtypes = [vp, vp, sz, C.c_int64, i, vp]
+    lib.dmz_hip_gather_wait.argtypes = [vp, i]
     _lib = lib
     return lib
 
@@ -222,6 +247,22 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.dmz_hip_synchronize(self.h))
+
+    # ---- frames sharded over the GPUs of a node (include/dmz_hip.h: one context per GPU) ----
+    def comm_init(self, world=1, rank=0, unique_id=None):
+        """RCCL communicator of this context; `unique_id` = the 128 bytes rank 0 got from comm_unique_id()"""
+        buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        self._check(self.lib.dmz_hip_comm_init(self.h, buf, world, rank))
+
+    def comm_destroy(self):
+        self._check(self.lib.dmz_hip_comm_destroy(self.h))
+
+    def gather_records(self, local, record_bytes, n_total, root=0, root_dst=None):
+        """asynchronous gather of this rank's shard of n_total records on `root` (device pointers)"""
+        self._check(self.lib.dmz_hip_gather_records(self.h, _ptr(local), record_bytes, n_total, root, _ptr(root_dst)))
+
+    def gather_wait(self, host_sync=True):
+        self._check(self.lib.dmz_hip_gather_wait(self.h, int(host_sync)))
 
     def set_stream(self, stream_handle):
         self._check(self.lib.dmz_hip_set_stream(self.h, stream_handle))

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -54,6 +55,13 @@ struct dmz_hip_context {
   Buf patches;  // equalised digit patches between k_digit_patches and k_digits (digits.hip)
 
   int expiry_conv = DMZ_HIP_EXPIRY_CONV_BF16X3;
+
+  // multi-GPU (dmz_hip_comm_* / dmz_hip_gather_*): the communicator, its own queue, and the events that order it
+  void *comm = nullptr;  // ncclComm_t
+  int comm_world = 1, comm_rank = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
+  bool gather_pending = false;
 
   // profiling
   bool profiling = false;
@@ -697,6 +705,7 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
 void dmz_hip_context_destroy(dmz_hip_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  (void)dmz_hip_comm_destroy(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   resolve_spans(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
@@ -720,6 +729,161 @@ void dmz_hip_context_destroy(dmz_hip_context *ctx) {
   if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frames sharded over the GPUs of a node: shard ranges and the gather of the per-frame records on the root.
+// RCCL is reached through dlopen so that a single-GPU host never loads it.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, struct RcclId, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+struct RcclId {
+  char internal[128];  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES), passed by value like the C API does
+};
+RcclApi *rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = (int (*)(void *))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (int (*)(void **, int, RcclId, int))dlsym(api.lib, "ncclCommInitRank");
+      api.CommDestroy = (int (*)(void *))dlsym(api.lib, "ncclCommDestroy");
+      api.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclSend");
+      api.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclRecv");
+      api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+      api.GetErrorString = (const char *(*)(int))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart ||
+          !api.GroupEnd) {
+        dlclose(api.lib);
+        api.lib = nullptr;
+      }
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+constexpr int kNcclInt8 = 0;  // ncclInt8 / ncclChar
+int rccl_fail(dmz_hip_context *ctx, const char *what, int rc) {
+  RcclApi *r = rccl();
+  ctx->err = std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(rc) : "RCCL error");
+  return DMZ_HIP_ERUNTIME;
+}
+}  // namespace
+
+void dmz_hip_shard_range(int64_t n_total, int world, int rank, int64_t *first, int64_t *count) {
+  int64_t lo = 0, hi = 0;
+  if (world > 0 && rank >= 0 && rank < world && n_total >= 0) {
+    lo = (int64_t)(((__int128)n_total * rank) / world);
+    hi = (int64_t)(((__int128)n_total * (rank + 1)) / world);
+  }
+  if (first) *first = lo;
+  if (count) *count = hi - lo;
+}
+
+int dmz_hip_comm_unique_id(void *id128) {
+  if (!id128) return DMZ_HIP_EINVAL;
+  RcclApi *r = rccl();
+  if (!r) return DMZ_HIP_EUNSUPPORTED;
+  return r->GetUniqueId(id128) == 0 ? DMZ_HIP_OK : DMZ_HIP_ERUNTIME;
+}
+
+int dmz_hip_comm_init(dmz_hip_context *ctx, const void *id128, int world, int rank) {
+  if (!ctx || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return ctx ? fail(ctx, DMZ_HIP_EINVAL, "bad communicator request") : DMZ_HIP_EINVAL;
+  if (ctx->comm || ctx->comm_stream) return fail(ctx, DMZ_HIP_EINVAL, "communicator already initialised");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_in, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_out, hipEventDisableTiming));
+  ctx->comm_world = world;
+  ctx->comm_rank = rank;
+  if (world > 1 || id128) {  // (world = 1 without an id: the local copy needs no RCCL)
+    RcclApi *r = rccl();
+    if (!r) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "librccl could not be loaded");
+    RcclId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    const int rc = r->CommInitRank(&ctx->comm, world, id, rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_comm_destroy(dmz_hip_context *ctx) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+  if (ctx->comm) {
+    RcclApi *r = rccl();
+    if (r) (void)r->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
+  if (ctx->ev_comm_in) (void)hipEventDestroy(ctx->ev_comm_in), ctx->ev_comm_in = nullptr;
+  if (ctx->ev_comm_out) (void)hipEventDestroy(ctx->ev_comm_out), ctx->ev_comm_out = nullptr;
+  if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream), ctx->comm_stream = nullptr;
+  ctx->comm_world = 1, ctx->comm_rank = 0, ctx->gather_pending = false;
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_gather_records(dmz_hip_context *ctx, const void *local, size_t record_bytes, int64_t n_total, int root,
+                           void *root_dst) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!ctx->comm_stream) return fail(ctx, DMZ_HIP_EINVAL, "dmz_hip_comm_init first");
+  const int world = ctx->comm_world, rank = ctx->comm_rank;
+  if (record_bytes == 0 || n_total < 0 || root < 0 || root >= world || (rank == root && !root_dst))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad gather request");
+  int64_t first = 0, count = 0;
+  dmz_hip_shard_range(n_total, world, rank, &first, &count);
+  if (count > 0 && !local) return fail(ctx, DMZ_HIP_EINVAL, "local records missing");
+  // behind everything already enqueued on the context's stream, on a queue of its own
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_in, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_in, 0));
+  if (rank == root && count > 0)
+    HIP_TRY(ctx, hipMemcpyAsync((char *)root_dst + (size_t)first * record_bytes, local, (size_t)count * record_bytes,
+                                hipMemcpyDeviceToDevice, ctx->comm_stream));
+  if (world > 1) {
+    RcclApi *r = rccl();
+    if (!r || !ctx->comm) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "no RCCL communicator");
+    int rc = r->GroupStart();
+    if (rc != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
+    if (rank == root) {
+      for (int p = 0; p < world && rc == 0; p++) {
+        if (p == root) continue;
+        int64_t pf = 0, pc = 0;
+        dmz_hip_shard_range(n_total, world, p, &pf, &pc);
+        if (pc > 0) rc = r->Recv((char *)root_dst + (size_t)pf * record_bytes, (size_t)pc * record_bytes, kNcclInt8, p, ctx->comm, ctx->comm_stream);
+      }
+    } else if (count > 0) {
+      rc = r->Send(local, (size_t)count * record_bytes, kNcclInt8, root, ctx->comm, ctx->comm_stream);
+    }
+    const int rc2 = r->GroupEnd();
+    if (rc != 0) return rccl_fail(ctx, "ncclSend / ncclRecv", rc);
+    if (rc2 != 0) return rccl_fail(ctx, "ncclGroupEnd", rc2);
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_out, ctx->comm_stream));
+  ctx->gather_pending = true;
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_gather_wait(dmz_hip_context *ctx, int host_sync) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!ctx->gather_pending) return DMZ_HIP_OK;
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_out, 0));
+  if (host_sync) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_comm_out));
+  ctx->gather_pending = false;
+  return DMZ_HIP_OK;
 }
 
 int dmz_hip_synchronize(dmz_hip_context *ctx) {

@@ -155,6 +155,11 @@ __device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int 
 __device__ __forceinline__ int lane_below(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ int lane_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 
+// Candidates per wave beyond which the hysteresis leaves the candidate lists for the bitmap flood: a card edge in front of a
+// quiet background leaves a handful of weak candidates per wave, a frame without a card (texture, noise) hundreds -- and the
+// list walk then costs (passes x candidates): 350 - 600 k cycles per box on noise frames against 4 k on card frames.
+constexpr int kDenseList = 96;
+
 // NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
 // given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
 // The reference's branches are kept: a wave whose 62 pixels are all below the low threshold (most of
@@ -219,7 +224,8 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   if (bal) {
     if (cand) {
       const int slot = ncand + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
-      if (slot < seg_cap) seg[slot] = (unsigned short)q;
+      // a list beyond kDenseList entries (or beyond its room) sends the box to the bitmap flood below
+      if (slot < seg_cap && slot < kDenseList) seg[slot] = (unsigned short)q;
       else s_int[3] = 1;
     }
     ncand += __popcll(bal);
@@ -493,11 +499,64 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 
   // (the appends ran on the owner lanes only: lane 1 of every wave is one)
   ncand = __builtin_amdgcn_readlane(ncand, 1);
+
   // ---- D. hysteresis: propagate MAP_EDGE over 8-connected candidates until stable ----
   // (8-adjacency is the same in walk space: rows = steps, columns = lanes)
   {
-    // every wave works through its own list; a wave that ran out of room sends everybody over the whole map
+    // every wave works through its own list; a wave whose list grew long sends the box to the bitmap flood (or, when the
+    // bitmaps do not fit a non-standard box, everybody over the whole map)
     const bool overflow = s_int[3] != 0;
+    constexpr int NW = NT / 64;
+    const int nwords = S * NW;
+    if (overflow && nwords * 16 <= list_cap * 2) {
+      // ---- dense candidates: flood on bitmaps.  Word (s, w) = the 64 lanes of wave w at step s (bits 1..62 own a pixel);
+      // `cand` = NMS survivors above the low threshold (seeds included), `edge` starts as the seeds.  One pass: an edge bit
+      // spreads to the candidate bits among its eight neighbours (three rows, the word's neighbours lend their border bits),
+      // then along the row through runs of candidates (Kogge-Stone fill), until a pass changes nothing: the same fixed point as
+      // the stack flood fill, at a cost that does not depend on how many candidates there are. ----
+      unsigned long long *bcand = (unsigned long long *)list, *bedge = bcand + nwords;
+      for (int a = 0; a < S; a++) {  // this wave's column of words
+        const int q = a * L + c.l;
+        const int fl = inbox ? (int)map[q] : 0;
+        const unsigned long long bc = __ballot((fl & MAP_CAND) != 0), be = __ballot((fl & MAP_EDGE) != 0);
+        if (lane == 0) {
+          bcand[a * NW + wave] = bc & 0x7ffffffffffffffeull;
+          bedge[a * NW + wave] = be & 0x7ffffffffffffffeull;
+        }
+      }
+      __syncthreads();
+      for (;;) {
+        int changed = 0;
+        for (int t = tid; t < nwords; t += NT) {
+          const int a = t / NW, w = t - a * NW;
+          const unsigned long long cm = bcand[t], mine = bedge[t];
+          unsigned long long d = 0ull;
+          for (int r = (a > 0 ? a - 1 : a); r <= (a < S - 1 ? a + 1 : a); r++) {
+            unsigned long long x = bedge[r * NW + w];
+            if (w > 0) x |= (bedge[r * NW + w - 1] >> 62) & 1ull;         // lane 62 of the wave below = our lane 0
+            if (w < NW - 1) x |= ((bedge[r * NW + w + 1] >> 1) & 1ull) << 63;  // lane 1 of the wave above = our lane 63
+            d |= x | (x << 1) | (x >> 1);
+          }
+          unsigned long long g = (d & cm) | mine, pl = cm, pr = cm;
+#pragma unroll
+          for (int sh = 1; sh < 64; sh <<= 1) {
+            g |= (pl & (g << sh)) | (pr & (g >> sh));
+            pl &= pl << sh;
+            pr &= pr >> sh;
+          }
+          if (g != mine) {
+            bedge[t] = g;
+            changed = 1;
+          }
+        }
+        if (!__syncthreads_or(changed)) break;
+      }
+      for (int a = 0; a < S; a++) {
+        const unsigned long long be = bedge[a * NW + wave];
+        if (owner && ((be >> lane) & 1ull)) map[a * L + c.l] = (unsigned char)(map[a * L + c.l] | MAP_EDGE);
+      }
+      __syncthreads();
+    } else {
     const int nitems = overflow ? N : ncand;
     const int i0 = overflow ? tid : lane, istep = overflow ? NT : 64;
     volatile unsigned char *vmap = map;
@@ -543,6 +602,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
         }
       }
       if (!__syncthreads_or(changed)) break;
+    }
     }
   }
   DMZ_STOP_AFTER(4, map[0] + map[N - 1])

@@ -318,6 +318,35 @@ int dmz_hip_free(dmz_hip_context *ctx, void *dptr);
 int dmz_hip_memcpy_h2d(dmz_hip_context *ctx, void *dst, const void *src, size_t bytes);
 int dmz_hip_memcpy_d2h(dmz_hip_context *ctx, void *dst, const void *src, size_t bytes);
 
+/* ---- Frames sharded over the GPUs of a node (north_star: "frames shard embarrassingly across the 8 GPUs
+ * of one node with an RCCL gather of ScannerResult over xGMI").  One process -- or one thread -- per GPU, each with its
+ * own dmz_hip_context; nothing is exchanged while a batch is scanned, the only collective is the gather of the fixed-size
+ * per-frame records on the root.  The reference has no counterpart (it scans one frame per call on one CPU thread): these
+ * are the calls a C++ host adds around its dmz_hip_*_batch loop; bench.py and the tests use the same ones.
+ *
+ * dmz_hip_shard_range: rank r of `world` owns the contiguous frame range [first, first + count); the ranges tile
+ * [0, n_total) in rank order (the same split as card.io-dmz_amd/sharding.py).  Pure arithmetic, no device needed.
+ *
+ * dmz_hip_comm_unique_id / dmz_hip_comm_init: the RCCL communicator of the context.  Rank 0 creates the 128-byte id and the
+ * host distributes it (MPI, a socket, a file: the host's business, as with ncclGetUniqueId); every rank then calls
+ * dmz_hip_comm_init with it.  librccl is loaded at run time (dlopen): a single-GPU host never needs it, and world = 1 works
+ * without it.
+ *
+ * dmz_hip_gather_records: every rank passes its device-resident records (`count` x record_bytes, its shard of a batch of
+ * n_total) -- rank `root` also passes the destination for all n_total records (device memory, frame order); the other
+ * ranks pass NULL.  The exchange is a group of point-to-point transfers into the root's xGMI links (ncclSend / ncclRecv:
+ * 1 / world of an all-gather's traffic), enqueued on the context's communication queue BEHIND the work already on the
+ * context's stream, and returns at once: the next batch's kernels overlap it.  The caller alternates between two record
+ * buffers / two destinations and calls dmz_hip_gather_wait before it reuses a buffer or reads the destination.
+ * dmz_hip_gather_wait makes the context's stream wait for the last gather (and blocks the host if `host_sync`). ---- */
+void dmz_hip_shard_range(int64_t n_total, int world, int rank, int64_t *first, int64_t *count);
+int dmz_hip_comm_unique_id(void *id128);
+int dmz_hip_comm_init(dmz_hip_context *ctx, const void *id128, int world, int rank);
+int dmz_hip_comm_destroy(dmz_hip_context *ctx);
+int dmz_hip_gather_records(dmz_hip_context *ctx, const void *local, size_t record_bytes, int64_t n_total, int root,
+                           void *root_dst);
+int dmz_hip_gather_wait(dmz_hip_context *ctx, int host_sync);
+
 #ifdef __cplusplus
 }
 #endif

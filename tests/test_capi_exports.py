@@ -62,3 +62,23 @@ def test_bench_tables_cover_every_stage(pkg):
     assert [bench.CONFIGS[c]["bytes"] for c in (2, 3, 4)] == [307280, 116584, 423784]
     for c in bench.CONFIGS.values():
         assert set(c["stages"]) <= set(pkg.STAGES)
+
+
+def test_capi_shard_ranges_tile_the_corpus_like_sharding_py(pkg):
+    """dmz_hip_shard_range (no device needed): contiguous, in rank order, covering [0, n) exactly once, and the same split
+    as card.io-dmz_amd/sharding.py uses for the torch.distributed path -- a C++ host and bench.py shard alike."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dmz_sharding", os.path.join(os.path.dirname(pkg.__file__), "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    for n in (0, 1, 7, 4096, 65536, 1048576, 1000003, (1 << 40) + 12345):
+        for world in (1, 2, 3, 4, 8, 13):
+            pos = 0
+            for rank in range(world):
+                first, count = pkg.shard_range(n, world, rank)
+                assert first == pos and count >= 0
+                assert (first, first + count) == sharding.shard_range(n, rank, world)
+                pos += count
+            assert pos == n
+    assert pkg.shard_range(100, 0, 0) == (0, 0) and pkg.shard_range(100, 4, 7) == (0, 0)  # bad requests: empty range

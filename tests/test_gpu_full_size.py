@@ -172,3 +172,44 @@ def test_config3_digit_pass_on_65536_prewarped_crops(ctx, pkg, oracle):
     assert vseg_ok > 0.9 and usable > 0.4
     for b in (cards, res, exp):
         b.free()
+
+
+def test_mixed_corpus_of_the_bench_against_the_oracle(ctx, pkg, oracle):
+    """bench.py --corpus mixed (40 % card-less, 10 % upside-down, 50 % cards; the kinds by bench.mixed_kind, the frames built
+    here on the host by the same rule): every kind occurs, the gates fire as the reference's would (frame.cpp:36-47
+    exits), and every record of a sample equals the oracle's on the same bytes.  Card-less frames are dense-candidate
+    boxes for the detector: its bitmap hysteresis runs here."""
+    import bench
+    n = 192
+    first = 5000
+    kind = bench.mixed_kind(np.arange(first, first + n, dtype=np.int64))
+    assert (kind < 4).sum() > n // 4 and (kind == 4).sum() > n // 32 and (kind > 4).sum() > n // 3
+    rng = np.random.default_rng(77)
+    host = np.stack([oracle.synth_frame(SEED, first + i)[0] for i in range(n)])
+    for i in range(n):
+        if kind[i] < 4:
+            host[i] = rng.integers(18, 58, (480, 640), dtype=np.uint8)
+        elif kind[i] == 4:
+            host[i] = host[i][::-1, ::-1]
+    y = ctx.alloc(host.nbytes).upload(host)
+    res, exp, cards = ctx.alloc(n * 1024), ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize), ctx.alloc(n * pkg.CARD_BYTES)
+    ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
+    ctx.synchronize()
+    got = res.download(pkg.RESULT_DTYPE, n)
+    gexp = exp.download(pkg.EXPIRY_DTYPE, n)
+    assert not got["found_all"][kind < 4].any()                                  # no card: detection stops the frame
+    assert ((got["flags"][kind == 4] & pkg.FLAG_UPSIDE_DOWN) != 0).all()         # upside down: vseg stops it
+    assert ((got["flags"][kind > 4] & pkg.FLAG_VSEG_OK) != 0).all()
+    for i in range(n):
+        w, wcard = oracle.scan_frame(host[i])
+        g = got[i]
+        assert np.array_equal(g["found"], w["found"]) and g["found_all"] == w["found_all"], i
+        m = w["found"] != 0
+        assert np.array_equal(g["rho"][m].view(np.uint32), w["rho"][m].view(np.uint32)), i
+        assert g["flags"] == w["flags"] and g["vseg_y_offset"] == w["vseg_y_offset"], i
+        assert np.array_equal(g["digits"], w["digits"]) and np.array_equal(g["offsets"], w["offsets"]), i
+        assert np.abs(g["scores"] - w["scores"]).max() <= 1e-4, i
+        we = oracle.scan_card_expiry(wcard, w)
+        assert gexp[i]["n_found"] == we["n_found"] and gexp[i]["categorised"] == we["categorised"], i
+    for b in (y, res, exp, cards):
+        b.free()

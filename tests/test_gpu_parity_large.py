@@ -5,7 +5,8 @@ PROVEN from the oracle's values (no blanket allowance):
   * a digit label: the oracle's top two vote scores of that digit are within 2e-4 (|delta| <= 1e-4 on
     every class and a different arg-max imply a top-two gap <= 2e-4);
   * the usable flag: the oracle's number_score is within 1e-3 of the gate value 3 (160 scores summed);
-  * y_offset / pattern: the oracle's OWN window sums of the two (offset, pattern) choices are within 1e-4.
+  * y_offset / pattern: the oracle's OWN window sums of the two (offset, pattern) choices are within 1e-4 -- in its final
+    scores, or in its coarse pass with the fine pass re-run from the other coarse choice (prove_vseg_near_tie).
     A proven tie does not end the frame's check: the oracle's later stages (hseg, digit models, expiry) are re-run at the
     device's segmentation and compared like everything else, so a tie cannot hide a second difference.
 Anything else counts as `unexplained` and fails the test.
@@ -18,6 +19,39 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 SEED = int(os.environ.get("DMZ_PARITY_SEED", "31337"))
+
+
+def prove_vseg_near_tie(oracle, card, gy, gp, wy, wp):
+    """Is the device's (y_offset, pattern) = (gy, gp) a float near-tie of the oracle's (wy, wp)?  Proven from the ORACLE'S
+    own scores only, in one of the two ways n_vseg.cpp:94-168 can come out differently under |delta| <= 1e-4 scores:
+      (a) fine tie: the oracle's final window sums at the two choices are within 1e-4;
+      (b) coarse tie: the coarse pass (every fourth row) has another window sum within 1e-4 of its maximum, and the fine
+          pass run from THAT coarse choice (other rows evaluated, n_vseg.cpp:140-152) ends at the device's choice -- exactly or
+          by a fine tie as in (a)."""
+    def wsum(vis, amx, yy, p):
+        return float((vis if p == 1 else amx)[yy:yy + 27].astype(np.float64).sum()) if p else 0.0
+
+    _, _, _, vis, amx = oracle.best_n_vseg(card)
+    if abs(wsum(vis, amx, gy, gp) - wsum(vis, amx, wy, wp)) < 1e-4:
+        return True
+    cv, ca = np.zeros(270, np.float32), np.zeros(270, np.float32)
+    for yy in range(0, 270, 4):
+        p3 = oracle.applym_vseg(oracle.vseg_row_features(card[yy, 10:418]))
+        cv[yy], ca[yy] = p3[1], p3[2]
+    sums = [(wsum(cv, ca, yy, p), yy, p) for yy in range(0, 244) for p in (1, 2)]
+    top = max(t[0] for t in sums)
+    for sc, yc, pc in sums:
+        if top - sc >= 1e-4:
+            continue
+        fv, fa = cv.copy(), ca.copy()
+        for yy in range(max(0, yc - 8), min(270, yc + 27 + 8)):
+            if fv[yy] == 0 and fa[yy] == 0:
+                p3 = oracle.applym_vseg(oracle.vseg_row_features(card[yy, 10:418]))
+                fv[yy], fa[yy] = p3[1], p3[2]
+        _, y2, p2 = oracle.best_segmentation_for_vseg_scores(fv, fa)
+        if (y2, p2) == (gy, gp) or abs(wsum(fv, fa, gy, gp) - wsum(fv, fa, y2, p2)) < 1e-4:
+            return True
+    return False
 
 
 def compare_with_oracle(ctx, pkg, oracle, y, n):
@@ -69,11 +103,8 @@ def _compare_frame(pkg, oracle, stats, g, ge, gcard, w, wcard, we):
             continue
         stats["card_bytes_diff"] += int((gcard != wcard).sum())
         if g["vseg_y_offset"] != w["vseg_y_offset"] or g["pattern_type"] != w["pattern_type"]:
-            _, _, _, vis, amx = oracle.best_n_vseg(wcard)
-            def wsum(y, p):
-                return float((vis if p == 1 else amx)[y:y + 27].astype(np.float64).sum()) if p else 0.0
-            near = abs(wsum(int(g["vseg_y_offset"]), int(g["pattern_type"])) -
-                       wsum(int(w["vseg_y_offset"]), int(w["pattern_type"]))) < 1e-4
+            near = prove_vseg_near_tie(oracle, wcard, int(g["vseg_y_offset"]), int(g["pattern_type"]),
+                                       int(w["vseg_y_offset"]), int(w["pattern_type"]))
             if not near:
                 stats["unexplained"] += 1
                 continue

@@ -130,3 +130,39 @@ def test_matrix_core_loops_are_run_to_run_identical(ctx, pkg):
         ctx.set_two_queues(True)
         for b in (y, res, cards, exp):
             b.free()
+
+
+def test_capi_gather_at_world_size_one(ctx, pkg):
+    """The C-ABI's multi-GPU entry points on the one GPU a test box has: communicator of one rank (with an RCCL id when
+    librccl loads, and the RCCL-free form), the asynchronous gather of both record types behind a pipeline call, two
+    alternating destinations, wait.  The N > 1 transfers (ncclSend / ncclRecv into the root) cannot run here: they are
+    covered by construction (the same shard ranges, tests/test_capi_exports.py) and by the driver's multi-GPU run."""
+    n = 1024
+    y = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 31000, n, y.ptr)
+    res, exp, cards = ctx.alloc(n * 1024), ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize), ctx.alloc(n * pkg.CARD_BYTES)
+    dst = [(ctx.alloc(n * 1024), ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)) for _ in range(2)]
+    try:
+        uid = pkg.comm_unique_id()
+    except pkg.DmzHipError:
+        uid = None
+    for use_id in ([True, False] if uid is not None else [False]):
+        ctx.comm_init(1, 0, uid if use_id else None)
+        try:
+            for step in range(3):
+                slot = step & 1
+                ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
+                ctx.gather_records(res.ptr, 1024, n, 0, dst[slot][0].ptr)
+                ctx.gather_wait(host_sync=False)  # (one communicator queue: the second record type follows the first)
+                ctx.gather_records(exp.ptr, pkg.EXPIRY_DTYPE.itemsize, n, 0, dst[slot][1].ptr)
+                ctx.gather_wait(host_sync=True)
+                assert np.array_equal(dst[slot][0].download(np.uint8), res.download(np.uint8))
+                assert np.array_equal(dst[slot][1].download(np.uint8), exp.download(np.uint8))
+            with pytest.raises(pkg.DmzHipError):
+                ctx.gather_records(res.ptr, 1024, n, 1, dst[0][0].ptr)  # root outside the communicator
+        finally:
+            ctx.comm_destroy()
+    with pytest.raises(pkg.DmzHipError):
+        ctx.gather_records(res.ptr, 1024, n, 0, dst[0][0].ptr)  # no communicator
+    for b in (y, res, exp, cards, dst[0][0], dst[0][1], dst[1][0], dst[1][1]):
+        b.free()
