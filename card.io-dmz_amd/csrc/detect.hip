@@ -81,7 +81,9 @@ struct WalkCtx {
 };
 
 // across-axis 7-tap pair (derivative {-1,-4,-5,0,5,4,1}, smooth {1,6,15,20,15,6,1}) of the
-// tile row `a` (already clamped to [0, S-1]) centred on this lane.
+// tile row `a` (already clamped to [0, S-1]) centred on this lane.  (Round 3, measured and rejected: the tile with bit 7
+// flipped and two CHAINED v_dot4_i32_i8 per output -- negative taps applied directly, one instruction fewer per step --
+// is bit-exact and 1.4 % slower on the whole kernel: the chained accumulator serialises what were independent dot products.)
 __device__ __forceinline__ void across_taps(const WalkCtx &c, int a, int &ad, int &as) {
   const uint32_t *p = (const uint32_t *)(c.row0 + a * c.sp);
   const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
