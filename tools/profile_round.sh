@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): collects the round's profile summaries into gpurun_out/profiles_$1/
-#   1. bench.py lines: config 4 (default command), config 2, config 3
+#   1. bench.py lines: config 4 (default command), config 2, config 3, and the mixed-corpus line (--corpus mixed)
 #   2. rocprofv3 --kernel-trace --stats of the default bench.py command (minus the CPU baseline leg)
 #   3. PMC passes (separate runs, kernel-trace only): FETCH_SIZE, WRITE_SIZE per kernel (batch 4096)
 #   4. SQ counter passes (batch 8192): VALU / MFMA / LDS / wait counters per kernel
@@ -15,6 +15,7 @@ export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/${TAG}_bench_batch$B.json 2> $OUT/bench.log
 python3 $ROOT/bench.py --config 2 > $OUT/${TAG}_bench_config2_batch4096.json 2>> $OUT/bench.log
 python3 $ROOT/bench.py --config 3 > $OUT/${TAG}_bench_config3_batch65536.json 2>> $OUT/bench.log
+python3 $ROOT/bench.py --corpus mixed --no-cpu-baseline > $OUT/${TAG}_bench_mixed_batch$B.json 2>> $OUT/bench.log
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ROOT/bench.py --batch $B --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 cp $OUT/trace/bench_kernel_stats.csv $OUT/${TAG}_kernel_stats_batch$B.csv 2>/dev/null || find $OUT/trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_batch$B.csv \;
