@@ -25,7 +25,10 @@
 //   * the strip's source window comes from its four corner pixels (a projective map with W
 //     of constant sign is monotone along lines, +-1 px for rounding) and is staged into LDS
 //     with aligned 32-bit row loads (zeros outside the image = BORDER_CONSTANT 0); the four
-//     taps are single-byte LDS reads (lanes are adjacent columns: conflict-free).
+//     taps are single-byte LDS reads.  Lanes are adjacent destination columns, so their taps fall into a handful of
+//     neighbouring dwords -- but a row of taps straddles 128-byte window rows wherever the quad is tilted: the PMC passes
+//     show SQ_LDS_BANK_CONFLICT = 0.31 of the kernel's active LDS cycles (profiles/r2_v8, unchanged in r3), i.e. ~3 % of its
+//     busy cycles; the kernel is VALU-issue bound and the LDS pipe has slack, so the layout stays.
 // Strips whose window exceeds the LDS buffer or whose W changes sign (extreme caller-supplied
 // matrices) take the direct global path.  Blocks are renumbered so that all strips of a
 // frame run on one XCD (block b is dispatched to XCD b % 8) and share its L2.
