@@ -894,6 +894,14 @@ __device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar r
 #ifndef DMZ_XCAT_STOP
 #define DMZ_XCAT_STOP 99
 #endif
+// developer probe: -DDMZ_XC_TIMING prints the cycle counter at the phase boundaries of one categorised workgroup
+#ifdef DMZ_XC_TIMING
+__device__ long long g_xc_t[16];
+__device__ int g_xc_block = -1;
+#define XC_T(i) if (threadIdx.x == 0 && (int)blockIdx.x == g_xc_block) g_xc_t[i] = clock64();
+#else
+#define XC_T(i)
+#endif
 // xf[nd][176] raw inputs -> scores (global, nd x 10 floats at `out`, row stride 10).  MODE = DMZ_HIP_EXPIRY_CONV_*
 template <int MODE>
 __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, const float *__restrict__ xw, CatLds &S, int nd,
@@ -908,6 +916,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   float *const l2 = MODE == DMZ_HIP_EXPIRY_CONV_F32 ? S.xin + 4 * XIN_H * XIN_W : S.c1w;
   float *const l3 = S.c1w + 4 * 120;
   static_assert(sizeof(S.xin3) >= sizeof(S.xin) + 4 * 120 * sizeof(float), "F32 variant: l2 behind the float planes");
+  XC_T(2)
   if (DMZ_XCAT_STOP == 1) return;
   // modelc_bf4dd6c8.cpp:13459: subtract the mean (sequential 176-term sum)
   if (tid < nd) {
@@ -942,6 +951,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     }
     __syncthreads();
   }
+  XC_T(3)
 #pragma unroll 1
   for (int d0 = 0; d0 < nd; d0 += XND) {  // ---- the two convolutions, XND digits per pass ----
   const int ndp = imin(XND, nd - d0);
@@ -1081,6 +1091,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   }
   }  // F32 variant
   __syncthreads();
+  if (d0 == 0) { XC_T(4) } else { XC_T(6) }
   if (DMZ_XCAT_STOP == 2) return;
   // layer 2: valid 5x5 correlation summed over the 50 maps -> 6 x 3, pool 2x3 -> 3, + bias, ReLU,
   // as the GEMM  out[p][n] = sum_k patch[p][k] W[k][n]  (p = digit x 18 positions = 36 rows per pass,
@@ -1181,48 +1192,55 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       // operand fragments, LDS contents and the matrix instruction itself check out one by one
       // (tools/dev/expiry_model_dup.py, tools/ubench/mfma_*_coresident.hip).  The strict form is
       // deterministic in every configuration tried; the other workgroup of the CU hides its bubbles.
-#ifndef DMZ_C2_SCHED  /* developer probe: 0 strict, 1 no fences, 2 B fragments prefetched one k-step ahead */
+#ifndef DMZ_C2_SCHED  /* developer probe: 0 strict, 1 no fences */
 #define DMZ_C2_SCHED 0
 #endif
-      bf16x8 bhn[3], bln[3];
-      if (DMZ_C2_SCHED == 2) load_b(ks0, bhn, bln);
+#ifndef DMZ_C2_KB  /* k-steps whose fragments are requested together, ahead of one wait */
+#define DMZ_C2_KB 1
+#endif
+      // KB k-steps per round: their B fragments (L2) and A fragments (LDS) are requested together, waited for once, then
+      // the 27 (9) matrix instructions of each k-step issue (the load -> wait -> matrix order of the strict form).  The
+      // timeline (-DDMZ_XC_TIMING) shows a k-step as ~2 k cycles of L2 latency + 460 cycles of matrix instructions, but
+      // batching does not pay: KB = 2 (133 registers) 2.12 vs 2.09 ms per 65 536 frames, KB = 3 2.35 -- the other two waves of
+      // the SIMD already fill the matrix pipe while one waits.
+      constexpr int KB = DMZ_C2_KB;
 #pragma unroll 1
-      for (int ks = ks0; ks < ks0 + kPerWave; ks++) {
-        bf16x8 ah[XMT], al[XMT], bh[3], bl[3];
-        if (DMZ_C2_SCHED == 2) {
+      for (int ks = ks0; ks < ks0 + kPerWave; ks += KB) {
+        bf16x8 ah[KB][XMT], al[KB][XMT], bh[KB][3], bl[KB][3];
 #pragma unroll
-          for (int nt = 0; nt < 3; nt++) bh[nt] = bhn[nt], bl[nt] = bln[nt];
-        } else {
-          load_b(ks, bh, bl);
-        }
-        const int R = 4 * ks + kk;
-        const int q7 = (R * 9363) >> 16;  // R / 7 for R < 176
-        const int t = imin(q7, 24);       // run 175 is padding (zero weights)
-        const int i5 = (t * 13) >> 6;     // t / 5
-        const int offA = ((i5 * 7 + (t - 5 * i5)) * C2_MP + 8 * (R - 7 * q7)) * 2;
+        for (int u = 0; u < KB; u++) {
+          const int kq = imin(ks + u, ks0 + kPerWave - 1);  // (a partial last round re-reads its last k-step: not used)
+          load_b(kq, bh[u], bl[u]);
+          const int R = 4 * kq + kk;
+          const int q7 = (R * 9363) >> 16;  // R / 7 for R < 176
+          const int t = imin(q7, 24);       // run 175 is padding (zero weights)
+          const int i5 = (t * 13) >> 6;     // t / 5
+          const int offA = ((i5 * 7 + (t - 5 * i5)) * C2_MP + 8 * (R - 7 * q7)) * 2;
 #pragma unroll
-        for (int mt = 0; mt < XMT; mt++) {
-          ah[mt] = *(const bf16x8 *)(ah_b + baseA[mt] + offA);
-          if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) al[mt] = *(const bf16x8 *)(ah_b + L1_BF16_ELEMS * 2 + baseA[mt] + offA);
+          for (int mt = 0; mt < XMT; mt++) {
+            ah[u][mt] = *(const bf16x8 *)(ah_b + baseA[mt] + offA);
+            if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) al[u][mt] = *(const bf16x8 *)(ah_b + L1_BF16_ELEMS * 2 + baseA[mt] + offA);
+          }
         }
         if (DMZ_C2_SCHED != 1) {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (DMZ_C2_SCHED == 2) {  // next k-step's B fragments travel while this k-step's matrix instructions run
-          load_b(imin(ks + 1, ks0 + kPerWave - 1), bhn, bln);
-          __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
-        for (int mt = 0; mt < XMT; mt++)
+        for (int u = 0; u < KB; u++) {
+          if (ks + u < ks0 + kPerWave) {  // uniform
 #pragma unroll
-          for (int nt = 0; nt < 3; nt++) {
-            if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) {  // small terms first
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-            }
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < XMT; mt++)
+#pragma unroll
+              for (int nt = 0; nt < 3; nt++) {
+                if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) {  // small terms first
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][mt], bh[u][nt], acc[mt][nt], 0, 0, 0);
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][mt], bl[u][nt], acc[mt][nt], 0, 0, 0);
+                }
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][mt], bh[u][nt], acc[mt][nt], 0, 0, 0);
+              }
           }
+        }
         if (DMZ_C2_SCHED != 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1253,6 +1271,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     }
   }
   __syncthreads();  // (the partial sums over l1 are consumed before the next pass writes l1)
+  if (d0 == 0) { XC_T(5) } else { XC_T(7) }
   }  // pass
   if (DMZ_XCAT_STOP == 3) return;
   // FC 120 -> 176, ReLU and FC 176 -> 10, softmax -- on the matrix core, not for its throughput
@@ -1313,6 +1332,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     out[d * 10 + k] = S.es[d * 16 + k] / tree_sum10(S.es + d * 16);
   }
   __syncthreads();
+  XC_T(8)
 }
 
 template <int MODE>
@@ -1361,6 +1381,11 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
     }
   }
   if (!(flags & DMZ_HIP_FLAG_USABLE)) return;  // scan.cpp:57-59
+#ifdef DMZ_XC_TIMING
+  if (tid == 0 && f > n / 2 && S.n_groups > 0) atomicCAS(&g_xc_block, -1, f);
+  __syncthreads();
+#endif
+  XC_T(0)
   if (tid == 0) er->categorised = 1;
   for (int i = tid; i < (int)(sizeof(S.xin3) / 4); i += XC_THREADS) ((uint32_t *)S.xin3)[i] = 0u;  // the zero padding
   __syncthreads();
@@ -1431,7 +1456,13 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
     __syncthreads();
     for (int p = lane; p < 176; p += 64) S.xf[d * 176 + p] = (float)sm[d * 176 + p] * (1.0f / 255.0f);
     __syncthreads();
+    XC_T(1)
     expiry_cnn_block<MODE>(wts, xw, S, 4, &er->groups[g].scores[0][0], tid);
+#ifdef DMZ_XC_TIMING
+    if (threadIdx.x == 0 && f == g_xc_block && g == 0)
+      printf("expiry_cat: prep %lld mean/split %lld conv1a %lld conv2a %lld conv1b %lld conv2b %lld fc %lld\n", g_xc_t[1] - g_xc_t[0],
+             g_xc_t[3] - g_xc_t[2], g_xc_t[4] - g_xc_t[3], g_xc_t[5] - g_xc_t[4], g_xc_t[6] - g_xc_t[5], g_xc_t[7] - g_xc_t[6], g_xc_t[8] - g_xc_t[7]);
+#endif
   }
 }
 
