@@ -195,6 +195,7 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 constexpr int IROWS = 23;    // inter rows: image rows base-4 .. base+18 (clamped to the ROI)
 constexpr int ISTRIDE = 428; // bytes per inter row (107 dwords)
 constexpr int XT_PITCH = 20; // bytes per row of a thresholded character tile (19 used)
+constexpr int kMaxRects = 80;
 struct SegLds {
   // (padded to a multiple of 16 bytes: the compiler merges the column sums' stores into ds_write_b128, and a b64 / b128
   // LDS access off its natural alignment is replayed at 64 cycles per instruction -- SQ_LDS_UNALIGNED_STALL)
@@ -216,7 +217,10 @@ struct SegLds {
       // 16-bit: positions and widths < 432, sums of at most 21 bytes (the workgroup's LDS decides how
       // many stripes a CU holds, and the kernel is latency-bound)
       short rL[64];                      // their left edges
-      short cLeft[64], cTop[64];         // optimised character rects of the current group
+      // optimised character rects of ALL the stripe's groups, one after the other: at most nine groups of at most
+      // (width + 36) / 11 + 1 regridded rects each, widths adding up to <= 428: 77
+      short cLeft[kMaxRects], cTop[kMaxRects];
+      unsigned char cand[kMaxRects];     // slash candidates: index of a window's middle character in cLeft / cTop
       // per slot of optimize_character_rects: 24 entries apart (21 used), so that the wide reads the compiler
       // merges a slot's 18 consecutive entries into start 16-byte aligned (a 42-byte slot pitch made them
       // unaligned ds_read_b128: SQ_LDS_UNALIGNED_STALL was twice the kernel's LDS busy cycles).  Column maxima,
@@ -224,7 +228,8 @@ struct SegLds {
       __attribute__((aligned(16))) short cm[80];
     } b;
   } u;
-  short gL[64], gW[64];                  // surviving local groups
+  // surviving local groups (a group is at least four 9-px rects and groups are a rect apart: at most nine fit 428 columns)
+  short gL[16], gW[16];
 };
 static_assert(sizeof(SegLds) <= 13648, "twelve stripes per CU");
 
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 
   XSEG_STOP(5, G)
   const int g_top = base - 1;  // expanded stripe top; group height 17
+  int rbase = 0, ncand = 0;  // rects / slash candidates of the groups so far
   for (int g = 0; g < G; g++) {
     // ---- regrid_group (169-229) ----
     const int left = L.gL[g], width = L.gW[g];
@@ -700,15 +706,25 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     const unsigned long long kbal = __ballot(keep);
     const int n2 = __popcll(kbal);
     if (keep) {
-      const int pos = __popcll(kbal & lanemask_lt(lane));
-      L.u.b.cLeft[pos] = my_left;
-      L.u.b.cTop[pos] = my_top;
+      const int pos = rbase + __popcll(kbal & lanemask_lt(lane));
+      if (pos < kMaxRects) {  // (always: see SegLds)
+        L.u.b.cLeft[pos] = my_left;
+        L.u.b.cTop[pos] = my_top;
+      }
     }
+    // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623); the windows of five of this group: middle characters 2 .. n2 - 3
+    if (n2 >= 5 && DMZ_XSEG_STOP != 7 && rbase + n2 <= kMaxRects) {
+      if (lane >= 2 && lane < n2 - 2) L.u.b.cand[ncand + lane - 2] = (unsigned char)(rbase + lane);
+      ncand += n2 - 4;
+    }
+    rbase += n2;
     __syncthreads();
-    if (n2 < 5 || DMZ_XSEG_STOP == 7) continue;  // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623)
-
+  }
+  {
     // ---- slash search (643-674): character first+2 of every window of five, sixteen candidates
-    // per pass.  applym_730c4cbd (176 -> 80 tanh -> 2 softmax): the hidden layer is a
+    // per pass -- over the candidates of ALL the stripe's groups (round 3: a pass per group fetched the 90 KB of weight
+    // fragments from L2 and built / evaluated sixteen rows for the two or three candidates a group has; a stripe's groups
+    // together rarely exceed sixteen).  applym_730c4cbd (176 -> 80 tanh -> 2 softmax): the hidden layer is a
     // [16 x 176] x [176 x 80] product.  On v_mfma_f32_16x16x32_bf16 with EXACT operand splits: a Scharr
     // sample is an integer <= 4080 = 256 a + b, and 256 a and b are both bf16 numbers; the weights,
     // pre-divided by 255 (the reference's x = s * (1/255) differs from that by one float rounding
@@ -720,11 +736,12 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     // Each k-step: the 15 weight fragments are requested (L2), the A fragments are built meanwhile, all
     // loads are waited for, and only then the 30 matrix instructions issue (see the conv2 loop below for
     // why no load stays in flight across them).
-    for (int p0 = 2; p0 + 2 < n2; p0 += 16) {
-      const int nc = imin(16, n2 - 2 - p0);
+    for (int k0 = 0; k0 < ncand; k0 += 16) {
+      const int nc = imin(16, ncand - k0);
       const int m = lane & 15, kk = lane >> 4;
       const bool live = m < nc;
-      const int pl = live ? L.u.b.cLeft[p0 + m] : 0, pt = live ? L.u.b.cTop[p0 + m] - (base - 3) : 0;
+      const int ci = live ? (int)L.u.b.cand[k0 + m] : 0;
+      const int pl = live ? L.u.b.cLeft[ci] : 0, pt = live ? L.u.b.cTop[ci] - (base - 3) : 0;
       // (buffer loads: descriptor + 32-bit lane offset + scalar fragment offset, no 64-bit address arithmetic)
       const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(xw + dmzx::SLASH_B3), 0, 3 * dmzx::SLASH_KSTEPS * 5 * 64 * 16, 0x00020000);
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       for (int q = 0; q < nc; q++) {
         if (!((hitmask >> q) & 1u)) continue;
         if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
-          const int first = p0 + q - 2;
+          const int first = (int)L.u.b.cand[k0 + q] - 2;
           int top = L.u.b.cTop[first], gleft = L.u.b.cLeft[first], gwidth = SCW, gheight = SCH;
           for (int i = 0; i < 5; i++) {
             const int ct = L.u.b.cTop[first + i], cl = L.u.b.cLeft[first + i];
@@ -834,7 +851,6 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
         n_emitted++;
       }
     }
-    __syncthreads();
   }
   if (lane == 0) sg->n = n_emitted;
 }
