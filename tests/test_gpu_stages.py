@@ -235,6 +235,29 @@ def test_detect_other_frame_geometries(ctx, pkg, oracle):
         assert res[0]["found_all"] == want["found_all"]
 
 
+def test_dense_candidate_boxes_in_every_kernel_form(ctx, pkg, oracle):
+    """Card-less texture leaves hundreds of weak Canny candidates per wave: the hysteresis then floods on bitmaps instead of
+    walking candidate lists (detect.hip).  Noise, a noisy ramp and a fine checker at the standard geometry (single-walk
+    kernels, parked and register-resident gradients) and at 1280x720 / 320x240 / portrait (generic two-walk kernels, other
+    wave counts): found flags, lines and corners equal the oracle's."""
+    rng = np.random.default_rng(404)
+    for (h, w, orientation) in ((480, 640, 3), (720, 1280, 3), (240, 320, 3), (640, 480, 1), (480, 640, 4)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames = [rng.integers(18, 58, (h, w), dtype=np.uint8),
+                  ((xx * 0.2 + yy * 0.1 + rng.integers(0, 50, (h, w))) % 256).astype(np.uint8),
+                  (np.where(((xx // 3) + (yy // 3)) % 2 == 0, 200, 40) + rng.integers(0, 30, (h, w))).astype(np.uint8)]
+        for k, frame in enumerate(frames):
+            res = np.zeros(1, pkg.RESULT_DTYPE)
+            ctx.detect(frame[None], 1, res, width=w, height=h, orientation=orientation)
+            want = oracle.detect_edges(frame, orientation=orientation)
+            assert np.array_equal(res[0]["found"], want["found"]), (w, h, orientation, k)
+            m = want["found"] != 0
+            assert np.array_equal(res[0]["rho"][m].view(np.uint32), want["rho"][m].view(np.uint32)), (w, h, k)
+            assert np.array_equal(res[0]["theta"][m].view(np.uint32), want["theta"][m].view(np.uint32)), (w, h, k)
+            assert np.array_equal(res[0]["corners"].view(np.uint32), want["corners"].view(np.uint32)), (w, h, k)
+            assert res[0]["found_all"] == want["found_all"]
+
+
 def test_padded_and_unaligned_strides(ctx, pkg, oracle):
     """frames embedded in larger buffers: row stride > width (aligned and odd), frame stride with slack, an
     unaligned base address -- detect and transform must not depend on the packing"""
