@@ -422,14 +422,13 @@ def main():
         k = step_no[0] % nbuf
         step_no[0] += 1
         if world > 1 and use_capi:
-            # one communication queue per context: its transfers run in order, so waiting for the last gather submitted
-            # also covers the older one that read this pair of buffers
-            if step_no[0] > nbuf:
-                ctx.gather_wait(host_sync=False)
+            # only the gathers that still read this pair of buffers (slots 2k, 2k + 1): the other pair's stay in flight
+            ctx.gather_wait(2 * k, host_sync=False)
+            ctx.gather_wait(2 * k + 1, host_sync=False)
             hot_path(k)
-            ctx.gather_records(results_b[k], 1024, world * B, 0, root_dst[k][0] if rank == 0 else None)
+            ctx.gather_records(results_b[k], 1024, world * B, 0, root_dst[k][0] if rank == 0 else None, slot=2 * k)
             if with_expiry:
-                ctx.gather_records(expiry_b[k], XB, world * B, 0, root_dst[k][1] if rank == 0 else None)
+                ctx.gather_records(expiry_b[k], XB, world * B, 0, root_dst[k][1] if rank == 0 else None, slot=2 * k + 1)
             return
         if world > 1:
             gatherer.wait(slots=(2 * k, 2 * k + 1))  # only the gathers that still read this pair of buffers
@@ -445,7 +444,7 @@ def main():
 
     def gather_drain():
         if world > 1 and use_capi:
-            ctx.gather_wait(host_sync=True)
+            ctx.gather_wait(-1, host_sync=True)
         elif world > 1:
             gatherer.wait()
 

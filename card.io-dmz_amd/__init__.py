@@ -171,8 +171,8 @@ def load_library():
     lib.dmz_hip_comm_unique_id.argtypes = [vp]
     lib.dmz_hip_comm_init.argtypes = [vp, vp, i, i]
     lib.dmz_hip_comm_destroy.argtypes = [vp]
-    lib.dmz_hip_gather_records.argtypes = [vp, vp, sz, C.c_int64, i, vp]
-    lib.dmz_hip_gather_wait.argtypes = [vp, i]
+    lib.dmz_hip_gather_records.argtypes = [vp, vp, sz, C.c_int64, i, vp, i]
+    lib.dmz_hip_gather_wait.argtypes = [vp, i, i]
     _lib = lib
     return lib
 
@@ -257,12 +257,13 @@ class Context:
     def comm_destroy(self):
         self._check(self.lib.dmz_hip_comm_destroy(self.h))
 
-    def gather_records(self, local, record_bytes, n_total, root=0, root_dst=None):
-        """asynchronous gather of this rank's shard of n_total records on `root` (device pointers)"""
-        self._check(self.lib.dmz_hip_gather_records(self.h, _ptr(local), record_bytes, n_total, root, _ptr(root_dst)))
+    def gather_records(self, local, record_bytes, n_total, root=0, root_dst=None, slot=0):
+        """asynchronous gather of this rank's shard of n_total records on `root` (device pointers); `slot` names it for the wait"""
+        self._check(self.lib.dmz_hip_gather_records(self.h, _ptr(local), record_bytes, n_total, root, _ptr(root_dst), slot))
 
-    def gather_wait(self, host_sync=True):
-        self._check(self.lib.dmz_hip_gather_wait(self.h, int(host_sync)))
+    def gather_wait(self, slot=-1, host_sync=True):
+        """wait for the slot's last gather (slot < 0: all of them)"""
+        self._check(self.lib.dmz_hip_gather_wait(self.h, slot, int(host_sync)))
 
     def set_stream(self, stream_handle):
         self._check(self.lib.dmz_hip_set_stream(self.h, stream_handle))

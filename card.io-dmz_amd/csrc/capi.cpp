@@ -60,8 +60,8 @@ struct dmz_hip_context {
   void *comm = nullptr;  // ncclComm_t
   int comm_world = 1, comm_rank = 0;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
-  bool gather_pending = false;
+  hipEvent_t ev_comm_in = nullptr, ev_comm_out[DMZ_HIP_GATHER_SLOTS] = {};
+  bool gather_pending[DMZ_HIP_GATHER_SLOTS] = {};
 
   // profiling
   bool profiling = false;
@@ -808,7 +808,7 @@ int dmz_hip_comm_init(dmz_hip_context *ctx, const void *id128, int world, int ra
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_in, hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_out, hipEventDisableTiming));
+  for (int i = 0; i < DMZ_HIP_GATHER_SLOTS; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_out[i], hipEventDisableTiming));
   ctx->comm_world = world;
   ctx->comm_rank = rank;
   if (world > 1 || id128) {  // (world = 1 without an id: the local copy needs no RCCL)
@@ -831,18 +831,22 @@ int dmz_hip_comm_destroy(dmz_hip_context *ctx) {
     ctx->comm = nullptr;
   }
   if (ctx->ev_comm_in) (void)hipEventDestroy(ctx->ev_comm_in), ctx->ev_comm_in = nullptr;
-  if (ctx->ev_comm_out) (void)hipEventDestroy(ctx->ev_comm_out), ctx->ev_comm_out = nullptr;
+  for (int i = 0; i < DMZ_HIP_GATHER_SLOTS; i++) {
+    if (ctx->ev_comm_out[i]) (void)hipEventDestroy(ctx->ev_comm_out[i]), ctx->ev_comm_out[i] = nullptr;
+    ctx->gather_pending[i] = false;
+  }
   if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream), ctx->comm_stream = nullptr;
-  ctx->comm_world = 1, ctx->comm_rank = 0, ctx->gather_pending = false;
+  ctx->comm_world = 1, ctx->comm_rank = 0;
   return DMZ_HIP_OK;
 }
 
 int dmz_hip_gather_records(dmz_hip_context *ctx, const void *local, size_t record_bytes, int64_t n_total, int root,
-                           void *root_dst) {
+                           void *root_dst, int slot) {
   if (!ctx) return DMZ_HIP_EINVAL;
   if (!ctx->comm_stream) return fail(ctx, DMZ_HIP_EINVAL, "dmz_hip_comm_init first");
   const int world = ctx->comm_world, rank = ctx->comm_rank;
-  if (record_bytes == 0 || n_total < 0 || root < 0 || root >= world || (rank == root && !root_dst))
+  if (record_bytes == 0 || n_total < 0 || root < 0 || root >= world || (rank == root && !root_dst) || slot < 0 ||
+      slot >= DMZ_HIP_GATHER_SLOTS)
     return fail(ctx, DMZ_HIP_EINVAL, "bad gather request");
   int64_t first = 0, count = 0;
   dmz_hip_shard_range(n_total, world, rank, &first, &count);
@@ -872,17 +876,19 @@ int dmz_hip_gather_records(dmz_hip_context *ctx, const void *local, size_t recor
     if (rc != 0) return rccl_fail(ctx, "ncclSend / ncclRecv", rc);
     if (rc2 != 0) return rccl_fail(ctx, "ncclGroupEnd", rc2);
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_out, ctx->comm_stream));
-  ctx->gather_pending = true;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_out[slot], ctx->comm_stream));
+  ctx->gather_pending[slot] = true;
   return DMZ_HIP_OK;
 }
 
-int dmz_hip_gather_wait(dmz_hip_context *ctx, int host_sync) {
-  if (!ctx) return DMZ_HIP_EINVAL;
-  if (!ctx->gather_pending) return DMZ_HIP_OK;
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_out, 0));
-  if (host_sync) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_comm_out));
-  ctx->gather_pending = false;
+int dmz_hip_gather_wait(dmz_hip_context *ctx, int slot, int host_sync) {
+  if (!ctx || slot >= DMZ_HIP_GATHER_SLOTS) return DMZ_HIP_EINVAL;
+  for (int i = slot < 0 ? 0 : slot; i < (slot < 0 ? DMZ_HIP_GATHER_SLOTS : slot + 1); i++) {
+    if (!ctx->gather_pending[i]) continue;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_out[i], 0));
+    if (host_sync) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_comm_out[i]));
+    ctx->gather_pending[i] = false;
+  }
   return DMZ_HIP_OK;
 }
 

@@ -336,16 +336,19 @@ int dmz_hip_memcpy_d2h(dmz_hip_context *ctx, void *dst, const void *src, size_t 
  * n_total) -- rank `root` also passes the destination for all n_total records (device memory, frame order); the other
  * ranks pass NULL.  The exchange is a group of point-to-point transfers into the root's xGMI links (ncclSend / ncclRecv:
  * 1 / world of an all-gather's traffic), enqueued on the context's communication queue BEHIND the work already on the
- * context's stream, and returns at once: the next batch's kernels overlap it.  The caller alternates between two record
- * buffers / two destinations and calls dmz_hip_gather_wait before it reuses a buffer or reads the destination.
- * dmz_hip_gather_wait makes the context's stream wait for the last gather (and blocks the host if `host_sync`). ---- */
+ * context's stream, and returns at once: the next batch's kernels overlap it.  `slot` (0 .. DMZ_HIP_GATHER_SLOTS - 1) names
+ * the gather for the wait: the caller alternates between two record buffers / two destinations (one slot per buffer and
+ * record type) and calls dmz_hip_gather_wait(slot) before it reuses that buffer or reads that destination -- the gather of
+ * batch k-1 stays in flight while batch k is scanned.  dmz_hip_gather_wait makes the context's stream wait for the slot's
+ * last gather (and blocks the host if `host_sync`); slot < 0 = every slot. ---- */
+#define DMZ_HIP_GATHER_SLOTS 8
 void dmz_hip_shard_range(int64_t n_total, int world, int rank, int64_t *first, int64_t *count);
 int dmz_hip_comm_unique_id(void *id128);
 int dmz_hip_comm_init(dmz_hip_context *ctx, const void *id128, int world, int rank);
 int dmz_hip_comm_destroy(dmz_hip_context *ctx);
 int dmz_hip_gather_records(dmz_hip_context *ctx, const void *local, size_t record_bytes, int64_t n_total, int root,
-                           void *root_dst);
-int dmz_hip_gather_wait(dmz_hip_context *ctx, int host_sync);
+                           void *root_dst, int slot);
+int dmz_hip_gather_wait(dmz_hip_context *ctx, int slot, int host_sync);
 
 #ifdef __cplusplus
 }

@@ -152,14 +152,17 @@ def test_capi_gather_at_world_size_one(ctx, pkg):
             for step in range(3):
                 slot = step & 1
                 ctx.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
-                ctx.gather_records(res.ptr, 1024, n, 0, dst[slot][0].ptr)
-                ctx.gather_wait(host_sync=False)  # (one communicator queue: the second record type follows the first)
-                ctx.gather_records(exp.ptr, pkg.EXPIRY_DTYPE.itemsize, n, 0, dst[slot][1].ptr)
-                ctx.gather_wait(host_sync=True)
+                ctx.gather_wait(2 * slot, host_sync=False)      # the gathers that used this pair of destinations two steps ago
+                ctx.gather_wait(2 * slot + 1, host_sync=False)
+                ctx.gather_records(res.ptr, 1024, n, 0, dst[slot][0].ptr, slot=2 * slot)
+                ctx.gather_records(exp.ptr, pkg.EXPIRY_DTYPE.itemsize, n, 0, dst[slot][1].ptr, slot=2 * slot + 1)
+                ctx.gather_wait(-1, host_sync=True)
                 assert np.array_equal(dst[slot][0].download(np.uint8), res.download(np.uint8))
                 assert np.array_equal(dst[slot][1].download(np.uint8), exp.download(np.uint8))
             with pytest.raises(pkg.DmzHipError):
                 ctx.gather_records(res.ptr, 1024, n, 1, dst[0][0].ptr)  # root outside the communicator
+            with pytest.raises(pkg.DmzHipError):
+                ctx.gather_records(res.ptr, 1024, n, 0, dst[0][0].ptr, slot=99)
         finally:
             ctx.comm_destroy()
     with pytest.raises(pkg.DmzHipError):
