@@ -30,7 +30,7 @@ ORIENTATION_LANDSCAPE_LEFT = 4
 
 FLAG_USABLE, FLAG_UPSIDE_DOWN, FLAG_VSEG_OK, FLAG_WARPED = 1, 2, 4, 8
 SCAN_ONLY_WARPED, SCAN_SKIP_NUMBER = 1, 2
-EXPIRY_CONV_F32, EXPIRY_CONV_BF16X3, EXPIRY_CONV_BF16 = 0, 1, 2
+EXPIRY_CONV_F32, EXPIRY_CONV_BF16X3, EXPIRY_CONV_BF16, EXPIRY_CONV_F16X3 = 0, 1, 2, 3
 OPT_TRUNCATE_CORNERS = 1
 OPT_UPSAMPLE = 2
 STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
@@ -269,7 +269,7 @@ class Context:
         self._check(self.lib.dmz_hip_set_stream(self.h, stream_handle))
 
     def set_expiry_conv(self, mode):
-        """arithmetic of the expiry CNN's conv2: EXPIRY_CONV_F32 / _BF16X3 (default) / _BF16"""
+        """arithmetic of the expiry CNN's convolutions: EXPIRY_CONV_F16X3 (default) / _F32 / _BF16X3 / _BF16"""
         self._check(self.lib.dmz_hip_set_expiry_conv(self.h, mode))
 
     def set_two_queues(self, on):

@@ -54,7 +54,7 @@ struct dmz_hip_context {
   Buf hits, mats, skip, synth, stage_in, stage_cb, stage_cr, stage_cards, stage_res, cards, misc, xstage, stage_exp, stage_sess;
   Buf patches;  // equalised digit patches between k_digit_patches and k_digits (digits.hip)
 
-  int expiry_conv = DMZ_HIP_EXPIRY_CONV_BF16X3;
+  int expiry_conv = DMZ_HIP_EXPIRY_CONV_F16X3;
 
   // multi-GPU (dmz_hip_comm_* / dmz_hip_gather_*): the communicator, its own queue, and the events that order it
   void *comm = nullptr;  // ncclComm_t
@@ -125,6 +125,29 @@ uint16_t bf16_rne(float v) {
   memcpy(&u, &v, 4);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
+}
+// float <-> IEEE half (round to nearest even, subnormals kept; |v| < 65504)
+uint16_t f16_rne(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const int e = (int)((u >> 23) & 0xffu) - 127;
+  uint32_t m = (u & 0x7fffffu) | 0x800000u;  // 24-bit significand
+  if (((u >> 23) & 0xffu) == 0) return (uint16_t)sign;  // zero / float subnormal
+  if (e > 15) return (uint16_t)(sign | 0x7c00u);
+  // value = m * 2^(e - 23); half: normal unit 2^(e - 10) for e >= -14, subnormal unit 2^-24
+  const int shift = e >= -14 ? 13 : 13 + (-14 - e);
+  if (shift > 25) return (uint16_t)sign;
+  const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  uint32_t r = q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u);
+  // r carries the implicit bit (normal) or not (subnormal); adding the exponent field absorbs a carry out of the mantissa
+  const uint32_t bits = e >= -14 ? ((uint32_t)(e + 15 - 1) << 10) + r : r;
+  return (uint16_t)(sign | bits);
+}
+float f16_to_float(uint16_t h) {
+  const int e = (h >> 10) & 31, m = h & 1023;
+  const float mag = e == 0 ? ldexpf((float)m, -24) : ldexpf((float)(m | 1024), e - 25);
+  return (h & 0x8000u) ? -mag : mag;
 }
 float bf16_to_float(uint16_t h) {
   const uint32_t u = (uint32_t)h << 16;
@@ -629,6 +652,9 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
             const size_t idx = (((size_t)ks * 3 + nt) * 64 + lane) * 8 + e;
             bh[idx] = h;
             bl[idx] = bf16_rne(wv - bf16_to_float(h));
+            const uint16_t fh = f16_rne(wv);
+            ((uint16_t *)(xw.data() + dmzx::CONV2_FH))[idx] = fh;
+            ((uint16_t *)(xw.data() + dmzx::CONV2_FL))[idx] = f16_rne(wv - f16_to_float(fh));
           }
     // slash hidden layer: W1[n][k] / 255 (the 1/255 of the input scaling folded in, in double) as three bf16 parts
     uint16_t *sb = (uint16_t *)(xw.data() + dmzx::SLASH_B3);
@@ -665,6 +691,27 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
           const float r2 = r1 - bf16_to_float(p1);
           const uint16_t parts[3] = {p0, p1, bf16_rne(r2)};
           for (int part = 0; part < 3; part++) cb[(((size_t)part * 4 + nt) * 64 + lane) * 8 + e] = parts[part];
+          uint16_t *cf = (uint16_t *)(xw.data() + dmzx::CONV1_F2);
+          const uint16_t fh = f16_rne(wv);
+          cf[(((size_t)0 * 4 + nt) * 64 + lane) * 8 + e] = fh;
+          cf[(((size_t)1 * 4 + nt) * 64 + lane) * 8 + e] = f16_rne(wv - f16_to_float(fh));
+        }
+  }
+  {
+    // the dense layers of the expiry CNN in fragment order (lane = (unit n = lane & 15, k = lane >> 4), k-step ks = 4 g + e)
+    const float *hw = w + dmzw::EXPIRY + dmzw::X_HW, *lw = w + dmzw::EXPIRY + dmzw::X_LW;
+    for (int nt = 0; nt < 11; nt++)
+      for (int g = 0; g < 8; g++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 4; e++) {
+            const int ks = 4 * g + e, k = 4 * ks + (lane >> 4), nn = 16 * nt + (lane & 15);
+            xw[dmzx::FC1_F + (((size_t)nt * 8 + g) * 64 + lane) * 4 + e] = ks < 30 ? hw[nn * 120 + k] : 0.0f;
+          }
+    for (int g = 0; g < 11; g++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 4; e++) {
+          const int ks = 4 * g + e, k = 4 * ks + (lane >> 4), nn = lane & 15;
+          xw[dmzx::FC2_F + ((size_t)g * 64 + lane) * 4 + e] = nn < 10 ? lw[nn * 176 + k] : 0.0f;
         }
   }
   // cv::bilateralFilter(d = 3, sigmaColor = 0.95, sigmaSpace = 2/3) tables, expiry_categorize.cpp:52-57
@@ -914,7 +961,8 @@ int dmz_hip_set_two_queues(dmz_hip_context *ctx, int enable) {
 
 int dmz_hip_set_expiry_conv(dmz_hip_context *ctx, int mode) {
   if (!ctx) return DMZ_HIP_EINVAL;
-  if (mode != DMZ_HIP_EXPIRY_CONV_F32 && mode != DMZ_HIP_EXPIRY_CONV_BF16X3 && mode != DMZ_HIP_EXPIRY_CONV_BF16)
+  if (mode != DMZ_HIP_EXPIRY_CONV_F32 && mode != DMZ_HIP_EXPIRY_CONV_BF16X3 && mode != DMZ_HIP_EXPIRY_CONV_BF16 &&
+      mode != DMZ_HIP_EXPIRY_CONV_F16X3)
     return fail(ctx, DMZ_HIP_EINVAL, "unknown expiry conv mode");
   ctx->expiry_conv = mode;
   return DMZ_HIP_OK;

@@ -121,7 +121,16 @@ constexpr int SLASH_B3 = CONV2_BL + C2_KSTEPS * 3 * 64 * 4;
 // expiry CNN conv1 for v_mfma_f32_16x16x32_bf16: B[k = tap (25, padded to 32)][n = map (50, padded to 64)] split into three
 // bf16 parts, fragments [part 3][n-tile 4][lane 64][8 bf16]
 constexpr int CONV1_B3 = SLASH_B3 + 3 * SLASH_KSTEPS * 5 * 64 * 4;
-constexpr int TOTAL = CONV1_B3 + 3 * 4 * 64 * 4;
+// the same two convolutions for v_mfma_f32_16x16x32_f16 (F16X3): operands in two f16 parts (hi = f16 rounding, lo = f16
+// rounding of the remainder), fragments as above: conv2 [k-step 44][n-tile 3][lane 64][8 f16] twice, conv1 [part 2][n-tile 4][lane 64][8 f16]
+constexpr int CONV2_FH = CONV1_B3 + 3 * 4 * 64 * 4;
+constexpr int CONV2_FL = CONV2_FH + C2_KSTEPS * 3 * 64 * 4;
+constexpr int CONV1_F2 = CONV2_FL + C2_KSTEPS * 3 * 64 * 4;
+// the two dense layers of the expiry CNN as B fragments of v_mfma_f32_16x16x4_f32, four k-steps of a lane per 16 bytes:
+// FC1 [n-tile 11][k-group 8][lane 64][4] (k-steps 30, 31 are zero), FC2 [k-group 11][lane 64][4] (units 10 .. 15 are zero)
+constexpr int FC1_F = CONV1_F2 + 2 * 4 * 64 * 4;
+constexpr int FC2_F = FC1_F + 11 * 8 * 64 * 4;
+constexpr int TOTAL = FC2_F + 11 * 64 * 4;
 }  // namespace dmzx
 // offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)
 namespace dmzw {

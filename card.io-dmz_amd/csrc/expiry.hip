@@ -907,6 +907,24 @@ __device__ __forceinline__ float tree_sum10(const float *v) {  // Eigen scalar r
   return a + b;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// the 16-bit matrix-core product of the variant: f16 operands (F16X3) or bf16 operands, fp32 accumulation
+template <int MODE>
+__device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (MODE == DMZ_HIP_EXPIRY_CONV_F16X3)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// v = hi + lo to 2^-22 |v| (or 2^-25: f16 subnormals, which the matrix core keeps -- tools/ubench/mfma_f16_denorm.hip)
+__device__ __forceinline__ void split_f16(float v, unsigned short &hi, unsigned short &lo) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
+
 #ifndef DMZ_XCAT_STOP
 #define DMZ_XCAT_STOP 99
 #endif
@@ -948,6 +966,8 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     const int at = d * XIN_H * XIN_W + (r + 4) * XIN_W + (c + 4);
     if (MODE == DMZ_HIP_EXPIRY_CONV_F32) {
       S.xin[at] = v;
+    } else if (MODE == DMZ_HIP_EXPIRY_CONV_F16X3) {
+      split_f16(v, S.xin3[0][at], S.xin3[1][at]);
     } else {
       // v = hi + mid + lo exactly (three bf16 numbers: 24 bits of mantissa)
       const __bf16 hi = (__bf16)v;
@@ -980,11 +1000,13 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     // packed-FMA form (below, F32 variant).  A tile's sixteen rows are four pool windows x their four positions, so the
     // four accumulator elements of a lane ARE a pool window: max, bias, ReLU, hi/lo split for conv2, one store pair.
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
-    bf16x8 wb[3][4];
+    // F16X3: both operands in two f16 parts (22 bits) and the three products that carry 2^-22 (lo*hi, hi*lo, hi*hi)
+    constexpr int NP = MODE == DMZ_HIP_EXPIRY_CONV_F16X3 ? 2 : 3;
+    u32x4 wb[NP][4];
     {
-      const bf16x8 *bsrc = (const bf16x8 *)(xw + dmzx::CONV1_B3) + lane;
+      const u32x4 *bsrc = (const u32x4 *)(xw + (MODE == DMZ_HIP_EXPIRY_CONV_F16X3 ? dmzx::CONV1_F2 : dmzx::CONV1_B3)) + lane;
 #pragma unroll
-      for (int part = 0; part < 3; part++)
+      for (int part = 0; part < NP; part++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) wb[part][nt] = bsrc[(part * 4 + nt) * 64];
     }
@@ -1005,17 +1027,16 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       const int d = (W * 937) >> 16, pos = W - 70 * d;     // W / 70 for W < 280
       const int pr = (pos * 37) >> 8, pc = pos - 7 * pr;   // pos / 7 for pos < 70
       const int base = (d0 + d) * XIN_H * XIN_W + (2 * pr + ((m16 >> 1) & 1)) * XIN_W + 2 * pc + (m16 & 1);
-      uint32_t a[3][4];
+      uint32_t a[NP][4];
 #pragma unroll
-      for (int part = 0; part < 3; part++) {
+      for (int part = 0; part < NP; part++) {
         const lds_vu16 pl = (lds_vu16)S.xin3[part] + base;
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) a[part][e2] = (uint32_t)pl[toff[2 * e2]] | ((uint32_t)pl[toff[2 * e2 + 1]] << 16);
       }
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){a[0][0], a[0][1], a[0][2], a[0][3]});
-      const bf16x8 am = __builtin_bit_cast(bf16x8, (u32x4){a[1][0], a[1][1], a[1][2], a[1][3]});
-      const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){a[2][0], a[2][1], a[2][2], a[2][3]});
+      const u32x4 ah = {a[0][0], a[0][1], a[0][2], a[0][3]};
+      const u32x4 am = {a[1][0], a[1][1], a[1][2], a[1][3]};                    // (F16X3: the low part)
+      const u32x4 al = {a[NP - 1][0], a[NP - 1][1], a[NP - 1][2], a[NP - 1][3]};
       // (no fence here, unlike the conv2 loop: the B fragments are resident and the A fragments come from LDS only; run to
       // run identical on 4 x 16 384 frames, tools/dev/det_variant.sh, and 4.6 % faster than the fenced form)
 #ifdef DMZ_C1_FENCE  /* developer probe */
@@ -1025,17 +1046,19 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       f32x4 acc[4];
       // small terms first; the four map tiles are independent chains, interleaved
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wb[0][nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int nt = 0; nt < 4; nt++) acc[nt] = mma16<MODE>(al, wb[0][nt], (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[2][nt], acc[nt], 0, 0, 0);
+      for (int nt = 0; nt < 4; nt++) acc[nt] = mma16<MODE>(ah, wb[NP - 1][nt], acc[nt]);
+      if constexpr (NP == 3) {
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wb[1][nt], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; nt++) acc[nt] = mma16<MODE>(am, wb[1][nt], acc[nt]);
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wb[0][nt], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; nt++) acc[nt] = mma16<MODE>(am, wb[0][nt], acc[nt]);
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[1][nt], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; nt++) acc[nt] = mma16<MODE>(ah, wb[1][nt], acc[nt]);
+      }
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wb[0][nt], acc[nt], 0, 0, 0);
+      for (int nt = 0; nt < 4; nt++) acc[nt] = mma16<MODE>(ah, wb[0][nt], acc[nt]);
 #ifdef DMZ_C1_FENCE
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1048,10 +1071,14 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
           if (n < C2_MP) {  // maps 50 .. 55 multiply zero weights in conv2 but must be finite: written as 0
             const float mx = fmaxf(fmaxf(acc[nt][0], acc[nt][1]), fmaxf(acc[nt][2], acc[nt][3]));
             const float v = n < 50 ? fmaxf(mx + bias[nt], 0.0f) : 0.0f;
-            const __bf16 hi = (__bf16)v;
-            const __bf16 lo = (__bf16)(v - (float)hi);
-            l1h[Wd * C2_MP + n] = __builtin_bit_cast(unsigned short, hi);
-            l1l[Wd * C2_MP + n] = __builtin_bit_cast(unsigned short, lo);
+            if constexpr (MODE == DMZ_HIP_EXPIRY_CONV_F16X3) {
+              split_f16(v, l1h[Wd * C2_MP + n], l1l[Wd * C2_MP + n]);
+            } else {
+              const __bf16 hi = (__bf16)v;
+              const __bf16 lo = (__bf16)(v - (float)hi);
+              l1h[Wd * C2_MP + n] = __builtin_bit_cast(unsigned short, hi);
+              l1l[Wd * C2_MP + n] = __builtin_bit_cast(unsigned short, lo);
+            }
           }
         }
       }
@@ -1188,16 +1215,17 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
         baseA[mt] = (d * 70 + r * 7 + c) * C2_MP * 2;
       }
       const unsigned char *ah_b = (const unsigned char *)l1h;
-      const bf16x8 *bhp = (const bf16x8 *)(xw + dmzx::CONV2_BH) + lane;
-      const bf16x8 *blp = (const bf16x8 *)(xw + dmzx::CONV2_BL) + lane;
+      constexpr bool kSplit = MODE == DMZ_HIP_EXPIRY_CONV_BF16X3 || MODE == DMZ_HIP_EXPIRY_CONV_F16X3;  // three products
+      const u32x4 *bhp = (const u32x4 *)(xw + (MODE == DMZ_HIP_EXPIRY_CONV_F16X3 ? dmzx::CONV2_FH : dmzx::CONV2_BH)) + lane;
+      const u32x4 *blp = (const u32x4 *)(xw + (MODE == DMZ_HIP_EXPIRY_CONV_F16X3 ? dmzx::CONV2_FL : dmzx::CONV2_BL)) + lane;
       constexpr int kPerWave = C2_KSTEPS / 4;
       static_assert(kPerWave * 4 == C2_KSTEPS, "k-steps split evenly over the four waves");
       const int ks0 = wave * kPerWave;
-      auto load_b = [&](int ks, bf16x8 (&h)[3], bf16x8 (&l)[3]) {
+      auto load_b = [&](int ks, u32x4 (&h)[3], u32x4 (&l)[3]) {
 #pragma unroll
         for (int nt = 0; nt < 3; nt++) {
           h[nt] = bhp[(ks * 3 + nt) * 64];
-          if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) l[nt] = blp[(ks * 3 + nt) * 64];
+          if (kSplit) l[nt] = blp[(ks * 3 + nt) * 64];
         }
       };
       // One k-step: all operand fragments loaded and WAITED FOR, then the 45 (15) matrix instructions, with
@@ -1222,7 +1250,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
       constexpr int KB = DMZ_C2_KB;
 #pragma unroll 1
       for (int ks = ks0; ks < ks0 + kPerWave; ks += KB) {
-        bf16x8 ah[KB][XMT], al[KB][XMT], bh[KB][3], bl[KB][3];
+        u32x4 ah[KB][XMT], al[KB][XMT], bh[KB][3], bl[KB][3];
 #pragma unroll
         for (int u = 0; u < KB; u++) {
           const int kq = imin(ks + u, ks0 + kPerWave - 1);  // (a partial last round re-reads its last k-step: not used)
@@ -1234,8 +1262,8 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
           const int offA = ((i5 * 7 + (t - 5 * i5)) * C2_MP + 8 * (R - 7 * q7)) * 2;
 #pragma unroll
           for (int mt = 0; mt < XMT; mt++) {
-            ah[u][mt] = *(const bf16x8 *)(ah_b + baseA[mt] + offA);
-            if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) al[u][mt] = *(const bf16x8 *)(ah_b + L1_BF16_ELEMS * 2 + baseA[mt] + offA);
+            ah[u][mt] = *(const u32x4 *)(ah_b + baseA[mt] + offA);
+            if (kSplit) al[u][mt] = *(const u32x4 *)(ah_b + L1_BF16_ELEMS * 2 + baseA[mt] + offA);
           }
         }
         if (DMZ_C2_SCHED != 1) {
@@ -1249,11 +1277,11 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
             for (int mt = 0; mt < XMT; mt++)
 #pragma unroll
               for (int nt = 0; nt < 3; nt++) {
-                if (MODE == DMZ_HIP_EXPIRY_CONV_BF16X3) {  // small terms first
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][mt], bh[u][nt], acc[mt][nt], 0, 0, 0);
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][mt], bl[u][nt], acc[mt][nt], 0, 0, 0);
+                if (kSplit) {  // small terms first
+                  acc[mt][nt] = mma16<MODE>(al[u][mt], bh[u][nt], acc[mt][nt]);
+                  acc[mt][nt] = mma16<MODE>(ah[u][mt], bl[u][nt], acc[mt][nt]);
                 }
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][mt], bh[u][nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = mma16<MODE>(ah[u][mt], bh[u][nt], acc[mt][nt]);
               }
           }
         }
@@ -1294,29 +1322,49 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   // (four rows of sixteen are real) but because every lane's weight loads are then independent:
   // the VALU version walked each output's 120 (176) weights as one dependent fmaf chain fed from L2.
   // The accumulation order is unchanged: v_mfma_f32_16x16x4_f32 adds its four k in order.
+  // Weights in fragment order (dmzx::FC1_F / FC2_F: four k-steps of a lane per 16-byte load), ALL of a wave's tiles and
+  // the output layer's weights requested up front: one L2 round trip for the two layers instead of one per tile and two
+  // for the output layer (the timeline showed 21 - 69 k cycles here under load, of ~170 k per group).
+  f32x4 b2v[11];
   {
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
-    const float *fc1t = xw + dmzx::FC1_T;
+    const f32x4 *fc1f = (const f32x4 *)(xw + dmzx::FC1_F) + lane;
+    if (wave == 0) {
+      const f32x4 *fc2f = (const f32x4 *)(xw + dmzx::FC2_F) + lane;
+#pragma unroll
+      for (int g = 0; g < 11; g++) b2v[g] = fc2f[g * 64];
+    }
+    // (two tiles' fragments in flight; the third tile's take the first tile's registers once that tile is done)
+    f32x4 bv[2][8];
+    auto load_tile = [&](int r, f32x4 (&dst)[8]) {
+      const int nt = imin(wave + 4 * r, 10);
+#pragma unroll
+      for (int g = 0; g < 8; g++) dst[g] = fc1f[(nt * 8 + g) * 64];
+    };
+    load_tile(0, bv[0]);
+    load_tile(1, bv[1]);
     float a1[30];
 #pragma unroll
     for (int ks = 0; ks < 30; ks++) a1[ks] = m16 < nd ? l2[m16 * 120 + 4 * ks + kk] : 0.0f;
-    for (int nt = wave; nt < 11; nt += XC_THREADS / 64) {
-      float b1[30];
 #pragma unroll
-      for (int ks = 0; ks < 30; ks++) b1[ks] = fc1t[(4 * ks + kk) * 176 + 16 * nt + m16];
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < 3; r++) {
+      const int nt = wave + 4 * r;
+      if (nt < 11) {  // uniform per wave
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int ks = 0; ks < 30; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], b1[ks], acc, 0, 0, 0);
-      // D: row (digit) = 4 * kk + v, column (unit) = m16: the digits sit in the lanes with kk == 0
-      if (kk == 0) {
-        const int j = 16 * nt + m16;
-        const float hb = xm[dmzw::X_HB + j];
+        for (int ks = 0; ks < 30; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], bv[r & 1][ks >> 2][ks & 3], acc, 0, 0, 0);
+        if (r == 0) load_tile(2, bv[0]);
+        // D: row (digit) = 4 * kk + v, column (unit) = m16: the digits sit in the lanes with kk == 0
+        if (kk == 0) {
+          const int j = 16 * nt + m16;
+          const float hb = xm[dmzw::X_HB + j];
 #pragma unroll
-        for (int v = 0; v < 4; v++)
-          if (v < nd) {
-            const float t = acc[v] + hb;
-            l3[v * 176 + j] = t > 0.0f ? t : 0.0f;
-          }
+          for (int v = 0; v < 4; v++)
+            if (v < nd) {
+              const float t = acc[v] + hb;
+              l3[v * 176 + j] = t > 0.0f ? t : 0.0f;
+            }
+        }
       }
     }
   }
@@ -1324,17 +1372,11 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   if (tid < 64) {
     const int m16 = tid & 15, kk = tid >> 4;
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-    for (int k0 = 0; k0 < 44; k0 += 22) {  // (two halves: 44 + 44 operand registers at once do not fit three waves per SIMD)
-      float a2[22], b2[22];
+    float a2[44];
 #pragma unroll
-      for (int ks = 0; ks < 22; ks++) {
-        a2[ks] = m16 < nd ? l3[m16 * 176 + 4 * (k0 + ks) + kk] : 0.0f;
-        b2[ks] = m16 < 10 ? xm[dmzw::X_LW + m16 * 176 + 4 * (k0 + ks) + kk] : 0.0f;
-      }
+    for (int ks = 0; ks < 44; ks++) a2[ks] = m16 < nd ? l3[m16 * 176 + 4 * ks + kk] : 0.0f;
 #pragma unroll
-      for (int ks = 0; ks < 22; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ks], b2[ks], acc, 0, 0, 0);
-    }
+    for (int ks = 0; ks < 44; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ks], b2v[ks >> 2][ks & 3], acc, 0, 0, 0);
     if (kk == 0 && m16 < 10) {
       const float lb = xm[dmzw::X_LB + m16];
 #pragma unroll
@@ -1411,29 +1453,37 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
   unsigned char *gp = S.l1raw;                             // 4 x 176 gradient / equalised patch
   unsigned char *sm = gp + 4 * 176;                        // 4 x 176 smoothed
   unsigned int *hist = (unsigned int *)(gp + 2 * 4 * 176); // 4 x 256
+  unsigned char *roil = gp + 2 * 4 * 176 + 4 * 256 * 4;    // 4 x [16 rows][16 bytes]: the characters' pixels
   for (int g = 0; g < n_groups; g++) {
     // (the thread index is made opaque per group: hoisted out of this loop, the index arithmetic of all the phases below
     // is some eighty registers of loop invariants -- more than three waves per SIMD leave)
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
-    // ---- prepare_image_for_cat (expiry_categorize.cpp:35-70): wave d = character d ----
+    // ---- prepare_image_for_cat (expiry_categorize.cpp:35-70): wave d = character d, on its own until the CNN (a wave's
+    // LDS operations execute in order: no workgroup barrier between the steps).  The 16 x 11 pixels arrive as one aligned
+    // dword per lane (the taps are clamped to the character, so nothing else is read) instead of fifteen byte loads. ----
     const int d = wave, ci = d < 2 ? d : d + 1;
     const int left = S.hdr[g][9 + ci], top = S.hdr[g][4 + ci];
-    const uint8_t *roi = card + (size_t)top * CW + left;
+    unsigned char *rl = roil + d * 256;
+    {
+      const int row = lane >> 2, dw = (left >> 2) + (lane & 3);
+      if (dw <= (left + TW - 1) >> 2) ((uint32_t *)rl)[lane] = *(const uint32_t *)(card + (size_t)(top + row) * CW + 4 * dw);
+    }
+    const unsigned char *roi = rl + (left & 3);
     for (int i = lane; i < 256; i += 64) hist[d * 256 + i] = 0u;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     for (int p = lane; p < 176; p += 64) {
       const int r = p / TW, c = p - r * TW;
       const int ru = r > 0 ? r - 1 : r, rd = r < TH - 1 ? r + 1 : r;
       const int cl = c > 0 ? c - 1 : c, cr = c < TW - 1 ? c + 1 : c;
-      const int nn = roi[ru * CW + c], ww = roi[r * CW + cl], cc = roi[r * CW + c], ee = roi[r * CW + cr],
-                ss = roi[rd * CW + c];
+      const int nn = roi[ru * 16 + c], ww = roi[r * 16 + cl], cc = roi[r * 16 + c], ee = roi[r * 16 + cr],
+                ss = roi[rd * 16 + c];
       const int gv = imax(nn, imax(ww, imax(cc, imax(ee, ss)))) - imin(nn, imin(ww, imin(cc, imin(ee, ss))));
       gp[d * 176 + p] = (unsigned char)gv;
       atomicAdd(&hist[d * 256 + gv], 1u);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     {  // llcv_equalize_hist LUT (stats.cpp:135-151): 4 bins per lane
       unsigned int *h = hist + d * 256;
       const int h0 = (int)h[lane * 4 + 0], h1 = (int)h[lane * 4 + 1], h2 = (int)h[lane * 4 + 2], h3 = (int)h[lane * 4 + 3];
@@ -1446,12 +1496,12 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
           l2 = __float2int_rn((float)c2 * scale), l3 = __float2int_rn((float)c3 * scale);
       l0 = imin(255, imax(0, l0)), l1 = imin(255, imax(0, l1)), l2 = imin(255, imax(0, l2)), l3 = imin(255, imax(0, l3));
       if (lane == 0) l0 = 0;
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
       h[lane * 4 + 0] = (unsigned)l0, h[lane * 4 + 1] = (unsigned)l1, h[lane * 4 + 2] = (unsigned)l2, h[lane * 4 + 3] = (unsigned)l3;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     for (int p = lane; p < 176; p += 64) gp[d * 176 + p] = (unsigned char)hist[d * 256 + gp[d * 176 + p]];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     // cv::bilateralFilter(d = 3, BORDER_REPLICATE), generic accumulation order
     for (int p = lane; p < 176; p += 64) {
       const int r = p / TW, c = p - r * TW;
@@ -1469,7 +1519,7 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
       }
       sm[d * 176 + p] = (unsigned char)__float2int_rn(sum / wsum);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     for (int p = lane; p < 176; p += 64) S.xf[d * 176 + p] = (float)sm[d * 176 + p] * (1.0f / 255.0f);
     __syncthreads();
     XC_T(1)
@@ -1532,9 +1582,10 @@ int dmz_configure_expiry(void) {
 #ifndef DMZ_XCAT_PAD  /* developer ablation: extra dynamic LDS = fewer workgroups per CU */
 #define DMZ_XCAT_PAD 0
 #endif
-  const void *kernels[6] = {(const void *)k_expiry_cat<0>,   (const void *)k_expiry_cat<1>,   (const void *)k_expiry_cat<2>,
-                            (const void *)k_expiry_model<0>, (const void *)k_expiry_model<1>, (const void *)k_expiry_model<2>};
-  for (int i = 0; i < 6; i++) {
+  const void *kernels[8] = {(const void *)k_expiry_cat<0>,   (const void *)k_expiry_cat<1>,   (const void *)k_expiry_cat<2>,
+                            (const void *)k_expiry_cat<3>,   (const void *)k_expiry_model<0>, (const void *)k_expiry_model<1>,
+                            (const void *)k_expiry_model<2>, (const void *)k_expiry_model<3>};
+  for (int i = 0; i < 8; i++) {
     hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(CatLds) + DMZ_XCAT_PAD);
     if (e != hipSuccess) return (int)e;
@@ -1560,6 +1611,9 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
   else if (conv_mode == DMZ_HIP_EXPIRY_CONV_BF16)
     hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_BF16>, grid, block, lds, s, weights, xw, tables, cards, card_stride, n,
                        results, stage, out);
+  else if (conv_mode == DMZ_HIP_EXPIRY_CONV_F16X3)
+    hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_F16X3>, grid, block, lds, s, weights, xw, tables, cards, card_stride, n,
+                       results, stage, out);
   else
     hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_BF16X3>, grid, block, lds, s, weights, xw, tables, cards, card_stride,
                        n, results, stage, out);
@@ -1576,6 +1630,8 @@ void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *x
     hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_F32>, grid, block, sizeof(CatLds), s, weights, xw, x, n, out);
   else if (conv_mode == DMZ_HIP_EXPIRY_CONV_BF16)
     hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_BF16>, grid, block, sizeof(CatLds), s, weights, xw, x, n, out);
+  else if (conv_mode == DMZ_HIP_EXPIRY_CONV_F16X3)
+    hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_F16X3>, grid, block, sizeof(CatLds), s, weights, xw, x, n, out);
   else
     hipLaunchKernelGGL(k_expiry_model<DMZ_HIP_EXPIRY_CONV_BF16X3>, grid, block, sizeof(CatLds) + DMZ_XCAT_PAD, s, weights, xw, x, n, out);
 }

@@ -170,19 +170,22 @@ int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_
 int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
                               const dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry);
 
-/* Arithmetic of the expiry CNN's second convolution (applyc_bf4dd6c8, models/expiry/modelc_bf4dd6c8.cpp:
- * 12688-12724: 72 x 1250 x 40 per group, the largest contraction of the path), BASELINE configs[3]
+/* Arithmetic of the expiry CNN's convolutions (applyc_bf4dd6c8, models/expiry/modelc_bf4dd6c8.cpp:
+ * 12688-12724: conv2 is 72 x 1250 x 40 per group, the largest contraction of the path), BASELINE configs[3]
  * "bf16 conv with fp32 parity check":
- *   F32     v_mfma_f32_16x16x4_f32, the reference's k-ordered fp32 accumulation;
- *   BF16X3  (default) v_mfma_f32_16x16x32_bf16 on operands split into bf16 high and low parts,
- *           a.b ~ ah.bh + ah.bl + al.bh with fp32 accumulation: products carry ~2^-16 relative
- *           error, the scores stay within the 1e-4 contract (measured against F32 by bench.py
- *           and tests/test_gpu_expiry.py);
+ *   F16X3   (default) v_mfma_f32_16x16x32_f16 on operands split into an f16 rounding and the f16 rounding of the
+ *           remainder (22 bits), a.b ~ al.bh + ah.bl + ah.bh with fp32 accumulation, both convolutions: the
+ *           scores agree with the fp32 variant and the CPU oracle to ~2e-6, inside the reference's own
+ *           known-answer tolerance 1e-5 (tests/test_gpu_expiry.py, bench.py);
+ *   F32     v_mfma_f32_16x16x4_f32 / packed FMAs, the reference's k-ordered fp32 accumulation;
+ *   BF16X3  the same three products on bf16 parts (16 bits): ~2^-16 per product, scores within the 1e-4 contract
+ *           (the default up to round 2);
  *   BF16    one bf16 pass (~2^-8 per product): reported beside the others, not a parity mode.
  * Everything else on the expiry path is unaffected. */
 #define DMZ_HIP_EXPIRY_CONV_F32 0
 #define DMZ_HIP_EXPIRY_CONV_BF16X3 1
 #define DMZ_HIP_EXPIRY_CONV_BF16 2
+#define DMZ_HIP_EXPIRY_CONV_F16X3 3
 int dmz_hip_set_expiry_conv(dmz_hip_context *ctx, int mode);
 
 /* dmz_hip_pipeline_expiry_batch schedules the expiry segmentation (which depends on the number row only) on a

@@ -110,7 +110,7 @@ def test_matrix_core_loops_are_run_to_run_identical(ctx, pkg):
     cards = ctx.alloc(n * pkg.CARD_BYTES)
     exp = ctx.alloc(n * pkg.EXPIRY_DTYPE.itemsize)
     try:
-        for mode in (pkg.EXPIRY_CONV_BF16X3, pkg.EXPIRY_CONV_F32, pkg.EXPIRY_CONV_BF16):
+        for mode in (pkg.EXPIRY_CONV_F16X3, pkg.EXPIRY_CONV_BF16X3, pkg.EXPIRY_CONV_F32, pkg.EXPIRY_CONV_BF16):
             ctx.set_expiry_conv(mode)
             first = None
             for run, two in enumerate((True, False, True, False)):
@@ -126,7 +126,7 @@ def test_matrix_core_loops_are_run_to_run_identical(ctx, pkg):
                     assert np.array_equal(first[0], got[0]), ("frame records", mode, run)
                     assert np.array_equal(first[1], got[1]), ("expiry records", mode, run)
     finally:
-        ctx.set_expiry_conv(pkg.EXPIRY_CONV_BF16X3)
+        ctx.set_expiry_conv(pkg.EXPIRY_CONV_F16X3)
         ctx.set_two_queues(True)
         for b in (y, res, cards, exp):
             b.free()
