@@ -889,11 +889,12 @@ struct CatLds {
   // every group; after layer 1 the outputs of layer 2 (4 x 120) and of the hidden layer (4 x 176) -- 48 KB in all: three
   // workgroups per CU
   union {
-    float xf[4 * 176];
+    __attribute__((aligned(16))) float xf[4 * 176];  // (16 bytes: the mean's reads are ds_read_b128)
     __attribute__((aligned(8))) float c1w[25 * 50];
   };
   short hdr[DMZ_HIP_EXPIRY_MAX_GROUPS][16];
   int n_groups;
+  float cwt[256], swt[8];  // the bilateral filter's tables (DmzExpiryTables)
 };
 static_assert(4 * 120 + 4 * 176 <= 25 * 50, "l2 + l3 overlay the conv1 weights");
 static_assert(sizeof(CatLds) <= 163840 / (XND == 1 ? 4 : 3), "three (four) workgroups per CU");
@@ -954,9 +955,16 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   if (DMZ_XCAT_STOP == 1) return;
   // modelc_bf4dd6c8.cpp:13459: subtract the mean (sequential 176-term sum)
   if (tid < nd) {
-    const float *x = S.xf + tid * 176;
-    float m = x[0];
-    for (int i = 1; i < 176; i++) m = m + x[i];
+    const f32x4 *x4 = (const f32x4 *)(S.xf + tid * 176);  // (the same sequential order, four terms per LDS read)
+    float m = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < 44; i++) {
+      const f32x4 v = x4[i];
+      m = i == 0 ? v[0] : m + v[0];
+      m = m + v[1];
+      m = m + v[2];
+      m = m + v[3];
+    }
     S.mean[tid] = m / 176.0f;
   }
   __syncthreads();
@@ -1446,6 +1454,8 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
   XC_T(0)
   if (tid == 0) er->categorised = 1;
   for (int i = tid; i < (int)(sizeof(S.xin3) / 4); i += XC_THREADS) ((uint32_t *)S.xin3)[i] = 0u;  // the zero padding
+  S.cwt[tid] = tab->color_weight[tid];  // (XC_THREADS = 256 entries)
+  if (tid < 8) S.swt[tid] = tab->space_weight[tid];
   __syncthreads();
   const int n_groups = S.n_groups;
   const uint8_t *card = cards + (size_t)f * card_stride;
@@ -1513,7 +1523,7 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const int val = e[rr[k] * TW + cq[k]];
-        const float w = tab->space_weight[k] * tab->color_weight[iabs(val - val0)];
+        const float w = S.swt[k] * S.cwt[iabs(val - val0)];
         sum += (float)val * w;
         wsum += w;
       }
