@@ -611,11 +611,14 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
         for (int lane = 0; lane < 64; lane++)
           for (int e = 0; e < 8; e++) {
             const int j = 16 * wv + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+            // W1 / 255 in three bf16 parts, each x 2^100 (exact: the data operand carries 2^-133 -- a byte's bits read as bf16)
             const double wv255 = (j < 50 && k < 204) ? (double)w[dmzw::VSEG_W1 + j * 204 + k] / 255.0 : 0.0;
-            const uint16_t p0 = bf16_rne((float)wv255);
-            const double r1 = wv255 - (double)bf16_to_float(p0);
-            const uint16_t p1 = bf16_rne((float)r1);
-            const uint16_t p2 = bf16_rne((float)(r1 - (double)bf16_to_float(p1)));
+            const uint16_t q0 = bf16_rne((float)wv255);
+            const double r1 = wv255 - (double)bf16_to_float(q0);
+            const uint16_t q1 = bf16_rne((float)r1);
+            const uint16_t q2 = bf16_rne((float)(r1 - (double)bf16_to_float(q1)));
+            const uint16_t p0 = bf16_rne(ldexpf(bf16_to_float(q0), 100)), p1 = bf16_rne(ldexpf(bf16_to_float(q1), 100)),
+                           p2 = bf16_rne(ldexpf(bf16_to_float(q2), 100));
             const uint16_t parts[3] = {p0, p1, p2};
             for (int part = 0; part < 3; part++)
               wb[((((size_t)wv * 7 + ks) * 3 + part) * 64 + lane) * 8 + e] = parts[part];

@@ -164,7 +164,7 @@ void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, 
 namespace dmzv {
 constexpr int WFRAG = 3 * 320 * 32;                 // offset of this block in the buffer
 // (offsets below are relative to WFRAG)
-constexpr int WB3 = 0;                              // W1 / 255 in three bf16 parts, fragments of v_mfma_f32_16x16x32_bf16:
+constexpr int WB3 = 0;                              // W1 / 255 in three bf16 parts x 2^100, fragments of v_mfma_f32_16x16x32_bf16:
                                                     // [wave 4][k-step 7][part 3][lane 64][8 bf16]
 constexpr int ROWSUM = 4 * 7 * 3 * 64 * 4;          // sum_k W1[j][k], 64 floats (zero beyond unit 49)
 // the digit models' 3x3 conv weights x 1/255 (the input scaling of n_categorize.cpp:99 folded in) as B fragments of

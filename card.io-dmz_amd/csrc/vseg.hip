@@ -15,9 +15,9 @@
 //     normalisation (scale, shift).  LDS keeps the u8 gradients + (scale, shift) per
 //     row -- 1/4 of the float features.
 //   * hidden layer = the one real contraction of the stage, [rows x 204] x [204 x 50], on
-//     v_mfma_f32_16x16x32_bf16 with exact operand splits (gradient bytes are bf16 numbers,
-//     the weights / 255 go in three bf16 parts, the row's scale and shift enter once per
-//     output: see vseg_mlp_rows_bf16).  Wave w owns hidden units 16w..16w+15 and streams
+//     v_mfma_f32_16x16x32_f16 with exact data operands (a gradient byte zero-extended to 16 bits is
+//     the f16 subnormal d x 2^-24; the weights / 255 x 2^12 go in three f16 parts, the row's scale and
+//     shift enter once per output: see vseg_mlp_rows_bf16).  Wave w owns hidden units 16w..16w+15 and streams
 //     its 21 weight fragments once per pass; all row tiles of a pass go through one sweep
 //     over k.  (The fp32 matrix core with register-resident weights, v_mfma_f32_16x16x4_f32,
 //     needed 16 times the matrix-pipe time per k and four VALU instructions per feature:
@@ -181,24 +181,32 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
 
 // Hidden + logistic layers for up to 16 NT rows on v_mfma_f32_16x16x32_bf16 with EXACT operand splits.
 // The feature of gradient byte d in a row with normalisation (s, t) is ((d / 255) s + t) (three float
-// operations in the reference), so  sum_k W[j][k] f_k = s sum_k (W[j][k] / 255) d_k + t sum_k W[j][k]:
-// d is an integer <= 255 -- a bf16 number as it is -- and W / 255 is split into three bf16 parts (24
-// bits), so three matrix instructions per 32 k reproduce the fp32 product of the integer sums to ~2^-24
-// per term; the two row constants enter once per output.  (Against the reference this regroups three
-// float roundings per feature: differences of the order of the 1e-6 that any reordering of the 204-term
-// sums makes; the 1e-4 contract on the scores and the proven-near-tie rule for y_offset are unchanged.)
-// One sixteenth of the fp32 matrix-core time per k, and 1.5 VALU instructions per feature instead of 4.
+// operations in the reference), so  sum_k W[j][k] f_k = s sum_k (W[j][k] / 255) d_k + t sum_k W[j][k].
+// A byte zero-extended to 16 bits IS a bf16 number: d x 2^-133 (exponent fields 0 and 1 continue one linear scale, and
+// the matrix core keeps subnormal inputs), so the A operand is one v_perm_b32 per two features -- no conversion at all
+// (round 2 converted every byte to float and packed the upper halves: 1.5 instructions per feature against 0.5).
+// W / 255 x 2^100 goes in three bf16 parts (24 bits: the parts of W / 255, their exponents moved), the 2^33 that is
+// left comes back with the row's scale: powers of two, nothing rounds differently -- tools/ubench/mfma_f16_subnormal_dot.hip
+// measures the same worst error as with the bytes as bf16 integers (6.2e-8 of the sum of |terms| per k-step; 1.3 % of the
+// outputs differ in the last bit).  The same trick on the f16 matrix instruction (bytes = f16 subnormals d x 2^-24, weights
+// x 2^12 in two or three f16 parts) was measured too: that instruction's accumulation is a little less exact (1.0e-7),
+// and because a weight-side error is the same for every row it adds up linearly in the 27-row window sums -- max
+// |vseg.score - oracle| 2.7e-5 instead of 7.6e-6; not used.  The products are exact in fp32 (8 x 8 bits): three matrix
+// instructions per 32 k reproduce the fp32 product of the integer sums to ~2^-24 per term; the two row constants enter once
+// per output.  (Against the reference this regroups three float roundings per feature: differences of the order of the 1e-6
+// that any reordering of the 204-term sums makes; the 1e-4 contract on the scores and the proven-near-tie rule for y_offset
+// are unchanged.)
 // All NT row tiles go through one sweep over k, so a wave streams its 21 weight fragments (fragment order,
 // 1-KB coalesced loads, prefetched one k-step ahead) once per pass.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
 __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb /* this wave + lane: [ks 7][part 3] x 64 */,
-                                                   float rowsum, float b1, float w20, float w21, float w22,
-                                                   const unsigned char *__restrict__ grad,
-                                                   const float *__restrict__ norm, int nrows,
-                                                   float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
-                                                   int lane) {
+                                                  float rowsum, float b1, float w20, float w21, float w22,
+                                                  const unsigned char *__restrict__ grad,
+                                                  const float *__restrict__ norm, int nrows,
+                                                  float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
+                                                  int lane) {
   const int ii = lane & 15, kk = lane >> 4;
   const unsigned char *ap[NT];
 #pragma unroll
@@ -223,17 +231,11 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const uint2 by = *(const uint2 *)(ap[t] + 32 * ks);  // eight gradient bytes k = 32 ks + 8 kk ..
-      float f[8];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        f[e] = (float)((by.x >> (8 * e)) & 255u);
-        f[4 + e] = (float)((by.y >> (8 * e)) & 255u);
-      }
-      u32x4 a;  // the upper halves of the floats are their exact bf16 forms
-      a.x = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
-      a.y = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
-      a.z = __builtin_amdgcn_perm(__float_as_uint(f[5]), __float_as_uint(f[4]), 0x07060302u);
-      a.w = __builtin_amdgcn_perm(__float_as_uint(f[7]), __float_as_uint(f[6]), 0x07060302u);
+      u32x4 a;  // bytes zero-extended to 16 bits: the bf16 numbers d x 2^-133
+      a.x = __builtin_amdgcn_perm(0u, by.x, 0x0c010c00u);
+      a.y = __builtin_amdgcn_perm(0u, by.x, 0x0c030c02u);
+      a.z = __builtin_amdgcn_perm(0u, by.y, 0x0c010c00u);
+      a.w = __builtin_amdgcn_perm(0u, by.y, 0x0c030c02u);
       const bf16x8 av = __builtin_bit_cast(bf16x8, a);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[2], acc[t], 0, 0, 0);  // small terms first
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[1], acc[t], 0, 0, 0);
@@ -246,7 +248,7 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       const int row = t * 16 + 4 * kk + v, rc = imin(row, nrows - 1);
-      const float pre = fmaf(norm[2 * rc], acc[t][v], fmaf(norm[2 * rc + 1], rowsum, b1));
+      const float pre = fmaf(norm[2 * rc] * 0x1p33f, acc[t][v], fmaf(norm[2 * rc + 1], rowsum, b1));  // (A carries 2^-133, B 2^100)
       const float hv = fast_tanh(pre);  // units >= 50 have zero logistic weights
       // sum over the 16 hidden units of this wave (one DPP row)
       const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
