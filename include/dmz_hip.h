@@ -176,7 +176,9 @@ int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t
  *   F16X3   (default) v_mfma_f32_16x16x32_f16 on operands split into an f16 rounding and the f16 rounding of the
  *           remainder (22 bits), a.b ~ al.bh + ah.bl + ah.bh with fp32 accumulation, both convolutions: the
  *           scores agree with the fp32 variant and the CPU oracle to ~2e-6, inside the reference's own
- *           known-answer tolerance 1e-5 (tests/test_gpu_expiry.py, bench.py);
+ *           known-answer tolerance 1e-5 (tests/test_gpu_expiry.py, bench.py).  Range: the layer-1 activations are
+ *           bounded by 16.4 max|x| for this model (sum of |conv1 weights| + |bias| per map), far inside f16 for the
+ *           pipeline's inputs (|x| < 1); dmz_hip_apply_expiry_model with |x| beyond ~4000 needs F32 / BF16X3;
  *   F32     v_mfma_f32_16x16x4_f32 / packed FMAs, the reference's k-ordered fp32 accumulation;
  *   BF16X3  the same three products on bf16 parts (16 bits): ~2^-16 per product, scores within the 1e-4 contract
  *           (the default up to round 2);
