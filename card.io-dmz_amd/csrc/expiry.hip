@@ -10,13 +10,13 @@
 // order-preserving IEEE float/double arithmetic (no contraction: the file is compiled with
 // -ffp-contract=off and uses explicit fmaf only inside the CNN), so stripes, groups and rects
 // are bit-exact.  The slash MLP's hidden layer runs on v_mfma_f32_16x16x32_bf16 with EXACT operand splits
-// (integer samples, weights in three bf16 parts), the CNN's two convolutions on the same instruction with split
-// operands (conv1: three parts each, six products -- fp32 to rounding; conv2: two parts, three products -- the
-// default DMZ_HIP_EXPIRY_CONV_BF16X3; the F32 variant keeps packed FMAs and v_mfma_f32_16x16x4_f32), tanh is
+// (integer samples, weights in three bf16 parts), the CNN's two convolutions on v_mfma_f32_16x16x32_f16 with both operands
+// split in two f16 parts and three products (the default DMZ_HIP_EXPIRY_CONV_F16X3: fp32 to ~2^-22 per product; BF16X3 /
+// BF16 keep the bf16 forms of round 2, the F32 variant packed FMAs and v_mfma_f32_16x16x4_f32), tanh is
 // exp2/rcp based, the dense layers run on v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain):
 // the slash decision P > 0.7 can differ from the oracle only within float noise of the threshold
-// (none in 3 x 65 536 frames) and the digit scores agree to 1e-4 (measured 5e-5 with BF16X3, 3e-6 with F32;
-// the reference's own KAT tolerance is 1e-5, which the F32 variant meets -- tests/test_gpu_expiry.py).
+// (none in 4 x 65 536 frames) and the digit scores agree to 5e-6 with F16X3 and F32 (measured 4.4e-6 / 3e-6 on 65 536 frames;
+// 5e-5 with BF16X3; the reference's own KAT tolerance is 1e-5 -- tests/test_gpu_expiry.py).
 //
 // std::sort in the reference is unstable; ties are resolved in ascending original index here
 // and in the oracle (see oracle/orc_expiry.c).
