@@ -635,7 +635,21 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
           // counter of (n, rr): half n & 1 of word (n >> 1) * numrho + rr -- the half is a
           // compile-time constant per angle; counts < 65536, so no carry between the halves
           const int t = col * bp.tab_cos[n] + r * bp.tab_sin[n];
-          atomicAdd(&acc32[(n >> 1) * numrho + half + (t >> 10)], (n & 1) ? 0x10000u : 1u);
+          const int cell = (n >> 1) * numrho + half + (t >> 10);
+          if (n == kNumAngle / 2) {
+            // The middle angle is the box's own direction (its table entry across the box is 0 or -1): the voters of one
+            // instruction -- neighbours on a card edge -- then all name ONE counter, and equal addresses serialise an LDS
+            // atomic at 2 cycles per lane (tools/ubench/lds_atomic_rate.hip: 127 cycles for 64 lanes against 4 for 64
+            // different counters).  One lane adds the count for all of them.
+            const int c0 = __builtin_amdgcn_readfirstlane(cell);
+            const unsigned long long act = __ballot(true);
+            if (__ballot(cell != c0) == 0ull) {
+              if ((int)(threadIdx.x & 63) == __builtin_ctzll(act))
+                atomicAdd(&acc32[c0], (unsigned)__popcll(act) << ((n & 1) * 16));
+              continue;
+            }
+          }
+          atomicAdd(&acc32[cell], (n & 1) ? 0x10000u : 1u);
         }
       }
     }
