@@ -66,19 +66,28 @@ __device__ __forceinline__ int slot_center(int off, int pi, float width) {
 
 // L1 score of one candidate, sequential in column order.  g has 64 zero floats of padding
 // behind column 427 so that inactive lanes may read past their segment.
-__device__ float hseg_score(const float *__restrict__ g, int pt, float width, int off, bool has) {
-  const int plen = pattern_len(pt);
-  const unsigned mask = pattern_mask(pt);
-  // in-bounds test (n_hseg.cpp:61-66) and first centre
-  bool in_bounds = has;
-  int first = 428;
-  for (int pi = plen - 1; pi >= 0; pi--) {
-    if (!((mask >> pi) & 1u)) continue;
-    const int c = slot_center(off, pi, width);
-    if (!(c + 19 < 428)) in_bounds = false;
-    first = c;
+// PT (the number pattern) is a template parameter: the slots of the pattern are then compile-time constants, the digit
+// loop unrolls and every digit's left column is computed ONCE (the rolled form evaluated slot_center three times per slot:
+// in the bounds test, as a segment's start and as its predecessor's end).
+template <int PT>
+__device__ float hseg_score_t(const float *__restrict__ g, float width, int off, bool has) {
+  constexpr int plen = PT == 1 ? 19 : 17;
+  constexpr unsigned mask = PT == 1 ? 0x7BDEFu : 0x1F7EFu;
+  constexpr int nd = PT == 1 ? 16 : 15;
+  int c[nd];
+  {
+    int k = 0;
+#pragma unroll
+    for (int pi = 0; pi < plen; pi++)
+      if ((mask >> pi) & 1u) c[k++] = slot_center(off, pi, width);
   }
+  // in-bounds test (n_hseg.cpp:61-66)
+  bool in_bounds = has;
+#pragma unroll
+  for (int k = 0; k < nd; k++)
+    if (!(c[k] + 19 < 428)) in_bounds = false;
   const bool live = in_bounds;
+  const int first = c[0];
   float s = 0.0f;
   // leading gap: columns [0, first) against pattern value 0
   {
@@ -90,14 +99,11 @@ __device__ float hseg_score(const float *__restrict__ g, int pt, float width, in
     }
   }
   // digit segments in slot order; segment k covers [c_k, c_next) (c_next = 428 for the last)
-  for (int pi = 0; pi < plen; pi++) {
-    if (!((mask >> pi) & 1u)) continue;
-    int nxt = pi + 1;
-    while (nxt < plen && !((mask >> nxt) & 1u)) nxt++;
-    const int c = slot_center(off, pi, width);
-    const int cn = nxt < plen ? slot_center(off, nxt, width) : 428;
-    const int len = live ? cn - c : 0;
-    const float *gp = g + (live ? c : 0);
+#pragma unroll
+  for (int k = 0; k < nd; k++) {
+    const int cn = k + 1 < nd ? c[k + 1] : 428;
+    const int len = live ? cn - c[k] : 0;
+    const float *gp = g + (live ? c[k] : 0);
     // the first 16 taps are inside every live lane's segment (digit spacing >= 16); the sum of a
     // lane that is not live is discarded below, so it needs no masking here
 #pragma unroll
@@ -114,6 +120,10 @@ __device__ float hseg_score(const float *__restrict__ g, int pt, float width, in
     }
   }
   return live ? s : FLT_MAX;
+}
+__device__ __forceinline__ float hseg_score(const float *__restrict__ g, int pt, float width, int off, bool has) {
+  // (pattern type 0 never reaches the search: VSEG_OK implies a pattern)
+  return pt == 2 ? hseg_score_t<2>(g, width, off, has) : hseg_score_t<1>(g, width, off, has);
 }
 
 struct HsegBest {
