@@ -442,7 +442,9 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   if (nfine > 0) {
     vseg_prepare_rows(card, row_y, nfine, grad, norm, wave, lane);
     __syncthreads();
-    vseg_mlp_rows_bf16<3>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
+    // (43 rows around the coarse winner minus the 10 or 11 the coarse pass scored: 32 fresh rows in three cards of four -- two tiles)
+    if (nfine <= 32) vseg_mlp_rows_bf16<2>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
+    else vseg_mlp_rows_bf16<3>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
     __syncthreads();
     vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
     __syncthreads();
