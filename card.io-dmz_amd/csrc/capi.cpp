@@ -680,6 +680,32 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
           }
   }
   {
+    // slash hidden layer on `inter` bytes: W'[n][(rho, c)] = (3 W[n][rho][c] + 10 W[n][rho - 1][c] + 3 W[n][rho - 2][c]) / 255
+    // (sample row r = 3 inter[r] + 10 inter[r + 1] + 3 inter[r + 2]; W rows outside 0..15 are zero), in double
+    const float *sw = w + dmzw::SLASH + dmzw::S_W1;
+    uint16_t *sf = (uint16_t *)(xw.data() + dmzx::SLASH_F3);
+    for (int ks = 0; ks < dmzx::SLASH_FSTEPS; ks++)
+      for (int nt = 0; nt < 5; nt++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 8; e++) {
+            const int kk = lane >> 4, nn = 16 * nt + (lane & 15);
+            const int rho = ks < 6 ? 8 * (kk & 1) + e : 16 + (kk >> 1), c = ks < 6 ? 2 * ks + (kk >> 1) : 8 * (kk & 1) + e;
+            double wv = 0.0;
+            if (c < 11) {
+              auto W = [&](int r) { return (r >= 0 && r < 16) ? (double)sw[nn * 176 + r * 11 + c] : 0.0; };
+              wv = (3.0 * W(rho) + 10.0 * W(rho - 1) + 3.0 * W(rho - 2)) / 255.0;
+            }
+            const uint16_t q0 = bf16_rne((float)wv);
+            const double r1 = wv - (double)bf16_to_float(q0);
+            const uint16_t q1 = bf16_rne((float)r1);
+            const uint16_t q2 = bf16_rne((float)(r1 - (double)bf16_to_float(q1)));
+            const uint16_t parts[3] = {bf16_rne(ldexpf(bf16_to_float(q0), 100)), bf16_rne(ldexpf(bf16_to_float(q1), 100)),
+                                       bf16_rne(ldexpf(bf16_to_float(q2), 100))};
+            for (int part = 0; part < 3; part++)
+              sf[((((size_t)part * dmzx::SLASH_FSTEPS + ks) * 5 + nt) * 64 + lane) * 8 + e] = parts[part];
+          }
+  }
+  {
     // expiry CNN conv1 weights [map 50][tap 25] as the B operand of a [positions x 32] x [32 x 64] product, three bf16 parts
     const float *c1 = w + dmzw::EXPIRY + dmzw::X_C1W;
     uint16_t *cb = (uint16_t *)(xw.data() + dmzx::CONV1_B3);

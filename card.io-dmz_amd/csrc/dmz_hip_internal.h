@@ -130,7 +130,13 @@ constexpr int CONV1_F2 = CONV2_FL + C2_KSTEPS * 3 * 64 * 4;
 // FC1 [n-tile 11][k-group 8][lane 64][4] (k-steps 30, 31 are zero), FC2 [k-group 11][lane 64][4] (units 10 .. 15 are zero)
 constexpr int FC1_F = CONV1_F2 + 2 * 4 * 64 * 4;
 constexpr int FC2_F = FC1_F + 11 * 8 * 64 * 4;
-constexpr int TOTAL = FC2_F + 11 * 64 * 4;
+// slash MLP hidden layer with the vertical 3 / 10 / 3 pass of the Scharr operator folded into the weights: W' over the 18 x 11
+// `inter` bytes under a 16 x 11 window, / 255, three bf16 parts x 2^100 (the A operand is the bytes' bits: d x 2^-133),
+// fragments [part 3][k-step 7][n-tile 5][lane 64][8 bf16]; k-steps 0..5: inter row 8 (kk & 1) + e, column 2 ks + (kk >> 1);
+// k-step 6: inter row 16 + (kk >> 1), column 8 (kk & 1) + e
+constexpr int SLASH_FSTEPS = 7;
+constexpr int SLASH_F3 = FC2_F + 11 * 64 * 4;
+constexpr int TOTAL = SLASH_F3 + 3 * SLASH_FSTEPS * 5 * 64 * 4;
 }  // namespace dmzx
 // offsets inside the expiry CNN block of the weight blob (modelc_bf4dd6c8.cpp)
 namespace dmzw {

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #ifndef DMZ_XSEG_STOP
 #define DMZ_XSEG_STOP 99
 #endif
+#ifndef DMZ_XSEG_FOLD  /* developer switch: 0 = the slash MLP always on Scharr samples */
+#define DMZ_XSEG_FOLD 1
+#endif
 #define XSEG_STOP(k, expr)                     \
   if (DMZ_XSEG_STOP == (k)) {                  \
     if (lane == 0) sg->n = (int)(expr) & 0;    \
@@ -753,6 +756,56 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       f32x4 acc[5];
 #pragma unroll
       for (int t = 0; t < 5; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      // ---- the common case: every candidate's sixteen sample rows lie inside the ROI.  A Scharr sample is then the fixed
+      // combination 3 / 10 / 3 of three `inter` bytes, so the vertical pass folds into the weights (dmzx::SLASH_F3: W' =
+      // W (x) [3 10 3] / 255 over the 18 x 11 `inter` bytes under the window, computed in double on the host) and the A
+      // operand is the `inter` bytes THEMSELVES -- a byte zero-extended to 16 bits is the bf16 number d x 2^-133 (see
+      // k_vseg), the weights carry 2^100, the 2^33 left over comes back before the tanh.  Per k-step: eight byte reads and
+      // four packs instead of ten reads, 24 operations of sample arithmetic, 32 of splitting and converting and 8 packs; one
+      // exact A part instead of two (15 matrix instructions instead of 30); seven k-steps instead of six (K = 16 x 12 as
+      // before + one step for `inter` rows 16, 17).  The products are exact, the sums differ from the sample form by fp32
+      // rounding (~1e-7 of the pre-activation): the decision P > 0.7 moves only within float noise of the threshold.
+      // Windows that touch the ROI edge (a stripe at the very top or bottom) keep the sample form below. ----
+      const bool inside = !live || ((vmask >> pt) & 0xFFFFu) == 0xFFFFu;
+      const bool folded = DMZ_XSEG_FOLD && __builtin_amdgcn_ballot_w64(!inside) == 0ull;
+      if (folded) {
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(xw + dmzx::SLASH_F3), 0, 3 * dmzx::SLASH_FSTEPS * 5 * 64 * 16, 0x00020000);
+        const unsigned char *ipa = ip;                                                       // rows r0 .. r0 + 7, column 2 ks + (kk >> 1)
+        const unsigned char *ipb = L.inter + (pt + 16 + (kk >> 1)) * ISTRIDE + pl + 8 * (kk & 1);  // rows 16 / 17, columns 8 (kk & 1) ..
+#pragma unroll 1
+        for (int ks = 0; ks < (DMZ_XSEG_STOP == 8 ? 1 : dmzx::SLASH_FSTEPS); ks++) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 wb[3][5];
+#pragma unroll
+          for (int part = 0; part < 3; part++)
+#pragma unroll
+            for (int t = 0; t < 5; t++)
+              wb[part][t] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, ((part * dmzx::SLASH_FSTEPS + ks) * 5 + t) * 1024, 0);
+          uint32_t by[8];
+          if (ks < dmzx::SLASH_KSTEPS) {  // uniform
+#pragma unroll
+            for (int e = 0; e < 8; e++) by[e] = ipa[e * ISTRIDE];
+            ipa += 2;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) by[e] = ipb[e];
+          }
+          const u32x4 a = {by[0] | (by[1] << 16), by[2] | (by[3] << 16), by[4] | (by[5] << 16), by[6] | (by[7] << 16)};
+          const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 5; t++) {  // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wb[2][t]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wb[1][t]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wb[0][t]), acc[t], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 5; t++) acc[t] = acc[t] * 0x1p33f;  // (A carried 2^-133, B 2^100: exact)
+      } else
 #pragma unroll 1
       for (int ks = 0; ks < (DMZ_XSEG_STOP == 8 ? 1 : dmzx::SLASH_KSTEPS); ks++) {
         bf16x8 wb[3][5];
