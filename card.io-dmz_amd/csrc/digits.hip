@@ -338,10 +338,7 @@ static_assert(PART_BYTES + 3 * 16 * HID_PITCH * 4 <= DG_RAW && DG_LDS <= DG_RAW,
 // LDS strip -- 36 byte loads per lane keep the texture path busier than 180 LDS byte reads keep the LDS: 1.9 vs 0.9 ms
 // per 65 536 cards.)
 constexpr int STRIP_BYTES = 11568;     // 27 x 428 = 11,556, padded to 16
-#ifndef DMZ_DP_U32
-#define DMZ_DP_U32 0
-#endif
-constexpr int HIST_BYTES = 16 * 512 * (DMZ_DP_U32 ? 2 : 1);   // one histogram / LUT per digit
+constexpr int HIST_BYTES = 16 * 512;   // (with the strip: the 16 KB of the four-fold histograms)
 constexpr int DP_LDS = STRIP_BYTES + HIST_BYTES;  // 19,760 B: eight workgroups per CU
 #ifndef DMZ_DP_WGS
 #define DMZ_DP_WGS 8
@@ -367,19 +364,13 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
 
   // ---- number strip -> LDS (2889 aligned dwords) ----
   for (int i = tid; i < 27 * 107; i += DG_THREADS) ((uint32_t *)strip_l)[i] = strip[i];
-  constexpr int HW = DMZ_DP_U32 ? 256 : 128;  // dwords per histogram
-  unsigned int *hd = (unsigned int *)(raw + STRIP_BYTES) + wave * (4 * HW);  // 4 x (256 counters, then the LUT)
-  {
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = 0; i < HW / 64; i++) *(u32x4 *)(hd + (HW / 16) * lane + 4 * i) = z;
-  }
   __syncthreads();
   if (DMZ_DP_STOP == 1) return;
   // ---- per digit, a wave each (wave w owns digits 4 w .. 4 w + 3): cross gradient clamped at the 19x27 ROI edge,
   // histogram, equalisation LUT (stats.cpp:135-151), equalised pixels as bf16.
   // Lane l < 57 owns column l % 19 of rows l / 19, l / 19 + 3, ...: pixel index p = 57 k + l in step k, so nine steps
   // cover the 513 pixels with no per-pixel division and the five taps at constant offsets from one address.
-  // The wave's four digits go through every step together (four histograms per wave). ----
+  // The wave's four digits go through every step together. ----
   {
     const int rr = lane / 19, c = lane - 19 * rr;
     const int cl = c > 0 ? -1 : 0, cr = c < 18 ? 1 : 0;
@@ -407,27 +398,40 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
       if (acc == 12345678) xb[0] = 1;
       return;
     }
+    // The gradients are in registers: the strip is dead once every wave is here, and its LDS becomes the histograms.
+    // The pixels of a digit crowd into a few bins, and lanes that meet in one counter serialise an LDS atomic at two
+    // cycles each (tools/ubench/lds_atomic_rate.hip; a probe with conflict-free addresses ran the kernel 28 % faster) -- so a
+    // digit gets FOUR histograms, one per lane & 3, of 8-bit counters (a quarter of the lanes own <= 135 pixels: no carry
+    // between the four counters of a dword): 4 x 256 B per digit, 4 KB per wave over the old strip; the LUT pass adds them.
+    __syncthreads();
+    unsigned int *hq = (unsigned int *)raw + wave * 1024;  // [digit 4][copy 4][64 dwords]
+    {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 4; i++) *(u32x4 *)(hq + 256 * i + 4 * lane) = z;
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int dj = 0; dj < 4; dj++)
       if (4 * wave + dj < nd && lane < 57) {
+        unsigned int *hc = hq + (dj * 4 + (lane & 3)) * 64;
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-          if (DMZ_DP_U32) atomicAdd(&hd[dj * HW + gv[dj][k]], 1u);
-          else atomicAdd(&hd[dj * HW + (gv[dj][k] >> 1)], 1u << ((gv[dj][k] & 1) * 16));  // counts <= 513: no carry
+        for (int k = 0; k < 9; k++) atomicAdd(&hc[gv[dj][k] >> 2], 1u << ((gv[dj][k] & 3) * 8));
       }
     __builtin_amdgcn_wave_barrier();
     if (DMZ_DP_STOP == 3) return;
     uint2 lut[4];
 #pragma unroll
     for (int dj = 0; dj < 4; dj++) {
-      int h0, h1, h2, h3;
-      if (DMZ_DP_U32) {
-        const u32x4 hh = *(const u32x4 *)(hd + dj * HW + 4 * lane);
-        h0 = (int)hh.x, h1 = (int)hh.y, h2 = (int)hh.z, h3 = (int)hh.w;
-      } else {
-        const uint2 hh = *(const uint2 *)(hd + dj * HW + 2 * lane);
-        h0 = hh.x & 0xffff, h1 = hh.x >> 16, h2 = hh.y & 0xffff, h3 = hh.y >> 16;
+      // values 4 lane .. 4 lane + 3: dword `lane` of each copy; even and odd bytes added as 16-bit fields
+      unsigned int ev = 0u, od = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned int cq = hq[(dj * 4 + q) * 64 + lane];
+        ev += cq & 0x00FF00FFu;
+        od += (cq >> 8) & 0x00FF00FFu;
       }
+      const int h0 = ev & 0xffff, h1 = od & 0xffff, h2 = ev >> 16, h3 = od >> 16;
       const int tot = h0 + h1 + h2 + h3;
       const int incl = dmzwave::inclusive_scan_i32(tot);
       const int excl = incl - tot;
@@ -444,6 +448,9 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
       lut[dj] = make_uint2(b0 | b1, b2 | b3);
     }
     __builtin_amdgcn_wave_barrier();
+    // the LUTs (256 bf16 each) over the first half of the wave's region
+    constexpr int HW = 128;
+    unsigned int *hd = hq;
 #pragma unroll
     for (int dj = 0; dj < 4; dj++) *(uint2 *)(hd + dj * HW + 2 * lane) = lut[dj];
     __builtin_amdgcn_wave_barrier();
