@@ -259,6 +259,41 @@ def test_expiry_on_random_text_cards(ctx, pkg, oracle):
     assert found >= 8
 
 
+def test_expiry_stripes_at_the_roi_edge(ctx, pkg, oracle):
+    """The slash MLP has two forms: on the horizontal-pass bytes with the Scharr operator's vertical pass folded into the
+    weights (every sample row of the window inside the ROI: the common case) and on Scharr samples (a window that touches
+    the ROI edge).  Here the ROI is made to start ONE row above every group the oracle finds, so that the windows of the
+    topmost stripe reach above the ROI -- the sample form -- and the records must still be the oracle's, group by group."""
+    rng = np.random.default_rng(31415)
+    n = 48
+    cards = np.ascontiguousarray(np.stack([_text_card(rng, oracle, 100 + i) for i in range(n)]))
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_cards(cards, n, res)
+    forced = res.copy()
+    forced["flags"] = pkg.FLAG_VSEG_OK | pkg.FLAG_USABLE
+    forced["vseg_y_offset"] = 140
+    # first pass: where are the groups?
+    tops = np.full(n, -1)
+    for i in range(n):
+        want = oracle.scan_card_expiry(cards[i], forced[i])
+        if want["n_groups"] > 0:
+            tops[i] = int(min(want["groups"][k]["stripe_base_row"] for k in range(int(want["n_groups"]))))
+    # second pass: the ROI starts one row above the topmost stripe that carried a group (y0 = y_offset + 27 = base row - 1)
+    moved = tops > 160
+    forced["vseg_y_offset"] = np.where(moved, tops - 28, 140)
+    ctx.scan_expiry(cards, n, forced, exp)
+    edge_groups = 0
+    for i in range(n):
+        want = oracle.scan_card_expiry(cards[i], forced[i])
+        _compare(pkg, exp[i], want, i)
+        if moved[i]:
+            y0 = int(forced[i]["vseg_y_offset"]) + 27
+            edge_groups += sum(int(want["groups"][k]["stripe_base_row"]) - 3 < y0 for k in range(int(want["n_groups"])))
+    print("groups whose stripe window reaches above the ROI: %d (of %d cards moved)" % (edge_groups, int(moved.sum())))
+    assert edge_groups >= 4
+
+
 def test_expiry_model_rows_do_not_depend_on_their_position_in_a_workgroup(ctx, pkg):
     """The CNN runs its convolutions two digits per pass and four inputs per workgroup: an input's scores must be the
     same bits whether it is evaluated alone, first, last or in the middle of a batch (all conv variants)."""
