@@ -65,6 +65,8 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
     gexp = exp.download(pkg.EXPIRY_DTYPE, n)
     stats = dict(found_all=int(got["found_all"].astype(bool).sum()),
                  vseg_ok=int(((got["flags"] & pkg.FLAG_VSEG_OK) != 0).sum()) if hasattr(pkg, "FLAG_VSEG_OK") else -1,
+                 # frames the 15-digit pattern won (n_vseg.cpp:26-30): the second instantiation of the hseg score, a 15-digit categorise
+                 amex_like=int((((got["flags"] & pkg.FLAG_VSEG_OK) != 0) & (got["pattern_type"] == 2)).sum()),
                  card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
                  label_diff=0, flag_diff=0, unexplained=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
                  expiry_slash_flips=0, max_expiry_err=0.0)
