@@ -86,7 +86,7 @@ EXPORTS = (
     "dmz_hip_deinterleave_c2", "dmz_hip_deinterleave_rgba_to_r", "dmz_hip_ycbcr_to_rgb",
     "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv", "dmz_hip_set_two_queues",
     "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
-    "dmz_hip_gather_records", "dmz_hip_gather_wait",
+    "dmz_hip_gather_records", "dmz_hip_gather_wait", "dmz_hip_expiry_sort_positions",
 )
 
 
@@ -154,6 +154,7 @@ def load_library():
     lib.dmz_hip_scan_sessions_batch.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.dmz_hip_apply_slash_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_apply_expiry_model.argtypes = [vp, vp, i, vp]
+    lib.dmz_hip_expiry_sort_positions.argtypes = [vp, vp, vp, i, i, i, vp, vp]
     lib.dmz_hip_calc_persp_transform.argtypes = [vp, vp, vp, vp]
     lib.dmz_hip_warp_perspective_batch.argtypes = [vp, vp, sz, i, i, i, i, vp, vp, sz]
     lib.dmz_hip_apply_vseg_model.argtypes = [vp, vp, i, vp]
@@ -384,6 +385,16 @@ class Context:
         out = np.empty((x.shape[0], 10), np.float32)
         self._check(self.lib.dmz_hip_apply_expiry_model(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
         return out
+
+    def expiry_sort_positions(self, keys, lens, kind=0):
+        """(pos, flags) of dmz_hip_expiry_sort_positions for int32 key lists [n_lists, stride]."""
+        keys = np.ascontiguousarray(keys, np.int32)
+        lens = np.ascontiguousarray(lens, np.int32)
+        pos = np.zeros(keys.shape, np.int32)
+        flags = np.zeros(keys.shape[0], np.int32)
+        self._check(self.lib.dmz_hip_expiry_sort_positions(self.h, keys.ctypes.data, lens.ctypes.data, keys.shape[0],
+                                                           keys.shape[1], kind, pos.ctypes.data, flags.ctypes.data))
+        return pos, flags
 
     def synth_frames(self, seed, first, n, y_dev):
         self._check(self.lib.dmz_hip_synth_frames(self.h, seed, first, n, _ptr(y_dev)))

@@ -18,8 +18,10 @@
 // (none in 4 x 65 536 frames) and the digit scores agree to 5e-6 with F16X3 and F32 (measured 4.4e-6 / 3e-6 on 65 536 frames;
 // 5e-5 with BF16X3; the reference's own KAT tolerance is 1e-5 -- tests/test_gpu_expiry.py).
 //
-// std::sort in the reference is unstable; ties are resolved in ascending original index here
-// and in the oracle (see oracle/orc_expiry.c).
+// std::sort in the reference is unstable: candidates with equal sums are visited in the order libstdc++'s introsort
+// leaves them (dmz_stdsort.h; oracle/orc_expiry.c is pinned on the reference's own instantiation).  Both picks run
+// in parallel rounds with the column / row as tie-break and WATCH for a tie that could change the outcome (two live
+// candidates with equal sums that exclude each other); only then the library's order is computed and the pick repeated.
 //
 // Mapping: the list logic is short, serial and data-dependent, so one 64-lane wave owns one
 // (frame, stripe): lanes are columns, candidate rects, groups, grid hypotheses or character
@@ -31,6 +33,7 @@
 
 #include "dmz_hip_internal.h"
 #include "dmz_wave.h"
+#include "dmz_stdsort.h"
 
 // developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
 #ifndef DMZ_LDS_PAD
@@ -154,20 +157,59 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
       if (good) key[j] = ((unsigned)sum << 7) | (unsigned)(127 - idx);
     }
   }
-  // descending by sum (ties: ascending base row), up to three that do not overlap (838-858)
+  // descending by sum, up to three that do not overlap (838-866): three rounds of "the best live candidate".  Equal sums:
+  // the reference visits them in std::sort's order.  A round whose best sum is held by two live candidates is the only place
+  // where that order can matter (0.3 % of the corpus' cards): then the good stripes are sorted as the library sorts them
+  // (one lane; <= 111 elements) and the rounds repeat with the sorted position as tie-break.
+  __shared__ unsigned sv[128];
+  __shared__ unsigned sstack[20];
+  __shared__ unsigned short sq[128];
+  const unsigned k0 = key[0], k1 = key[1];
   int np = 0;
-  for (int round = 0; round < 3; round++) {
-    const unsigned m = wave_max_u32(key[0] > key[1] ? key[0] : key[1]);
-    if (m == 0u) break;
-    const int idx = 127 - (int)(m & 127u);
-    if (lane == 0) {
-      out[f].stripe_base_row[np] = y0 + 1 + idx;
-      out[f].stripe_sum[np] = (int64_t)(m >> 7);
+  auto rounds = [&](bool watch) -> bool {
+    bool tie = false;
+    np = 0;
+    for (int round = 0; round < 3; round++) {
+      const unsigned m = wave_max_u32(key[0] > key[1] ? key[0] : key[1]);
+      if (m == 0u) break;
+      const int idx = 127 - (int)(m & 127u);
+      if (watch) {  // the best sum again, preferring the LAST of its holders
+        const unsigned r0 = key[0] ? (key[0] | 127u) - (127u - (unsigned)lane) : 0u;
+        const unsigned r1 = key[1] ? (key[1] | 127u) - (127u - (unsigned)(lane + 64)) : 0u;
+        const unsigned m2 = wave_max_u32(r0 > r1 ? r0 : r1);
+        tie |= (m2 >> 7) == (m >> 7) && (int)(m2 & 127u) != idx;
+      }
+      if (lane == 0) {
+        out[f].stripe_base_row[np] = y0 + 1 + idx;
+        out[f].stripe_sum[np] = (int64_t)(m >> 7);
+      }
+      np++;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        if (iabs(lane + 64 * j - idx) < SCH) key[j] = 0u;
     }
-    np++;
+    return tie;
+  };
+  if (rounds(true)) {
+    // stripe_sums in base-row order (830-835), std::sort (842)
+    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(k0 != 0u), b1 = __builtin_amdgcn_ballot_w64(k1 != 0u);
+    const int n0 = __popcll(b0), ns = n0 + __popcll(b1);
+    const int c0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+    const int c1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+    if (k0) sv[c0] = (k0 & ~127u) | (unsigned)lane;
+    if (k1) sv[c1] = (k1 & ~127u) | (unsigned)(lane + 64);
+    __syncthreads();
+    if (lane == 0) dmzsort::serial_sort<7>(sv, ns, sstack);
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; j++)
-      if (iabs(lane + 64 * j - idx) < SCH) key[j] = 0u;
+      if (lane + 64 * j < ns) sq[sv[lane + 64 * j] & 127u] = (unsigned short)(lane + 64 * j);
+    __syncthreads();
+    key[0] = k0 ? (k0 & ~127u) | (127u - sq[lane]) : 0u;
+    key[1] = k1 ? (k1 & ~127u) | (127u - sq[lane + 64]) : 0u;
+    rounds(false);
+    if (lane == 0)
+      for (int i = np; i < 3; i++) out[f].stripe_base_row[i] = 0, out[f].stripe_sum[i] = 0;
   }
   if (lane == 0) out[f].n_stripes = np;
 }
@@ -207,6 +249,10 @@ struct SegLds {
   // three tenants, one after the other (a single wave: its LDS operations execute in program order)
   union {
     int colA[428];                       // column sums over rows base .. base+16, until the rect sums are in registers
+    struct {                             // the candidate order of the pick when equal sums matter (dmz_stdsort.h)
+      unsigned v[420];
+      unsigned tabP[26], tabB[26], tabE[26];
+    } s;
     struct {                             // the picked rects sorted by left, until the local groups are formed
       int itemS[64];
       short itemL[64];
@@ -454,19 +500,20 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   // neighbourhood (keys are distinct: sum, then the smaller column), so all such local maxima are picked at once,
   // everything within 8 columns of a pick dies, and the rounds repeat until nothing is alive -- the same set as
   // the sequential greedy (the priority-ordered maximal independent set), in ~4 rounds instead of ~30 picks. ----
+  // Equal sums: the reference visits them in std::sort's order (dmz_stdsort.h).  The rounds first run with the smaller column
+  // as tie-break and watch for the one event where that order can change the outcome: a pick with a LIVE candidate of the same
+  // sum within its eight columns (with this tie-break such a candidate lies to the right of the pick, and it is the best of its
+  // right-hand neighbours) -- 15 % of the corpus' stripes.  Then the list is ordered as the library orders it and the rounds
+  // repeat with the position after the library's partition phase as tie-break: the sequential greedy in the sorted order.
   unsigned key[7];
-#pragma unroll
-  for (int j = 0; j < 7; j++) {
-    key[j] = 0u;
-    if (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
-      key[j] = ((unsigned)rs7[j] << 9) | (unsigned)(511 - (7 * lane + j));
-  }
   unsigned picked = 0u;  // bit j: the rect at column 7 lane + j was picked
-  {
+  auto pick_rounds = [&](bool watch) -> bool {
     // lane - 1 / lane + 1 of the wave (DPP wave_shr:1 / wave_shl:1), 0 at the ends
     auto below = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); };
     auto above = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); };
     auto umax = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    bool tie = false;
+    picked = 0u;
     for (;;) {
       unsigned alive = key[0];
 #pragma unroll
@@ -484,11 +531,17 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       for (int j = 0; j < 7; j++) {
         // columns 7 l + j - 8 .. 7 l + j + 8: slots j - 1 .. 6 of lane l - 1, all of lane l, slots 0 .. j + 1 of lane
         // l + 1, and for the end slots one column of lane l -+ 2
+        unsigned right = above(pre[j < 6 ? j + 1 : 6]);  // the columns to the right outside the own lane
+        if (j == 6) right = umax(right, above(above(key[0])));
         unsigned w = umax(suf[0], below(suf[j > 0 ? j - 1 : 0]));
-        w = umax(w, above(pre[j < 6 ? j + 1 : 6]));
+        w = umax(w, right);
         if (j == 0) w = umax(w, below(below(key[6])));
-        if (j == 6) w = umax(w, above(above(key[0])));
-        now |= (key[j] != 0u && key[j] == w) ? 1u << j : 0u;
+        const bool pick = key[j] != 0u && key[j] == w;
+        now |= pick ? 1u << j : 0u;
+        if (watch) {
+          if (j < 6) right = umax(right, suf[j + 1]);
+          tie |= pick && ((right ^ key[j]) >> 9) == 0u;  // (a dead neighbour's key is 0: its sum field differs from a live one's)
+        }
       }
       picked |= now;
       // bit i of `near`: column 7 l - 8 + i holds a pick of this round (i = 0 .. 22)
@@ -497,6 +550,56 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 #pragma unroll
       for (int j = 0; j < 7; j++) key[j] = ((near >> j) & 0x1FFFFu) ? 0u : key[j];
     }
+    return __builtin_amdgcn_ballot_w64(tie) != 0ull;
+  };
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    key[j] = 0u;
+    if (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
+      key[j] = ((unsigned)rs7[j] << 9) | (unsigned)(511 - (7 * lane + j));
+  }
+  if (pick_rounds(true)) {
+    // rect_list: the windows above the first threshold in column order (expiry_seg.cpp:461-470); std::sort (:496)
+    unsigned *const sv = L.u.s.v;
+    auto fill_list = [&]() {
+      unsigned pos = 0u;
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(lane < 60 && (float)rs7[j] > thr1);
+        pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, pos));
+      }
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        if (lane < 60 && (float)rs7[j] > thr1) sv[pos++] = ((unsigned)rs7[j] << 9) | (unsigned)(7 * lane + j);
+      __syncthreads();
+    };
+    fill_list();
+    unsigned e[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < cnt ? sv[7 * lane + j] : 0u;
+    __syncthreads();
+    if (!dmzsort::wave_partitions<7, 9>(e, cnt, lane, sv, L.u.s.tabP, L.u.s.tabB, L.u.s.tabE)) {
+      // the depth limit of the introsort loop (adversarial lists only): the library's whole sort on one lane
+      fill_list();
+      if (lane == 0) dmzsort::serial_sort<9>(sv, cnt, L.u.s.tabP);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < cnt ? sv[7 * lane + j] : 0u;
+      __syncthreads();
+    }
+    unsigned short *const sq = (unsigned short *)sv;  // position of each column's window in that order
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+      if (7 * lane + j < cnt) sq[e[j] & 511u] = (unsigned short)(7 * lane + j);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      key[j] = 0u;
+      if (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
+        key[j] = ((unsigned)rs7[j] << 9) | (511u - (unsigned)sq[7 * lane + j]);
+    }
+    __syncthreads();
+    pick_rounds(false);
   }
   XSEG_STOP(4, picked)
   // sorted by left = column order = lane-major, slot-minor: a lane's first item follows the picks of the lanes below
@@ -1639,6 +1742,54 @@ __global__ __launch_bounds__(XC_THREADS, 3) void k_expiry_model(const float *__r
   expiry_cnn_block<MODE>(wts, xw, S, nd, out + (size_t)first * 10, tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_sort_order: the candidate order of dmz_stdsort.h on caller-supplied key lists (diagnostic entry
+// dmz_hip_expiry_sort_positions; tests/test_gpu_expiry.py checks it against the reference's own std::sort).
+// One wave per list.  pos[i] = position of element i: kind 0 after the partition phase (wave form, the form k_expiry_seg
+// uses; the final order is "key descending, then pos"), kinds 1 / 2 after the whole sort on one lane (9- / 7-bit index field).
+// flags[list] = 1 when the wave form hit the depth limit and the serial form took over.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sort_order(const int *__restrict__ keys, const int *__restrict__ lens, int stride,
+                                                   int kind, int *__restrict__ pos, int *__restrict__ flags) {
+  __shared__ unsigned sv[448];
+  __shared__ unsigned tabP[28], tabB[28], tabE[28];
+  const int list = blockIdx.x, lane = threadIdx.x;
+  const int n = lens[list];
+  const int *k = keys + (size_t)list * stride;
+  int *po = pos + (size_t)list * stride;
+  int fell_back = 0;
+  if (kind == 0) {
+    unsigned e[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < n ? ((unsigned)k[7 * lane + j] << 9) | (unsigned)(7 * lane + j) : 0u;
+    if (!dmzsort::wave_partitions<7, 9>(e, n, lane, sv, tabP, tabB, tabE)) {
+      fell_back = 1;
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        if (7 * lane + j < n) sv[7 * lane + j] = ((unsigned)k[7 * lane + j] << 9) | (unsigned)(7 * lane + j);
+      __syncthreads();
+      if (lane == 0) dmzsort::serial_sort<9>(sv, n, tabP);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < n ? sv[7 * lane + j] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+      if (7 * lane + j < n) po[e[j] & 511u] = 7 * lane + j;
+  } else {
+    const int sh = kind == 1 ? 9 : 7;
+    for (int i = lane; i < n; i += 64) sv[i] = ((unsigned)k[i] << sh) | (unsigned)i;
+    __syncthreads();
+    if (lane == 0) {
+      if (kind == 1) dmzsort::serial_sort<9>(sv, n, tabP);
+      else dmzsort::serial_sort<7>(sv, n, tabP);
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) po[sv[i] & ((1u << sh) - 1u)] = i;
+  }
+  if (lane == 0) flags[list] = fell_back;
+}
+
 }  // namespace
 
 int dmz_configure_expiry(void) {
@@ -1680,6 +1831,11 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
   else
     hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_BF16X3>, grid, block, lds, s, weights, xw, tables, cards, card_stride,
                        n, results, stage, out);
+}
+
+void dmz_launch_sort_order(hipStream_t s, const int *keys, const int *lens, int n_lists, int stride, int kind, int *pos,
+                           int *flags) {
+  hipLaunchKernelGGL(k_sort_order, dim3((unsigned)n_lists), dim3(64), 0, s, keys, lens, stride, kind, pos, flags);
 }
 
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out) {

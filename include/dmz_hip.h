@@ -294,6 +294,19 @@ int dmz_hip_apply_slash_model(dmz_hip_context *ctx, const float *x /* n x 176 */
 int dmz_hip_apply_expiry_model(dmz_hip_context *ctx, const float *x /* n x 16 x 11 */, int n,
                                float *out /* n x 10 */);
 
+/* The candidate order of the expiry segmentation on caller-supplied lists (host pointers): the reference
+ * sorts its window sums and stripe sums with std::sort and a "sum >" comparator (scan/expiry_seg.cpp:75-87, 456,
+ * 842), and which of two EQUAL sums comes first is libstdc++'s introsort permutation.  pos[list * stride + i] =
+ * position of element i of that list: kind 0 after the introsort's partition phase, computed by a whole wave as
+ * k_expiry_seg does (the final order is "key descending, then pos": the closing insertion sort is stable); kind 1 /
+ * 2 after the complete sort on one lane (keys < 2^23 / 2^25, lens <= 420 / 128).  kind 0: keys < 2^23, lens <= 420.
+ * flags[list] = 1 when the wave form met the introsort's depth limit and the one-lane form took over.
+ * Known-answer entry like the model passes below (tests/test_gpu_expiry.py: against the reference's own
+ * instantiation of std::sort). */
+int dmz_hip_expiry_sort_positions(dmz_hip_context *ctx, const int32_t *keys /* n_lists x stride */,
+                                  const int32_t *lens /* n_lists */, int n_lists, int stride, int kind,
+                                  int32_t *pos /* n_lists x stride */, int32_t *flags /* n_lists */);
+
 /* Synthetic inputs resident in HBM (bench/test generator; byte-identical to
  * oracle/orc_synth.c).  Frames are 640x480, cards 428x270, tightly packed. */
 int dmz_hip_synth_frames(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n,

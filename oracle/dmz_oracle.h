@@ -192,6 +192,13 @@ void orc_categorize_expiry_groups(const uint8_t *card, int stride, orc_expiry_re
 /* frame.cpp:71-73 gate + scan.cpp:62-64 gate, given the number-path result of the same card */
 void orc_scan_card_expiry(const uint8_t *card, int stride, const orc_frame_result *res,
                           orc_expiry_result *out);
+/* libstdc++'s std::sort with a "key descending" comparator, as a permutation: order[k] = index of the k-th
+ * element after the sort (expiry_seg.cpp:456, 842 with the comparators at 75-87) */
+void orc_sort_order_desc(int n, const long *key, int *order);
+/* test hook: capture the key lists orc_best_expiry_seg sorts, as [n, keys...] records */
+void orc_expiry_capture_sort_lists(int64_t *buf, int len);
+int orc_expiry_captured_len(void);
+int orc_sort_heap_sorts(void); /* test hook: depth-limit heap sorts so far on this thread */
 /* flat-array hooks onto gather_into_groups (expiry_seg.cpp:131-167) and regrid_group (169-229) */
 int orc_expiry_gather_into_groups(int n_items, const int *lefts, const int64_t *sums, int top, int height,
                                   int *group_n, int *group_left, int *group_width, int *rect_left,

@@ -327,6 +327,32 @@ class Oracle:
         self.lib.orc_best_expiry_seg(_p(card, _u8p), card.shape[1], int(y_offset), out.ctypes.data_as(C.c_void_p))
         return out[0]
 
+    def sort_order_desc(self, keys):
+        """order[k] = index of the k-th element after std::sort(.., sum descending) as libstdc++ leaves it"""
+        k = np.ascontiguousarray(keys, np.int64)
+        o = np.empty(len(k), np.int32)
+        self.lib.orc_sort_order_desc(len(k), k.ctypes.data_as(C.POINTER(C.c_long)), o.ctypes.data_as(C.POINTER(C.c_int)))
+        return o
+
+    def sort_heap_sorts(self):
+        return int(self.lib.orc_sort_heap_sorts())
+
+    def best_expiry_seg_sort_lists(self, card, y_offset):
+        """the key lists (window sums per stripe, stripe sums) orc_best_expiry_seg hands to the sort, in call order"""
+        card = np.ascontiguousarray(card, np.uint8)
+        buf = np.zeros(4 * 430 + 300, np.int64)
+        out = np.zeros(1, EXPIRY_DTYPE)
+        self.lib.orc_expiry_capture_sort_lists(buf.ctypes.data_as(C.c_void_p), len(buf))
+        self.lib.orc_best_expiry_seg(_p(card, _u8p), card.shape[1], int(y_offset), out.ctypes.data_as(C.c_void_p))
+        used = int(self.lib.orc_expiry_captured_len())
+        self.lib.orc_expiry_capture_sort_lists(None, 0)
+        lists, i = [], 0
+        while i < used:
+            n = int(buf[i])
+            lists.append(buf[i + 1:i + 1 + n].copy())
+            i += 1 + n
+        return lists
+
     def prepare_image_for_cat(self, card, left, top):
         card = np.ascontiguousarray(card, np.uint8)
         x = np.empty(176, np.float32)
@@ -360,6 +386,14 @@ class Reference:
 
     def pass_kats(self):
         return self.lib.ref_pass_kats()
+
+    def sort_order(self, keys, stripes=False):
+        """the reference's std::sort of its CharacterRect / StripeSum lists with its own comparators (expiry_seg.cpp:456, 842)"""
+        k = np.ascontiguousarray(keys, np.int64)
+        o = np.empty(len(k), np.int32)
+        fn = self.lib.ref_sort_stripe_sums if stripes else self.lib.ref_sort_rect_sums
+        fn(len(k), k.ctypes.data_as(C.POINTER(C.c_long)), o.ctypes.data_as(C.POINTER(C.c_int)))
+        return o
 
     def _model(self, fn, x, n):
         x = np.ascontiguousarray(x, np.float32)

@@ -10,10 +10,18 @@
  * holds no fixture for them; they are restated from the in-tree source and the published
  * OpenCV 2.4.9 semantics.
  *
- * One deliberate definition: the reference orders candidates with std::sort (unstable; the
- * order of equal keys is unspecified and differs between libstdc++ and libc++).  The oracle --
- * and the device -- resolve ties in ascending original index, i.e. the permutation
- * std::stable_sort yields, which is one of the outcomes std::sort is allowed to produce.
+ * Candidate order: the reference orders the window sums and the stripe sums with std::sort and a
+ * "sum >" comparator (expiry_seg.cpp:75-87, 456, 842).  std::sort is not stable, so the order of
+ * equal sums is whatever the standard library's algorithm leaves -- and it decides which of two
+ * overlapping windows / stripes with equal sums the greedy picks below take.  The reference's
+ * standard library here is libstdc++ (GCC 11.4); its std::sort is a deterministic function of the
+ * comparison results, restated in orc_sort_order_desc() below: introsort loop (ranges > 16:
+ * median of first+1 / middle / last-1 swapped to first, unguarded Hoare partition around it, the
+ * right part recursed, depth limit 2*floor(log2 n), heap sort of a range once it is reached),
+ * then one insertion sort over everything.  Pinned against the reference's own types and
+ * comparators compiled with this toolchain (oracle/_ref: ref_sort_rect_sums /
+ * ref_sort_stripe_sums; tests/test_oracle_vs_ref.py: random lists with ties, adversarial lists
+ * that reach the heap sort, and every list of a corpus sample).
  */
 #include "dmz_oracle.h"
 
@@ -47,6 +55,155 @@ typedef struct {
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ---- libstdc++'s std::sort(first, last, comp) with comp(a, b) = key[a] > key[b], as a permutation:
+ * v[] holds element indices and is rearranged exactly as the library rearranges the elements
+ * (bits/stl_algo.h of GCC 11: __introsort_loop, __move_median_to_first, __unguarded_partition,
+ * __final_insertion_sort; bits/stl_heap.h: __make_heap / __adjust_heap / __push_heap / __pop_heap for the
+ * depth-limit fallback).  The algorithm is a published one; the code below is a restatement, the
+ * pin is oracle/_ref (the reference's own instantiation). ---- */
+typedef struct {
+  const long *key;
+  int *v;
+} sort_ctx;
+
+#define SORT_GT(c, a, b) ((c)->key[(a)] > (c)->key[(b)]) /* the comparator on ELEMENTS a, b */
+
+static void sort_swap(sort_ctx *c, int i, int j) {
+  int t = c->v[i];
+  c->v[i] = c->v[j];
+  c->v[j] = t;
+}
+
+/* heap helpers on v[first .. first+len) */
+static void sort_push_heap(sort_ctx *c, int first, int hole, int top, int value) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && SORT_GT(c, c->v[first + parent], value)) {
+    c->v[first + hole] = c->v[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  c->v[first + hole] = value;
+}
+
+static void sort_adjust_heap(sort_ctx *c, int first, int hole, int len, int value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (SORT_GT(c, c->v[first + child], c->v[first + child - 1])) child--;
+    c->v[first + hole] = c->v[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    c->v[first + hole] = c->v[first + child - 1];
+    hole = child - 1;
+  }
+  sort_push_heap(c, first, hole, top, value);
+}
+
+static __thread int heap_sorts; /* test hook: how often the depth limit was reached */
+int orc_sort_heap_sorts(void) { return heap_sorts; }
+
+static void sort_heap_range(sort_ctx *c, int first, int last) { /* __partial_sort(first, last, last) */
+  int len = last - first;
+  heap_sorts++;
+  if (len >= 2)
+    for (int parent = (len - 2) / 2;; parent--) {
+      sort_adjust_heap(c, first, parent, len, c->v[first + parent]);
+      if (parent == 0) break;
+    }
+  while (last - first > 1) {
+    --last;
+    int value = c->v[last];
+    c->v[last] = c->v[first];
+    sort_adjust_heap(c, first, 0, last - first, value);
+  }
+}
+
+static void sort_introsort_loop(sort_ctx *c, int first, int last, int depth_limit) {
+  while (last - first > 16) {
+    if (depth_limit == 0) {
+      sort_heap_range(c, first, last);
+      return;
+    }
+    --depth_limit;
+    /* __move_median_to_first(first, first + 1, mid, last - 1) */
+    int a = first + 1, b = first + (last - first) / 2, cc = last - 1;
+    int ea = c->v[a], eb = c->v[b], ec = c->v[cc];
+    if (SORT_GT(c, ea, eb)) {
+      if (SORT_GT(c, eb, ec)) sort_swap(c, first, b);
+      else if (SORT_GT(c, ea, ec)) sort_swap(c, first, cc);
+      else sort_swap(c, first, a);
+    } else if (SORT_GT(c, ea, ec)) sort_swap(c, first, a);
+    else if (SORT_GT(c, eb, ec)) sort_swap(c, first, cc);
+    else sort_swap(c, first, b);
+    /* __unguarded_partition(first + 1, last, pivot = first) */
+    int lo = first + 1, hi = last;
+    for (;;) {
+      while (SORT_GT(c, c->v[lo], c->v[first])) ++lo;
+      --hi;
+      while (SORT_GT(c, c->v[first], c->v[hi])) --hi;
+      if (!(lo < hi)) break;
+      sort_swap(c, lo, hi);
+      ++lo;
+    }
+    sort_introsort_loop(c, lo, last, depth_limit);
+    last = lo;
+  }
+}
+
+static void sort_linear_insert(sort_ctx *c, int last) { /* __unguarded_linear_insert */
+  int value = c->v[last];
+  int next = last - 1;
+  while (SORT_GT(c, value, c->v[next])) {
+    c->v[last] = c->v[next];
+    last = next;
+    --next;
+  }
+  c->v[last] = value;
+}
+
+static void sort_insertion(sort_ctx *c, int first, int last) { /* __insertion_sort */
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (SORT_GT(c, c->v[i], c->v[first])) {
+      int value = c->v[i];
+      memmove(&c->v[first + 1], &c->v[first], sizeof(int) * (size_t)(i - first));
+      c->v[first] = value;
+    } else
+      sort_linear_insert(c, i);
+  }
+}
+
+/* test hook: when armed, every list handed to the sort below is appended to cap_buf as
+ * [n, key_0 .. key_{n-1}] (tests/test_oracle_vs_ref.py runs the corpus' own lists through the
+ * reference's std::sort) */
+static __thread int64_t *cap_buf;
+static __thread int cap_len, cap_used;
+void orc_expiry_capture_sort_lists(int64_t *buf, int len) { cap_buf = buf, cap_len = len, cap_used = 0; }
+int orc_expiry_captured_len(void) { return cap_used; }
+
+/* order[k] = index (into key[]) of the k-th element of the list after
+ * std::sort(list.begin(), list.end(), <sum descending>) */
+void orc_sort_order_desc(int n, const long *key, int *order) {
+  sort_ctx c = {key, order};
+  if (cap_buf && cap_used + n + 1 <= cap_len) {
+    cap_buf[cap_used++] = n;
+    for (int i = 0; i < n; i++) cap_buf[cap_used++] = key[i];
+  }
+  for (int i = 0; i < n; i++) order[i] = i;
+  if (n == 0) return;
+  int lg = 0;
+  for (unsigned m = (unsigned)n; m > 1; m >>= 1) lg++;
+  sort_introsort_loop(&c, 0, n, 2 * lg);
+  if (n > 16) {
+    sort_insertion(&c, 0, 16);
+    for (int i = 16; i != n; ++i) sort_linear_insert(&c, i);
+  } else
+    sort_insertion(&c, 0, n);
+}
 
 /* sobel.cpp:706-804, scalar branch: |right-left| with the column index clamped, then
  * 3/10/3 down the column with the row index clamped -- both clamps at the ROI edge. */
@@ -325,21 +482,18 @@ static void find_character_groups_for_stripe(const int16_t *sobel, int stripe_ba
   float rect_sum_average = rect_sum_total / (float)n_rects;
   float rect_sum_threshold = (float)(0.8 * rect_sum_average);
 
-  /* [2]+[3] descending by sum (ties: ascending left), greedy non-overlapping pick.  Visiting
-   * the sorted list and skipping masked rects == repeatedly taking the best unmasked rect. */
+  /* [2] std::sort descending by sum -- the library's own permutation, ties included (see above);
+   * [3] greedy non-overlapping pick in that order */
   static __thread grouped_rects items[W / kSmallCharacterWidth + 2];
+  static __thread long sort_keys[W];
+  static __thread int sort_order[W];
   int n_items = 0;
   uint8_t mask[W + 16];
-  uint8_t used[W];
   memset(mask, 0, sizeof(mask));
-  memset(used, 0, sizeof(used));
-  for (;;) {
-    int best = -1;
-    for (int i = 0; i < n_rects; i++)
-      if (!used[i] && (best < 0 || rect_list[i].sum > rect_list[best].sum)) best = i;
-    if (best < 0) break;
-    used[best] = 1;
-    const char_rect *r = &rect_list[best];
+  for (int i = 0; i < n_rects; i++) sort_keys[i] = rect_list[i].sum;
+  orc_sort_order_desc(n_rects, sort_keys, sort_order);
+  for (int k = 0; k < n_rects; k++) {
+    const char_rect *r = &rect_list[sort_order[k]];
     if ((float)r->sum <= rect_sum_threshold) break;
     if (!mask[r->left] && !mask[r->left + kSmallCharacterWidth - 1]) {
       grouped_rects *it = &items[n_items++];
@@ -351,7 +505,7 @@ static void find_character_groups_for_stripe(const int16_t *sobel, int stripe_ba
       it->sum = r->sum;
       it->character_width = kSmallCharacterWidth;
       it->n = 0;
-      for (int k = 0; k < kSmallCharacterWidth; k++) mask[r->left + k] = 1;
+      for (int k2 = 0; k2 < kSmallCharacterWidth; k2++) mask[r->left + k2] = 1;
     }
   }
 
@@ -422,18 +576,17 @@ void orc_best_expiry_seg(const uint8_t *card, int stride, int starting_y_offset,
       n_stripes++;
     }
   }
-  /* descending by sum, ties in ascending base_row; keep up to 3 that do not overlap */
-  uint8_t taken[H];
-  memset(taken, 0, sizeof(taken));
+  /* std::sort descending by sum (the library's permutation, ties included); keep up to 3 that do
+   * not overlap (expiry_seg.cpp:842-866) */
+  long stripe_keys[H];
+  int stripe_order[H];
+  for (int i = 0; i < n_stripes; i++) stripe_keys[i] = stripes[i].sum;
+  orc_sort_order_desc(n_stripes, stripe_keys, stripe_order);
   int probable_rows[3];
   long probable_sums[3];
   int n_probable = 0;
-  for (;;) {
-    int best = -1;
-    for (int i = 0; i < n_stripes; i++)
-      if (!taken[i] && (best < 0 || stripes[i].sum > stripes[best].sum)) best = i;
-    if (best < 0) break;
-    taken[best] = 1;
+  for (int k = 0; k < n_stripes; k++) {
+    const int best = stripe_order[k];
     int overlap = 0;
     for (int p = 0; p < n_probable; p++)
       if (probable_rows[p] - kSmallCharacterHeight < stripes[best].base_row &&

@@ -414,3 +414,32 @@ REF_API void ref_card_rect_for_screen(int card_w, int card_h, int std_w, int std
   rect[2] = r.width;
   rect[3] = r.height;
 }
+
+// ---- the two candidate orders of the expiry segmentation (expiry_seg.cpp:456, :842): the reference's own
+// element types and comparators (expiry_seg.cpp:69-87, expiry_types.h:51-66) through this toolchain's
+// std::sort, exactly as the unity TU instantiates it.  order_out[k] = original index of the k-th visited
+// element.  Pins orc_expiry.c's restatement of libstdc++'s introsort permutation.
+REF_API void ref_sort_rect_sums(int n, const long *sums, int *order_out) {
+  CharacterRectList rect_list;
+  for (int i = 0; i < n; i++) {
+    CharacterRect rect;
+    rect.top = 0;
+    rect.left = i;
+    rect.sum = sums[i];
+    rect_list.push_back(rect);
+  }
+  std::sort(rect_list.begin(), rect_list.end(), CharacterRectCompareSumDescending());
+  for (int i = 0; i < n; i++) order_out[i] = rect_list[i].left;
+}
+
+REF_API void ref_sort_stripe_sums(int n, const long *sums, int *order_out) {
+  std::vector<StripeSum> stripe_sums;
+  for (int i = 0; i < n; i++) {
+    StripeSum stripe_sum;
+    stripe_sum.base_row = i;
+    stripe_sum.sum = sums[i];
+    stripe_sums.push_back(stripe_sum);
+  }
+  std::sort(stripe_sums.begin(), stripe_sums.end(), StripeSumCompareDescending());
+  for (int i = 0; i < n; i++) order_out[i] = stripe_sums[i].base_row;
+}

@@ -95,6 +95,79 @@ def test_expiry_conv_variants_against_fp32(ctx, pkg, oracle):
         ctx.set_expiry_conv(7)
 
 
+def test_candidate_order_on_device_is_std_sort(ctx, oracle, orc):
+    """scan/expiry_seg.cpp:456 / 842: std::sort with a "sum >" comparator; which of two EQUAL sums comes first is libstdc++'s
+    introsort permutation.  The device's two forms (csrc/dmz_stdsort.h: a wave running the partition phase of all ranges
+    of a level at once, as k_expiry_seg does; one lane running the whole sort, as k_expiry_stripes does and as the wave form's
+    fall-back at the depth limit) against the oracle's restatement -- which tests/test_oracle_vs_ref.py pins on the reference's
+    own instantiation -- and, where oracle/_ref is present, against that instantiation itself."""
+    from sort_lists import adversarial_lists, random_lists, structured_lists
+    ref = orc.Reference() if orc.Reference.available() else None
+    rng = np.random.default_rng(842)
+    for kind, max_len, max_key in ((0, 420, 1 << 20), (1, 420, 1 << 20), (2, 111, 1 << 25)):
+        lists = random_lists(rng, 1500, max_len) + [k for k in structured_lists() + adversarial_lists() if len(k) <= max_len]
+        lists.append(rng.integers(max_key - 50, max_key, max_len))  # the largest sums the path can produce, with ties
+        keys = np.zeros((len(lists), 420), np.int32)
+        lens = np.array([len(k) for k in lists], np.int32)
+        for i, k in enumerate(lists):
+            keys[i, :len(k)] = k
+        pos, flags = ctx.expiry_sort_positions(keys, lens, kind)
+        for i, k in enumerate(lists):
+            got = np.lexsort((pos[i, :len(k)], -np.asarray(k)))  # key descending, then the position the device reports
+            assert np.array_equal(np.sort(pos[i, :len(k)]), np.arange(len(k))), (kind, i)  # a permutation
+            assert np.array_equal(got, oracle.sort_order_desc(k)), (kind, i, len(k))
+            if ref is not None:
+                assert np.array_equal(got, ref.sort_order(k, stripes=kind == 2)), (kind, i, len(k))
+        print("sort kind %d: %d lists, %d through the depth-limit fall-back" % (kind, len(lists), int(flags.sum())))
+        # the adversarial lists drive the wave form into its fall-back; nothing else does
+        assert (flags.sum() > 0) == (kind == 0)
+
+
+def _tie_card(rng, oracle, idx):
+    """cards whose Scharr image has plateaus: posterised grey levels and periodic column patterns below the number row, so
+    that many 9-px windows (and stripes) have EQUAL sums and the candidate order decides which of two overlapping ones wins"""
+    card, _ = oracle.synth_card(SEED, 900 + idx)
+    card = card.astype(np.int64)
+    mode = idx % 4
+    step = int(rng.choice([8, 16, 32, 64]))
+    card[178:] = (card[178:] // step) * step
+    if mode == 1:    # period-3 columns: every window of the band sums to the same value
+        card[185:260, 10:420] += np.where((np.arange(10, 420) % 3) == 0, int(rng.integers(10, 60)), 0)[None, :]
+    elif mode == 2:  # two-level noise
+        card[185:262] = 100 + 24 * rng.integers(0, 2, (77, 428))
+    elif mode == 3:  # repeated glyph columns with a pitch of 9 / 10 / 11: equal sums one pitch apart
+        pitch = int(rng.choice([9, 10, 11]))
+        for x in range(12, 410, pitch):
+            card[195:210, x:x + 2] -= 60
+            card[225:240, x + 3:x + 5] -= 45
+    return np.clip(card, 0, 255).astype(np.uint8)
+
+
+def test_expiry_on_cards_with_equal_sums(ctx, pkg, oracle):
+    """The tie order of the two std::sorts (expiry_seg.cpp:456, 842) on cards that are full of equal window / stripe sums:
+    records equal to the oracle's, which follows the reference's library order (a stable order differs on such cards)."""
+    rng = np.random.default_rng(456842)
+    n = 96
+    cards = np.ascontiguousarray(np.stack([_tie_card(rng, oracle, i) for i in range(n)]))
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.scan_cards(cards, n, res)
+    forced = res.copy()
+    forced["flags"] = pkg.FLAG_VSEG_OK | pkg.FLAG_USABLE
+    forced["vseg_y_offset"] = 125 + (np.arange(n) * 7) % 60
+    ctx.scan_expiry(cards, n, forced, exp)
+    tied_lists = found = 0
+    for i in range(n):
+        want = oracle.scan_card_expiry(cards[i], forced[i])
+        _compare(pkg, exp[i], want, i)
+        found += int(want["n_found"] > 0)
+        for k in oracle.best_expiry_seg_sort_lists(cards[i], int(forced[i]["vseg_y_offset"])):
+            order = oracle.sort_order_desc(k)
+            tied_lists += int(not np.array_equal(order, np.argsort(-k, kind="stable")))
+    print("cards with equal sums: %d lists whose library order is not the stable one, %d cards with groups" % (tied_lists, found))
+    assert tied_lists >= n
+
+
 def test_scan_expiry_on_synthetic_cards(ctx, pkg, oracle):
     """pre-warped cards (BASELINE config 3 shape): number path, then the expiry path"""
     n = 96

@@ -99,7 +99,10 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
 def _compare_frame(pkg, oracle, stats, g, ge, gcard, w, wcard, we):
     """one frame's device records against the oracle's; counts into stats"""
     for _ in (0,):  # (a one-pass loop: `continue` ends the frame's check as in the original flat loop)
+        fmask = w["found"] != 0  # rho / theta bits of every edge that was found, also on frames with fewer than four
         if not (np.array_equal(g["found"], w["found"]) and g["found_all"] == w["found_all"]
+                and np.array_equal(g["rho"].view(np.uint32)[fmask], w["rho"].view(np.uint32)[fmask])
+                and np.array_equal(g["theta"].view(np.uint32)[fmask], w["theta"].view(np.uint32)[fmask])
                 and np.array_equal(g["corners"].view(np.uint32), w["corners"].view(np.uint32))):
             stats["det_diff"] += 1
             continue
@@ -128,7 +131,13 @@ def _compare_frame(pkg, oracle, stats, g, ge, gcard, w, wcard, we):
             # the usable gate compares number_score with 3: only a float near-tie may flip it
             near = (g["flags"] ^ w["flags"]) == pkg.FLAG_USABLE and abs(float(w["number_score"]) - 3.0) < 1e-3
             stats["flag_diff" if near else "unexplained"] += 1
-            continue
+            if not near:
+                continue
+            # a proven tie of the usable gate does not end the frame's check: the oracle's expiry stage at the device's flags
+            # (scan.cpp:57-64: the expiry digits are categorised for usable frames only)
+            w = w.copy()
+            w["flags"] = g["flags"]
+            we = oracle.scan_card_expiry(wcard, w)
         # ---- expiry: stripes, groups and rects exact; scores 1e-4 ----
         ns = int(we["n_stripes"])
         if not (ge["n_stripes"] == ns and np.array_equal(ge["stripe_base_row"][:ns], we["stripe_base_row"][:ns])
@@ -152,6 +161,19 @@ def _compare_frame(pkg, oracle, stats, g, ge, gcard, w, wcard, we):
             stats["max_expiry_err"] = max(stats["max_expiry_err"], float(np.abs(a["scores"] - b["scores"]).max()))
 
 
+def assert_parity(stats, n, min_expiry_frames=0):
+    """the bars of DESIGN.md section 4 on one run's counters"""
+    assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0, stats
+    assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4, stats
+    # near-tie events are proven one by one in _compare_frame; anything unproven fails
+    assert stats["unexplained"] == 0, stats
+    # ... and proven near-ties of two votes / of the usable gate are rare events (measured: <= 1 per 65 536 corpus frames);
+    # a regression that produced many "provable" ones must not pass
+    assert stats["label_diff"] <= max(2, n // 2048) and stats["flag_diff"] <= max(2, n // 2048), stats
+    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4, stats
+    assert stats["expiry_frames"] >= min_expiry_frames, stats
+
+
 def test_1024_frames_against_oracle(ctx, pkg, oracle):
     n = int(os.environ.get("DMZ_PARITY_FRAMES", "4096"))  # raise for a one-off sweep (the oracle does ~215 frames/s per core)
     y = ctx.alloc(n * pkg.FRAME_BYTES)
@@ -159,17 +181,21 @@ def test_1024_frames_against_oracle(ctx, pkg, oracle):
     stats = compare_with_oracle(ctx, pkg, oracle, y, n)
     y.free()
     print("parity stats over %d frames: %s" % (n, stats))
-    assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
-    assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
-    # near-tie events are proven one by one in compare_with_oracle; anything unproven fails
-    assert stats["unexplained"] == 0
-    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4
-    assert stats["expiry_frames"] >= n // 4
+    assert_parity(stats, n, min_expiry_frames=n // 4)
 
 
 def _fuzz_frame(rng, kind, oracle):
     """Frames the synthetic corpus never produces: no clean card, or a card in the wrong place."""
     yy, xx = np.mgrid[0:480, 0:640]
+    if kind >= 7:    # a card frame posterised to a few grey levels: flat regions and plateaus -> runs of EQUAL Scharr window
+        # sums and stripe sums, i.e. the candidate order of the expiry segmentation (std::sort's tie order) decides picks
+        f = oracle.synth_frame(SEED + 98, int(rng.integers(0, 1 << 20)))[0].astype(np.int64)
+        step = int(rng.choice([8, 16, 32, 64]))
+        f = (f // step) * step
+        if kind == 8:  # ... and a periodic column pattern over the lower half of the card (period 3: all 9-px windows tie)
+            per = int(rng.choice([2, 3, 4, 6]))
+            f[300:372, 110:530] += np.where((xx[300:372, 110:530] % per) == 0, int(rng.integers(8, 40)), 0)
+        return np.clip(f, 0, 255).astype(np.uint8)
     if kind >= 5:    # a synthetic card frame shifted off the guide frame, dimmed, with heavy noise
         f = oracle.synth_frame(SEED + 99, int(rng.integers(0, 1 << 20)))[0].astype(np.int64)
         f = np.roll(f, (int(rng.integers(-14, 15)), int(rng.integers(-14, 15))), axis=(0, 1))
@@ -206,15 +232,12 @@ def test_fuzz_frames_against_oracle(ctx, pkg, oracle):
     """Noise, ramps, stray quadrilaterals, bar patterns and line clutter through the whole pipeline:
     detect with thousands of NMS survivors, edges that do not meet, quads that leave the frame, garbage
     for the scan stages -- every record must still equal the oracle's."""
-    n = int(os.environ.get("DMZ_FUZZ_FRAMES", "210"))
+    n = int(os.environ.get("DMZ_FUZZ_FRAMES", "270"))
     rng = np.random.default_rng(int(os.environ.get("DMZ_PARITY_SEED", "31337")) + 7)
-    frames = np.stack([_fuzz_frame(rng, i % 7, oracle) for i in range(n)])
+    frames = np.stack([_fuzz_frame(rng, i % 9, oracle) for i in range(n)])
     y = ctx.alloc(frames.nbytes).upload(frames)
     stats = compare_with_oracle(ctx, pkg, oracle, y, n)
     y.free()
     print("fuzz parity stats over %d frames: %s" % (n, stats))
-    assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0
-    assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4
     # garbage cards have flat vseg scores: near-ties (each one proven within 1e-4) are more frequent here
-    assert stats["unexplained"] == 0
-    assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4
+    assert_parity(stats, n)

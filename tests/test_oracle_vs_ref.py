@@ -144,6 +144,46 @@ def test_expiry_regrid_group_bit_exact(oracle, reference):
             assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
 
 
+def test_expiry_candidate_order_is_the_reference_std_sort(oracle, reference):
+    """expiry_seg.cpp:456 / 842: std::sort with a "sum >" comparator is not stable; the order of EQUAL sums is libstdc++'s
+    introsort permutation and decides which of two overlapping candidates the greedy picks take.  The oracle's
+    restatement (orc_sort_order_desc) against the reference's own element types and comparators through this toolchain's
+    std::sort: random lists with ties, structured lists, and adversarial lists that reach the depth-limit heap sort."""
+    from sort_lists import adversarial_lists, random_lists, structured_lists
+    rng = np.random.default_rng(456)
+    unstable = 0
+    for i, k in enumerate(random_lists(rng, 6000) + structured_lists()):
+        want = reference.sort_order(k, stripes=bool(i & 1))
+        assert np.array_equal(oracle.sort_order_desc(k), want), (i, len(k))
+        unstable += int(not np.array_equal(want, np.argsort(-k, kind="stable")))
+    assert unstable > 1000  # the stable permutation is NOT what the library produces
+    heap0 = oracle.sort_heap_sorts()
+    for k in adversarial_lists():
+        assert np.array_equal(oracle.sort_order_desc(k), reference.sort_order(k))
+    assert oracle.sort_heap_sorts() > heap0  # the heap-sort branch was exercised
+
+
+def test_expiry_candidate_order_on_corpus_lists(oracle, reference):
+    """... and on every list the segmentation itself sorts (window sums per stripe, stripe sums) for 4 096 corpus cards:
+    the restatement visits them in the reference's order; most of the lists hold equal sums."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        card, _ = oracle.synth_card(0xCA4D10, i)
+        res = oracle.scan_card_image(card, warped=False)
+        return oracle.best_expiry_seg_sort_lists(card, int(res["vseg_y_offset"]))
+
+    with ThreadPoolExecutor(8) as pool:
+        per_card = list(pool.map(one, range(4096)))
+    n_lists = with_ties = 0
+    for lists in per_card:
+        for k in lists:
+            n_lists += 1
+            with_ties += int(len(np.unique(k)) < len(k))
+            assert np.array_equal(oracle.sort_order_desc(k), reference.sort_order(k))
+    assert n_lists >= 3 * 4096 and with_ties > n_lists // 4, (n_lists, with_ties)
+
+
 def _synthetic_session(rng, orc, n_frames, digits, month_year, p_usable=0.8, noise=0.05, alt_len_rate=0.1):
     """per-frame records of one session: noisy near-one-hot digit scores, an MM/YY group most frames"""
     fr = np.zeros(n_frames, orc.RESULT_DTYPE)
