@@ -154,7 +154,7 @@ def load_library():
     lib.dmz_hip_scan_sessions_batch.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.dmz_hip_apply_slash_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_apply_expiry_model.argtypes = [vp, vp, i, vp]
-    lib.dmz_hip_expiry_sort_positions.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    lib.dmz_hip_expiry_sort_positions.argtypes = [vp, vp, vp, vp, i, i, i, vp, vp]
     lib.dmz_hip_calc_persp_transform.argtypes = [vp, vp, vp, vp]
     lib.dmz_hip_warp_perspective_batch.argtypes = [vp, vp, sz, i, i, i, i, vp, vp, sz]
     lib.dmz_hip_apply_vseg_model.argtypes = [vp, vp, i, vp]
@@ -386,13 +386,18 @@ class Context:
         self._check(self.lib.dmz_hip_apply_expiry_model(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
         return out
 
-    def expiry_sort_positions(self, keys, lens, kind=0):
+    def expiry_sort_positions(self, keys, lens, kind=0, marks=None):
         """(pos, flags) of dmz_hip_expiry_sort_positions for int32 key lists [n_lists, stride]."""
         keys = np.ascontiguousarray(keys, np.int32)
+        if marks is not None:
+            marks = np.ascontiguousarray(marks, np.int32)
+            assert marks.shape == keys.shape
         lens = np.ascontiguousarray(lens, np.int32)
         pos = np.zeros(keys.shape, np.int32)
         flags = np.zeros(keys.shape[0], np.int32)
-        self._check(self.lib.dmz_hip_expiry_sort_positions(self.h, keys.ctypes.data, lens.ctypes.data, keys.shape[0],
+        self._check(self.lib.dmz_hip_expiry_sort_positions(self.h, keys.ctypes.data,
+                                                           marks.ctypes.data if marks is not None else None,
+                                                           lens.ctypes.data, keys.shape[0],
                                                            keys.shape[1], kind, pos.ctypes.data, flags.ctypes.data))
         return pos, flags
 

@@ -1526,13 +1526,13 @@ int dmz_hip_apply_expiry_model(dmz_hip_context *ctx, const float *x, int n, floa
   return run_model(ctx, 3, 0, x, n, out, 176, 10);
 }
 
-int dmz_hip_expiry_sort_positions(dmz_hip_context *ctx, const int32_t *keys, const int32_t *lens, int n_lists, int stride,
-                                  int kind, int32_t *pos, int32_t *flags) {
+int dmz_hip_expiry_sort_positions(dmz_hip_context *ctx, const int32_t *keys, const int32_t *marks, const int32_t *lens,
+                                  int n_lists, int stride, int kind, int32_t *pos, int32_t *flags) {
   if (!ctx) return DMZ_HIP_EINVAL;
   if (!keys || !lens || !pos || !flags || n_lists <= 0 || stride <= 0 || kind < 0 || kind > 2)
     return fail(ctx, DMZ_HIP_EINVAL, "bad sort-order arguments");
   const int max_len = kind == 2 ? 128 : 420;
-  const int64_t max_key = kind == 2 ? (1 << 25) : (1 << 23);
+  const int64_t max_key = kind == 2 ? (1 << 25) : (1 << 20);
   for (int l = 0; l < n_lists; l++) {
     if (lens[l] < 0 || lens[l] > max_len || lens[l] > stride) return fail(ctx, DMZ_HIP_EINVAL, "list too long");
     for (int i = 0; i < lens[l]; i++)
@@ -1542,13 +1542,15 @@ int dmz_hip_expiry_sort_positions(dmz_hip_context *ctx, const int32_t *keys, con
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t kb = sizeof(int32_t) * (size_t)n_lists * stride, lb = sizeof(int32_t) * (size_t)n_lists;
   int rc;
-  if ((rc = ensure(ctx, ctx->misc, 2 * kb + 2 * lb))) return rc;
+  if ((rc = ensure(ctx, ctx->misc, 3 * kb + 2 * lb))) return rc;
   char *base = (char *)ctx->misc.p;
-  int *dk = (int *)base, *dp = (int *)(base + kb), *dl = (int *)(base + 2 * kb), *df = (int *)(base + 2 * kb + lb);
+  int *dk = (int *)base, *dp = (int *)(base + kb), *dm = (int *)(base + 2 * kb), *dl = (int *)(base + 3 * kb),
+      *df = (int *)(base + 3 * kb + lb);
   HIP_TRY(ctx, hipMemcpyAsync(dk, keys, kb, hipMemcpyHostToDevice, ctx->stream));
+  if (marks) HIP_TRY(ctx, hipMemcpyAsync(dm, marks, kb, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(dl, lens, lb, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dp, 0, kb, ctx->stream));
-  dmz_launch_sort_order(ctx->stream, dk, dl, n_lists, stride, kind, dp, df);
+  dmz_launch_sort_order(ctx->stream, dk, marks ? dm : nullptr, dl, n_lists, stride, kind, dp, df);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(pos, dp, kb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(flags, df, lb, hipMemcpyDeviceToHost, ctx->stream));

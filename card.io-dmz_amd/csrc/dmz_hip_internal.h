@@ -207,8 +207,8 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* d
                        const dmz_hip_frame_result *results, DmzExpiryStage *stage /* n x 3 */,
                        dmz_hip_expiry_result *out, hipEvent_t mid /* recorded between seg and cat, or null */,
                        int conv_mode /* DMZ_HIP_EXPIRY_CONV_* */, int phases = 3 /* 1: stripes + seg, 2: cat */);
-void dmz_launch_sort_order(hipStream_t s, const int *keys, const int *lens, int n_lists, int stride, int kind, int *pos,
-                           int *flags);
+void dmz_launch_sort_order(hipStream_t s, const int *keys, const int *marks /* or null */, const int *lens, int n_lists,
+                           int stride, int kind, int *pos, int *flags);
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out);
 void dmz_launch_expiry_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out,
                              int conv_mode);

@@ -12,10 +12,12 @@
 //
 // Elements are packed as (sum << SH) | index; the comparator looks at the sum only.
 //   serial_sort      one lane, the whole std::sort (heap sort included): v[] ends up in the library's final order.
-//   wave_partitions  a whole wave, the partition phase only, level by level over ALL ranges of a level at once (every
-//                    range of one level has the same depth limit); NS consecutive positions per lane.  Returns false when
-//                    the depth limit is reached (adversarial inputs): the caller then takes serial_sort.
+//   wave_mark_partitions  a whole wave, the partition phase only, and only the ranges that still hold two MARKED elements
+//                    (the elements whose order the caller needs).  Returns false when the depth limit is reached
+//                    (adversarial inputs): the caller then takes serial_sort.
 #pragma once
+
+#include "dmz_wave.h"
 
 namespace dmzsort {
 
@@ -126,148 +128,150 @@ __device__ inline void serial_sort(unsigned *v, int n, unsigned *stack) {
   for (int i = head; i < n; ++i) linear_insert<SH>(v, i);
 }
 
-// The partition phase for a wave: position p = NS lane + j holds e[j] (p < n); on return e[] is the arrangement the
-// introsort loop leaves.  LDS: v[n] dwords (element exchange; between the exchanges it holds, per range, the k-th stop of
-// the left scan and of the right scan as two 16-bit halves), and three small tables indexed by (range start >> 4) -- ranges
-// in work are longer than 16, so that index is unique among them: tabP (the pivot, later the cut), tabB / tabE (how many
-// left / right stops precede the range's start / lie before its end).  One wave per workgroup: __syncthreads() orders
-// the LDS phases.
+// The partition phase for a wave, restricted to what the caller needs: the relative order of MARKED elements (bit 29 of an
+// element; the caller marks the elements whose order among equal sums can matter).  v[0 .. n) is the list in LDS; ranges are
+// taken one at a time (explicit stack), a range is partitioned only while it is longer than 16 AND holds at least two marked
+// elements -- the arrangement inside any other range cannot change the order of two marked elements with equal sums (ranges are
+// disjoint, and an element never leaves its range).  On return every marked element sits where the library's partition
+// phase would leave it relative to every other marked element of equal sum.  Returns false when a range reaches the depth
+// limit (adversarial inputs): the caller then takes serial_sort.
 //
-// A Hoare partition in closed form: with a_1 < a_2 < ... the positions (after `first`) whose element is NOT "> pivot" and
-// b_1 > b_2 > ... those whose element is NOT "< pivot", the loop swaps (a_k, b_k) for k = 1 .. K while a_k < b_k, and returns
-// a_{K+1} if that lies before b_K (b_0 = last), else b_K; untouched positions keep their elements, the pivot stays at first.
-template <int NS, int SH>
-__device__ __forceinline__ bool wave_partitions(unsigned (&e)[NS], const int n, const int lane, unsigned *v, unsigned *tabP,
-                                                unsigned *tabB, unsigned *tabE) {
-  unsigned FL[NS];  // range of the slot's position: first | last << 16
-#pragma unroll
-  for (int j = 0; j < NS; j++) FL[j] = (unsigned)n << 16;
-  if (n <= 16) return true;
-  int depth = 2 * (31 - __builtin_clz((unsigned)n));
-  unsigned short *const pair = (unsigned short *)v;
-  for (;;) {
-    bool act[NS];
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int p = NS * lane + j;
-      act[j] = p < n && (int)(FL[j] >> 16) - (int)(FL[j] & 0xffffu) > 16;
-      any |= act[j];
+// One range [F, L), position p = F + 64 j + lane in slot j.  A Hoare partition in closed form: with a_1 < a_2 < ... the
+// positions after F whose element is NOT "> pivot" and b_1 > b_2 > ... those whose element is NOT "< pivot", the loop swaps
+// (a_k, b_k) for k = 1 .. K while a_k < b_k, and returns a_{K+1} if that lies before b_K (b_0 = L), else b_K; untouched
+// positions keep their elements, the pivot stays at F.  Ranks are ballots + popcounts, the k-th stops meet in T[k]
+// (16-bit halves; K <= 209), the exchange reads the old arrangement before it writes (LDS operations of one wave execute
+// in order).  One wave per workgroup; no barriers are needed, only the compiler must keep the order of the LDS accesses.
+constexpr unsigned MARK = 1u << 29;
+constexpr int TPAIRS = 210;
+#define DMZ_LDS_ORDER() __asm__ volatile("" ::: "memory")
+
+// one partition of [F, L) with NS >= ceil((L - F) / 64) slots, straight-line: every LDS load of a phase is issued before the
+// first one is used (addresses of idle slots are clamped to something readable), so a partition costs four LDS round trips.
+// Returns the cut; mL / mR = marked elements left / right of it.
+template <int NS, int SH, unsigned KMASK>
+__device__ __forceinline__ int partition_range(unsigned *v, const int F, const int L, const int lane, unsigned *T, int &mL,
+                                               int &mR) {
+  unsigned short *const T16 = (unsigned short *)T;
+  // __move_median_to_first(F, F + 1, mid, L - 1): wave-uniform
+  unsigned pk;
+  {
+    const int a = F + 1, b = F + ((L - F) >> 1), c = L - 1;
+    const unsigned ea = v[a], eb = v[b], ec = v[c], ef = v[F];
+    const unsigned ka = (ea >> SH) & KMASK, kb = (eb >> SH) & KMASK, kc = (ec >> SH) & KMASK;
+    const int m = ka > kb ? (kb > kc ? b : (ka > kc ? c : a)) : (ka > kc ? a : (kb > kc ? c : b));
+    const unsigned em = m == a ? ea : (m == b ? eb : ec);
+    pk = (unsigned)__builtin_amdgcn_readfirstlane((int)((em >> SH) & KMASK));
+    DMZ_LDS_ORDER();
+    if (lane == 0) {
+      v[m] = ef;
+      v[F] = em;
     }
-    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return true;
+    DMZ_LDS_ORDER();
+  }
+  unsigned e[NS], rA[NS], rB[NS];
+  bool inA[NS], inB[NS], valid[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int p = F + 64 * j + lane;
+    valid[j] = p < L;
+    e[j] = v[valid[j] ? p : F];
+  }
+  int nA = 0, nB = 0;
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int p = F + 64 * j + lane;
+    const unsigned k = (e[j] >> SH) & KMASK;
+    inA[j] = valid[j] && p != F && k <= pk;
+    inB[j] = valid[j] && p != F && k >= pk;
+    const unsigned long long ba = __builtin_amdgcn_ballot_w64(inA[j]), bb = __builtin_amdgcn_ballot_w64(inB[j]);
+    rA[j] = __builtin_amdgcn_mbcnt_hi((unsigned)(ba >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ba, (unsigned)nA));
+    rB[j] = __builtin_amdgcn_mbcnt_hi((unsigned)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bb, (unsigned)nB));
+    nA += __popcll(ba);
+    nB += __popcll(bb);
+  }
+  DMZ_LDS_ORDER();
+  const unsigned npair = (unsigned)(nA < nB ? (nA < TPAIRS ? nA : TPAIRS) : (nB < TPAIRS ? nB : TPAIRS));
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int p = F + 64 * j + lane;
+    rB[j] = (unsigned)(nB - 1) - rB[j];  // rank among the right stops, from the right
+    if (inA[j] && rA[j] < npair) T16[2 * rA[j]] = (unsigned short)p;
+    if (inB[j] && rB[j] < npair) T16[2 * rB[j] + 1] = (unsigned short)p;
+  }
+  DMZ_LDS_ORDER();
+  unsigned tA[NS], tB[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    tA[j] = T[inA[j] && rA[j] < npair ? rA[j] : 0u];
+    tB[j] = T[inB[j] && rB[j] < npair ? rB[j] : 0u];
+  }
+  int src[NS];
+  unsigned stop = 0xffffu;  // the first left stop that stays / the last right stop that moves: the cut is the smaller
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int p = F + 64 * j + lane;
+    const int bk = (int)(tA[j] >> 16), ak = (int)(tB[j] & 0xffffu);
+    const bool swA = inA[j] && rA[j] < npair && p < bk;
+    const bool swB = inB[j] && rB[j] < npair && ak < p;
+    src[j] = swA ? bk : (swB ? ak : (valid[j] ? p : F));
+    if ((inA[j] && !swA) || swB) stop = stop < (unsigned)p ? stop : (unsigned)p;
+  }
+  const int first_stop = (int)dmzwave::min_u32(stop);
+  const int cut = first_stop < L ? first_stop : L;
+  DMZ_LDS_ORDER();
+  unsigned en[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) en[j] = v[src[j]];  // the old arrangement
+  DMZ_LDS_ORDER();
+  mL = mR = 0;
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int p = F + 64 * j + lane;
+    if (valid[j] && src[j] != p) v[p] = en[j];
+    const bool mk = valid[j] && (en[j] & MARK) != 0u;
+    mL += __popcll(__builtin_amdgcn_ballot_w64(mk && p < cut));
+    mR += __popcll(__builtin_amdgcn_ballot_w64(mk && p >= cut));
+  }
+  DMZ_LDS_ORDER();
+  return cut;
+}
+
+template <int SH, unsigned KMASK>
+__device__ __forceinline__ bool wave_mark_partitions(unsigned *v, const int n, const int lane, unsigned *T, unsigned *stack) {
+  if (n <= 16) return true;
+  int sp = 0;
+  int F = 0, L = n, depth = 2 * (31 - __builtin_clz((unsigned)n));
+  for (;;) {
     if (depth == 0) return false;
     --depth;
-#pragma unroll
-    for (int j = 0; j < NS; j++)
-      if (NS * lane + j < n) v[NS * lane + j] = e[j];
-    __syncthreads();
-    // the slot at a range's first position moves the median of three there
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int p = NS * lane + j, F = (int)(FL[j] & 0xffffu), L = (int)(FL[j] >> 16);
-      if (act[j] && p == F) {
-        const int a = F + 1, b = F + (L - F) / 2, c = L - 1;
-        const unsigned ea = v[a], eb = v[b], ec = v[c];
-        int m;
-        if (gt<SH>(ea, eb)) m = gt<SH>(eb, ec) ? b : (gt<SH>(ea, ec) ? c : a);
-        else m = gt<SH>(ea, ec) ? a : (gt<SH>(eb, ec) ? c : b);
-        const unsigned em = m == a ? ea : (m == b ? eb : ec);
-        v[m] = e[j];
-        v[F] = em;
-        tabP[F >> 4] = em;
-      }
+    const int len = L - F;
+    int mL, mR, cut;
+#if defined(DMZ_SORT_ONE_FORM)  /* developer ablation: one instantiation (code size) */
+    cut = partition_range<7, SH, KMASK>(v, F, L, lane, T, mL, mR);
+#else
+    if (len <= 64) cut = partition_range<1, SH, KMASK>(v, F, L, lane, T, mL, mR);
+    else if (len <= 128) cut = partition_range<2, SH, KMASK>(v, F, L, lane, T, mL, mR);
+    else if (len <= 256) cut = partition_range<4, SH, KMASK>(v, F, L, lane, T, mL, mR);
+    else cut = partition_range<7, SH, KMASK>(v, F, L, lane, T, mL, mR);
+#endif
+    const bool goL = cut - F > 16 && mL >= 2, goR = L - cut > 16 && mR >= 2;
+    if (goL && goR) {
+      if (lane == 0) stack[sp] = (unsigned)cut | ((unsigned)L << 10) | ((unsigned)depth << 20);
+      sp++;
+      L = cut;
+    } else if (goL) {
+      L = cut;
+    } else if (goR) {
+      F = cut;
+    } else {
+      if (sp == 0) return true;
+      DMZ_LDS_ORDER();
+      const unsigned s = (unsigned)__builtin_amdgcn_readfirstlane((int)stack[--sp]);
+      F = (int)(s & 1023u), L = (int)((s >> 10) & 1023u), depth = (int)(s >> 20);
     }
-    __syncthreads();
-    bool inA[NS], inB[NS];
-    unsigned cA = 0u, cB = 0u;  // stops in the lanes below
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int p = NS * lane + j, F = (int)(FL[j] & 0xffffu);
-      if (p < n) e[j] = v[p];
-      const unsigned pk = act[j] ? tabP[F >> 4] >> SH : 0u;
-      const unsigned k = e[j] >> SH;
-      inA[j] = act[j] && p != F && k <= pk;
-      inB[j] = act[j] && p != F && k >= pk;
-      const unsigned long long ba = __builtin_amdgcn_ballot_w64(inA[j]), bb = __builtin_amdgcn_ballot_w64(inB[j]);
-      cA = __builtin_amdgcn_mbcnt_hi((unsigned)(ba >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ba, cA));
-      cB = __builtin_amdgcn_mbcnt_hi((unsigned)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bb, cB));
-    }
-    unsigned pax[NS], pbx[NS];  // stops before the slot's position, over the whole list
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      pax[j] = cA, pbx[j] = cB;
-      cA += inA[j] ? 1u : 0u;
-      cB += inB[j] ? 1u : 0u;
-      const int p = NS * lane + j, F = (int)(FL[j] & 0xffffu), L = (int)(FL[j] >> 16);
-      if (act[j] && p == F) tabB[F >> 4] = pax[j] | (pbx[j] << 16);
-      if (act[j] && p == L - 1) tabE[F >> 4] = cA | (cB << 16);
-    }
-    __syncthreads();
-    unsigned rA[NS], rB[NS], nAB[NS];
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int F = (int)(FL[j] & 0xffffu);
-      rA[j] = rB[j] = nAB[j] = 0u;
-      if (act[j]) {
-        const unsigned bs = tabB[F >> 4], en = tabE[F >> 4];
-        const unsigned nA = (en & 0xffffu) - (bs & 0xffffu), nB = (en >> 16) - (bs >> 16);
-        nAB[j] = nA | (nB << 16);
-        rA[j] = pax[j] - (bs & 0xffffu);             // rank among the left stops, from the left
-        rB[j] = nB - 1u - (pbx[j] - (bs >> 16));     // rank among the right stops, from the right
-      }
-    }
-    __syncthreads();  // (the tables were read; v is rewritten as the pair table)
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int p = NS * lane + j, F = (int)(FL[j] & 0xffffu);
-      if (inA[j]) pair[2 * (F + (int)rA[j])] = (unsigned short)p;
-      if (inB[j]) pair[2 * (F + (int)rB[j]) + 1] = (unsigned short)p;
-    }
-    __syncthreads();
-    int src[NS];
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int p = NS * lane + j, F = (int)(FL[j] & 0xffffu), L = (int)(FL[j] >> 16);
-      const unsigned nA = nAB[j] & 0xffffu, nB = nAB[j] >> 16;
-      src[j] = p;
-      if (inA[j]) {
-        const unsigned cur = v[F + (int)rA[j]];
-        const bool sw = rA[j] < nB && p < (int)(cur >> 16);
-        if (sw) {
-          src[j] = (int)(cur >> 16);
-        } else {
-          const unsigned prev = rA[j] > 0u ? v[F + (int)rA[j] - 1] : 0u;
-          const bool sw_prev = rA[j] > 0u && rA[j] - 1u < nB && (prev & 0xffffu) < (prev >> 16);
-          if (rA[j] == 0u || sw_prev) {  // the first left stop that stays: the cut is here, or at the last right stop swapped
-            const int bK = rA[j] > 0u ? (int)(prev >> 16) : L;
-            tabP[F >> 4] = (unsigned)(p < bK ? p : bK);
-          }
-        }
-      }
-      if (inB[j]) {
-        const unsigned cur = v[F + (int)rB[j]];
-        if (rB[j] < nA && (int)(cur & 0xffffu) < p) {
-          src[j] = (int)(cur & 0xffffu);
-          if (rB[j] + 1u == nA) tabP[F >> 4] = (unsigned)p;  // every left stop was swapped: the scan ends on the last right one
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NS; j++)
-      if (NS * lane + j < n) v[NS * lane + j] = e[j];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-      const int p = NS * lane + j, F = (int)(FL[j] & 0xffffu), L = (int)(FL[j] >> 16);
-      if (src[j] != p) e[j] = v[src[j]];
-      if (act[j]) {
-        const int cut = (int)tabP[F >> 4];
-        FL[j] = p < cut ? ((unsigned)F | ((unsigned)cut << 16)) : ((unsigned)cut | ((unsigned)L << 16));
-      }
-    }
-    __syncthreads();
   }
 }
+#undef DMZ_LDS_ORDER
 
 }  // namespace dmzsort

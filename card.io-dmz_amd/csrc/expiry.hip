@@ -172,13 +172,12 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
     for (int round = 0; round < 3; round++) {
       const unsigned m = wave_max_u32(key[0] > key[1] ? key[0] : key[1]);
       if (m == 0u) break;
-      const int idx = 127 - (int)(m & 127u);
-      if (watch) {  // the best sum again, preferring the LAST of its holders
-        const unsigned r0 = key[0] ? (key[0] | 127u) - (127u - (unsigned)lane) : 0u;
-        const unsigned r1 = key[1] ? (key[1] | 127u) - (127u - (unsigned)(lane + 64)) : 0u;
-        const unsigned m2 = wave_max_u32(r0 > r1 ? r0 : r1);
-        tie |= (m2 >> 7) == (m >> 7) && (int)(m2 & 127u) != idx;
-      }
+      // the holder of the best key (keys are distinct); its low bits are the row only in the watched run
+      const unsigned long long h0 = __builtin_amdgcn_ballot_w64(key[0] == m), h1 = __builtin_amdgcn_ballot_w64(key[1] == m);
+      const int idx = h0 ? __builtin_ctzll(h0) : 64 + __builtin_ctzll(h1);
+      if (watch)  // another live candidate with the best sum?
+        tie |= __builtin_amdgcn_ballot_w64((key[0] != m && (key[0] >> 7) == (m >> 7)) ||
+                                           (key[1] != m && (key[1] >> 7) == (m >> 7))) != 0ull;
       if (lane == 0) {
         out[f].stripe_base_row[np] = y0 + 1 + idx;
         out[f].stripe_sum[np] = (int64_t)(m >> 7);
@@ -229,6 +228,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #ifndef DMZ_XSEG_STOP
 #define DMZ_XSEG_STOP 99
 #endif
+#ifndef DMZ_XSEG_TIES  /* developer ablation (timing only, wrong ties): 0 = column tie-break, no watch; 1 = watch, never re-order */
+#define DMZ_XSEG_TIES 2
+#endif
 #ifndef DMZ_XSEG_FOLD  /* developer switch: 0 = the slash MLP always on Scharr samples */
 #define DMZ_XSEG_FOLD 1
 #endif
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
     if (lane == 0) sg->n = (int)(expr) & 0;    \
     return;                                    \
   }
+#ifdef DMZ_XSEG_DBG  /* developer timing of the pick (tools/dev/xseg_dbg.py): stripes, re-ordered stripes, cycles */
+__device__ unsigned long long g_xs_dbg[8];
+#endif
 constexpr int IROWS = 23;    // inter rows: image rows base-4 .. base+18 (clamped to the ROI)
 constexpr int ISTRIDE = 428; // bytes per inter row (107 dwords)
 constexpr int XT_PITCH = 20; // bytes per row of a thresholded character tile (19 used)
@@ -251,7 +256,7 @@ struct SegLds {
     int colA[428];                       // column sums over rows base .. base+16, until the rect sums are in registers
     struct {                             // the candidate order of the pick when equal sums matter (dmz_stdsort.h)
       unsigned v[420];
-      unsigned tabP[26], tabB[26], tabE[26];
+      unsigned stack[36];
     } s;
     struct {                             // the picked rects sorted by left, until the local groups are formed
       int itemS[64];
@@ -367,6 +372,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   const uint8_t *card = cards + (size_t)f * card_stride;
   DmzExpiryStage *sg = stage + (size_t)f * 3 + st;
   int n_emitted = 0;
+#ifdef DMZ_XSEG_DBG
+  const long long dbg_start = __builtin_readcyclecounter();
+#endif
   // window rows k = 0..20 <-> image rows base-3+k; the Scharr image is zero outside [y0, 269]
   unsigned vmask = 0u;
   for (int k = 0; k < 21; k++) {
@@ -558,10 +566,54 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     if (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
       key[j] = ((unsigned)rs7[j] << 9) | (unsigned)(511 - (7 * lane + j));
   }
-  if (pick_rounds(true)) {
-    // rect_list: the windows above the first threshold in column order (expiry_seg.cpp:461-470); std::sort (:496)
+#ifdef DMZ_XSEG_DBG
+  const long long dbg_t0 = __builtin_readcyclecounter();
+  const bool dbg_tie = pick_rounds(true);
+  const long long dbg_t1 = __builtin_readcyclecounter();
+  if (lane == 0) {
+    atomicAdd(&g_xs_dbg[0], 1ull);
+    atomicAdd(&g_xs_dbg[1], dbg_tie ? 1ull : 0ull);
+    atomicAdd(&g_xs_dbg[2], (unsigned long long)(dbg_t1 - dbg_t0));
+  }
+  if (dbg_tie) {
+#else
+  if (pick_rounds(DMZ_XSEG_TIES >= 1) && DMZ_XSEG_TIES >= 2 && (DMZ_XSEG_TIES != 3 || n == -12345)) {  // (3: the code is there, never run)
+#endif
+    // Whose order can matter: candidates with an equal sum within eight columns (only such a pair can ever be a pick and
+    // its live neighbour, in this run or in the repeated one).  Bit j of `mark`: the window at column 7 lane + j.
+    unsigned mark = 0u;
+    {
+      auto below = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); };
+      auto above = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); };
+      unsigned cs[7], nx[7];  // candidate sums (0: not a candidate; a candidate's sum is >= 1), the next lane's
+#pragma unroll
+      for (int j = 0; j < 7; j++) cs[j] = (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2) ? (unsigned)rs7[j] : 0u;
+#pragma unroll
+      for (int j = 0; j < 7; j++) nx[j] = above(cs[j]);
+      const unsigned nx2 = above(nx[0]);  // column 7 (lane + 2)
+      unsigned fwd1 = 0u, fwd2 = 0u;      // partners found in the next lane's slots / in slot 0 of the lane after it
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        if (cs[j] == 0u) continue;
+#pragma unroll
+        for (int k = j + 1; k < 7; k++)  // columns c + 1 .. within the own lane
+          if (cs[k] == cs[j]) mark |= (1u << j) | (1u << k);
+#pragma unroll
+        for (int k = 0; k <= (j < 6 ? j + 1 : 6); k++)  // columns 7 (lane + 1) + k <= c + 8
+          if (nx[k] == cs[j]) mark |= 1u << j, fwd1 |= 1u << k;
+        if (j == 6 && nx2 == cs[j]) mark |= 1u << j, fwd2 = 1u;
+      }
+      mark |= below(fwd1) | below(below(fwd2));
+    }
+    // rect_list: the windows above the first threshold in column order (expiry_seg.cpp:461-470); std::sort (:496).
+    // The partition phase needs a table of 210 dwords beside the list: the first 210 column sums of colB (kept for
+    // regrid_group) wait in registers meanwhile.
     unsigned *const sv = L.u.s.v;
-    auto fill_list = [&]() {
+    unsigned *const tb = (unsigned *)L.colB;
+    int keep[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) keep[i] = lane + 64 * i < dmzsort::TPAIRS ? L.colB[lane + 64 * i] : 0;
+    auto fill_list = [&](bool marks) {
       unsigned pos = 0u;
 #pragma unroll
       for (int j = 0; j < 7; j++) {
@@ -570,36 +622,47 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       }
 #pragma unroll
       for (int j = 0; j < 7; j++)
-        if (lane < 60 && (float)rs7[j] > thr1) sv[pos++] = ((unsigned)rs7[j] << 9) | (unsigned)(7 * lane + j);
+        if (lane < 60 && (float)rs7[j] > thr1)
+          sv[pos++] = ((unsigned)rs7[j] << 9) | (unsigned)(7 * lane + j) | ((marks && ((mark >> j) & 1u)) ? dmzsort::MARK : 0u);
       __syncthreads();
     };
-    fill_list();
-    unsigned e[7];
-#pragma unroll
-    for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < cnt ? sv[7 * lane + j] : 0u;
-    __syncthreads();
-    if (!dmzsort::wave_partitions<7, 9>(e, cnt, lane, sv, L.u.s.tabP, L.u.s.tabB, L.u.s.tabE)) {
-      // the depth limit of the introsort loop (adversarial lists only): the library's whole sort on one lane
-      fill_list();
-      if (lane == 0) dmzsort::serial_sort<9>(sv, cnt, L.u.s.tabP);
+    fill_list(true);
+    if (!dmzsort::wave_mark_partitions<9, 0xFFFFFu>(sv, cnt, lane, tb, L.u.s.stack)) {
+      // the depth limit of the introsort loop (adversarial lists only): the library's whole sort on one lane, every
+      // window then carries its final position
       __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < cnt ? sv[7 * lane + j] : 0u;
-      __syncthreads();
+      fill_list(false);
+      if (lane == 0) dmzsort::serial_sort<9>(sv, cnt, L.u.s.stack);
+      mark = 0x7Fu;
     }
-    unsigned short *const sq = (unsigned short *)sv;  // position of each column's window in that order
-#pragma unroll
-    for (int j = 0; j < 7; j++)
-      if (7 * lane + j < cnt) sq[e[j] & 511u] = (unsigned short)(7 * lane + j);
+    __syncthreads();
+    unsigned short *const sq = (unsigned short *)tb;  // position of a column's window in that order (marked windows)
+    for (int p = lane; p < cnt; p += 64) {
+      const unsigned el = sv[p];
+      sq[el & 511u] = (unsigned short)p;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 7; j++) {
       key[j] = 0u;
       if (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
-        key[j] = ((unsigned)rs7[j] << 9) | (511u - (unsigned)sq[7 * lane + j]);
+        key[j] = ((unsigned)rs7[j] << 9) | (511u - (((mark >> j) & 1u) ? (unsigned)sq[7 * lane + j] : (unsigned)(7 * lane + j)));
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (lane + 64 * i < dmzsort::TPAIRS) L.colB[lane + 64 * i] = keep[i];
+#ifdef DMZ_XSEG_DBG
+    const long long dbg_t2 = __builtin_readcyclecounter();
+#endif
     pick_rounds(false);
+#ifdef DMZ_XSEG_DBG
+    const long long dbg_t3 = __builtin_readcyclecounter();
+    if (lane == 0) {
+      atomicAdd(&g_xs_dbg[3], (unsigned long long)(dbg_t2 - dbg_t1));
+      atomicAdd(&g_xs_dbg[4], (unsigned long long)(dbg_t3 - dbg_t2));
+    }
+#endif
   }
   XSEG_STOP(4, picked)
   // sorted by left = column order = lane-major, slot-minor: a lane's first item follows the picks of the lanes below
@@ -1009,6 +1072,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
   }
   if (lane == 0) sg->n = n_emitted;
+#ifdef DMZ_XSEG_DBG
+  if (lane == 0) atomicAdd(&g_xs_dbg[5], (unsigned long long)(__builtin_readcyclecounter() - dbg_start)), atomicAdd(&g_xs_dbg[6], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1745,48 +1811,45 @@ __global__ __launch_bounds__(XC_THREADS, 3) void k_expiry_model(const float *__r
 // ---------------------------------------------------------------------------------------------
 // k_sort_order: the candidate order of dmz_stdsort.h on caller-supplied key lists (diagnostic entry
 // dmz_hip_expiry_sort_positions; tests/test_gpu_expiry.py checks it against the reference's own std::sort).
-// One wave per list.  pos[i] = position of element i: kind 0 after the partition phase (wave form, the form k_expiry_seg
-// uses; the final order is "key descending, then pos"), kinds 1 / 2 after the whole sort on one lane (9- / 7-bit index field).
+// One wave per list.  pos[i] = position of element i: kind 0 after the partition phase as far as the wave form follows
+// it (the form k_expiry_seg uses: marked elements -- marks[i] != 0, all if marks is null -- are ordered among equal keys by
+// "key descending, then pos"), kinds 1 / 2 after the whole sort on one lane (9- / 7-bit index field).
 // flags[list] = 1 when the wave form hit the depth limit and the serial form took over.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sort_order(const int *__restrict__ keys, const int *__restrict__ lens, int stride,
-                                                   int kind, int *__restrict__ pos, int *__restrict__ flags) {
+__global__ __launch_bounds__(64) void k_sort_order(const int *__restrict__ keys, const int *__restrict__ marks,
+                                                   const int *__restrict__ lens, int stride, int kind, int *__restrict__ pos,
+                                                   int *__restrict__ flags) {
   __shared__ unsigned sv[448];
-  __shared__ unsigned tabP[28], tabB[28], tabE[28];
+  __shared__ unsigned tb[dmzsort::TPAIRS];
+  __shared__ unsigned stack[36];
   const int list = blockIdx.x, lane = threadIdx.x;
   const int n = lens[list];
   const int *k = keys + (size_t)list * stride;
+  const int *mk = marks ? marks + (size_t)list * stride : nullptr;
   int *po = pos + (size_t)list * stride;
   int fell_back = 0;
+  const int sh = kind == 2 ? 7 : 9;
+  for (int i = lane; i < n; i += 64)
+    sv[i] = ((unsigned)k[i] << sh) | (unsigned)i | ((kind == 0 && (!mk || mk[i])) ? dmzsort::MARK : 0u);
+  __syncthreads();
+  bool sorted = false;
   if (kind == 0) {
-    unsigned e[7];
-#pragma unroll
-    for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < n ? ((unsigned)k[7 * lane + j] << 9) | (unsigned)(7 * lane + j) : 0u;
-    if (!dmzsort::wave_partitions<7, 9>(e, n, lane, sv, tabP, tabB, tabE)) {
+    sorted = dmzsort::wave_mark_partitions<9, 0xFFFFFu>(sv, n, lane, tb, stack);
+    __syncthreads();
+    if (!sorted) {
       fell_back = 1;
-#pragma unroll
-      for (int j = 0; j < 7; j++)
-        if (7 * lane + j < n) sv[7 * lane + j] = ((unsigned)k[7 * lane + j] << 9) | (unsigned)(7 * lane + j);
+      for (int i = lane; i < n; i += 64) sv[i] = ((unsigned)k[i] << 9) | (unsigned)i;
       __syncthreads();
-      if (lane == 0) dmzsort::serial_sort<9>(sv, n, tabP);
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 7; j++) e[j] = 7 * lane + j < n ? sv[7 * lane + j] : 0u;
     }
-#pragma unroll
-    for (int j = 0; j < 7; j++)
-      if (7 * lane + j < n) po[e[j] & 511u] = 7 * lane + j;
-  } else {
-    const int sh = kind == 1 ? 9 : 7;
-    for (int i = lane; i < n; i += 64) sv[i] = ((unsigned)k[i] << sh) | (unsigned)i;
-    __syncthreads();
-    if (lane == 0) {
-      if (kind == 1) dmzsort::serial_sort<9>(sv, n, tabP);
-      else dmzsort::serial_sort<7>(sv, n, tabP);
-    }
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) po[sv[i] & ((1u << sh) - 1u)] = i;
   }
+  if (!sorted) {
+    if (lane == 0) {
+      if (sh == 9) dmzsort::serial_sort<9>(sv, n, stack);
+      else dmzsort::serial_sort<7>(sv, n, stack);
+    }
+    __syncthreads();
+  }
+  for (int i = lane; i < n; i += 64) po[sv[i] & ((1u << sh) - 1u)] = i;
   if (lane == 0) flags[list] = fell_back;
 }
 
@@ -1833,9 +1896,20 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
                        n, results, stage, out);
 }
 
-void dmz_launch_sort_order(hipStream_t s, const int *keys, const int *lens, int n_lists, int stride, int kind, int *pos,
-                           int *flags) {
-  hipLaunchKernelGGL(k_sort_order, dim3((unsigned)n_lists), dim3(64), 0, s, keys, lens, stride, kind, pos, flags);
+#ifdef DMZ_XSEG_DBG
+extern "C" void dmz_dbg_xseg(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xs_dbg), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_xs_dbg), z, sizeof(z));
+  }
+}
+#endif
+
+void dmz_launch_sort_order(hipStream_t s, const int *keys, const int *marks, const int *lens, int n_lists, int stride, int kind,
+                           int *pos, int *flags) {
+  hipLaunchKernelGGL(k_sort_order, dim3((unsigned)n_lists), dim3(64), 0, s, keys, marks, lens, stride, kind, pos, flags);
 }
 
 void dmz_launch_slash_model(hipStream_t s, const float *weights, const float *xw, const float *x, int n, float *out) {

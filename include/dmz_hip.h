@@ -297,13 +297,18 @@ int dmz_hip_apply_expiry_model(dmz_hip_context *ctx, const float *x /* n x 16 x 
 /* The candidate order of the expiry segmentation on caller-supplied lists (host pointers): the reference
  * sorts its window sums and stripe sums with std::sort and a "sum >" comparator (scan/expiry_seg.cpp:75-87, 456,
  * 842), and which of two EQUAL sums comes first is libstdc++'s introsort permutation.  pos[list * stride + i] =
- * position of element i of that list: kind 0 after the introsort's partition phase, computed by a whole wave as
- * k_expiry_seg does (the final order is "key descending, then pos": the closing insertion sort is stable); kind 1 /
- * 2 after the complete sort on one lane (keys < 2^23 / 2^25, lens <= 420 / 128).  kind 0: keys < 2^23, lens <= 420.
+ * position of element i of that list:
+ *   kind 0  the form k_expiry_seg uses: a wave follows the introsort's partition phase through every range that still
+ *           holds two MARKED elements (marks[list * stride + i] != 0; marks == NULL marks all): any two marked elements
+ *           with equal keys are then in the library's order by their pos (the closing insertion sort is stable, so
+ *           with all marked the library's whole order is "key descending, then pos").  keys < 2^20, lens <= 420;
+ *   kind 1 / 2  the complete sort on one lane (k_expiry_stripes' form, and kind 0's fall-back): pos is the final
+ *           position.  keys < 2^20 / 2^25, lens <= 420 / 128.
  * flags[list] = 1 when the wave form met the introsort's depth limit and the one-lane form took over.
- * Known-answer entry like the model passes below (tests/test_gpu_expiry.py: against the reference's own
+ * Known-answer entry like the model passes above (tests/test_gpu_expiry.py: against the reference's own
  * instantiation of std::sort). */
 int dmz_hip_expiry_sort_positions(dmz_hip_context *ctx, const int32_t *keys /* n_lists x stride */,
+                                  const int32_t *marks /* n_lists x stride, or NULL */,
                                   const int32_t *lens /* n_lists */, int n_lists, int stride, int kind,
                                   int32_t *pos /* n_lists x stride */, int32_t *flags /* n_lists */);
 

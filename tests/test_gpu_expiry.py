@@ -121,6 +121,34 @@ def test_candidate_order_on_device_is_std_sort(ctx, oracle, orc):
         print("sort kind %d: %d lists, %d through the depth-limit fall-back" % (kind, len(lists), int(flags.sum())))
         # the adversarial lists drive the wave form into its fall-back; nothing else does
         assert (flags.sum() > 0) == (kind == 0)
+        if kind != 0:
+            continue
+        # the wave form follows only the ranges that still hold two MARKED elements: any two marked elements with equal keys
+        # must come out in the library's order (that is all k_expiry_seg asks of it)
+        marks = np.zeros_like(keys)
+        for i, k in enumerate(lists):
+            if len(k):
+                m = rng.random(len(k)) < rng.choice([0.01, 0.05, 0.3])
+                vals, cnt = np.unique(k, return_counts=True)
+                dup = vals[cnt > 1]
+                if len(dup):  # make sure some tied groups are marked whole
+                    m |= np.isin(k, rng.choice(dup, min(len(dup), 3), replace=False))
+                marks[i, :len(k)] = m
+        pos, flags = ctx.expiry_sort_positions(keys, lens, 0, marks)
+        pairs = 0
+        for i, k in enumerate(lists):
+            want = oracle.sort_order_desc(k)
+            rank = np.empty(len(k), np.int64)
+            rank[want] = np.arange(len(k))
+            idx = np.nonzero(marks[i, :len(k)])[0]
+            assert len(np.unique(pos[i, :len(k)])) == len(k), i
+            for key in np.unique(np.asarray(k)[idx]):
+                grp = idx[np.asarray(k)[idx] == key]
+                if len(grp) > 1:
+                    pairs += len(grp) - 1
+                    assert np.array_equal(grp[np.argsort(pos[i, grp])], grp[np.argsort(rank[grp])]), (i, key)
+        print("marked form: %d tied marked neighbours in library order" % pairs)
+        assert pairs > 2000
 
 
 def _tie_card(rng, oracle, idx):

@@ -18,6 +18,10 @@ for V in head work; do
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/ab/lib_$V.so $OBJS -ldl
 done
+if [ -n "$AB_STAGES" ]; then  # per-stage hipEvent times (one queue) instead of the timed step
+  for rep in $(seq $REPS); do for V in head work; do echo -n "$V: "; DMZ_HIP_LIB=$PWD/gpurun_out/ab/lib_$V.so python tools/stage_times.py ${AB_BATCH:-65536} 2 2>/dev/null | cut -d" " -f3-; done; done
+  exit 0
+fi
 for rep in $(seq $REPS); do
   for V in head work; do
     echo -n "$V: "
