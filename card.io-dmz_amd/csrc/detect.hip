@@ -94,30 +94,62 @@ __device__ __forceinline__ void across_taps(const WalkCtx &c, int a, int &ad, in
        (int)__builtin_amdgcn_udot4(lo, 0x00050401u, 0u, false);
 }
 
-// The 7-deep window keeps the entry of along-position a in slot (a + 3) mod 7, so that
-// with the step loop unrolled by 7 every slot index is a compile-time constant.
+// Along the walk the two 7-tap filters are binomial CASCADES instead of weighted sums over a 7-deep window: the smooth
+// {1,6,15,20,15,6,1} = [1 1]^6 is six running pair sums, the derivative {-1,-4,-5,0,5,4,1} = [1 1]^4 * [-1 0 1] four pair
+// sums and one difference two steps apart -- eleven plain integer additions per step (the full-rate class of
+// tools/ubench/valu_table.hip; the weighted sums took five v_mul_lo_u32 and four v_add3_u32 of the half-rate class), and
+// twelve registers of state instead of fourteen.  Exact: integer sums, |values| <= 255 * 10 * 64.
 struct Window {
-  int d[7];  // across-derivative
-  int s[7];  // across-smooth
+  int pd[6];     // across-derivative: the previous input and the previous value of cascade levels 1..5
+  int ps[4];     // across-smooth: the previous input and the previous value of levels 1..3
+  int b1, b2;    // level 4 of the across-smooth cascade one and two pushes ago
 };
 
-__device__ __forceinline__ void window_init(const WalkCtx &c, Window &wn) {
-  // along positions -3..+2 -> slots 0..5 (position +3 is pushed by the first window_step)
+// push along-position a (clamped by the caller's arithmetic); after the push of position t the filters centred on t - 3 are out
+__device__ __forceinline__ void window_push(const WalkCtx &c, Window &wn, int a, int &g_ds, int &g_sd) {
+  int ad, as;
+  across_taps(c, a, ad, as);
+  int v = ad;
 #pragma unroll
-  for (int i = 0; i < 6; i++) across_taps(c, clampi(i - 3, 0, c.S - 1), wn.d[i], wn.s[i]);
-  wn.d[6] = wn.s[6] = 0;
+  for (int k = 0; k < 6; k++) {
+    const int nv = v + wn.pd[k];
+    wn.pd[k] = v;
+    v = nv;
+  }
+  g_ds = v;
+  int u = as;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int nu = u + wn.ps[k];
+    wn.ps[k] = u;
+    u = nu;
+  }
+  g_sd = u - wn.b2;
+  wn.b2 = wn.b1;
+  wn.b1 = u;
 }
 
-// step s = s0 + K (s0 a multiple of 7): push position s+3, return the saturated (dx, dy)
+__device__ __forceinline__ void window_init(const WalkCtx &c, Window &wn) {
+  // along positions -3..+2 (position +3 is pushed by the first window_step): whatever the zeroed state contributes has left
+  // the cascades by then (level k at push t holds inputs t-k..t)
+#pragma unroll
+  for (int k = 0; k < 6; k++) wn.pd[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) wn.ps[k] = 0;
+  wn.b1 = wn.b2 = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    int g_ds, g_sd;
+    window_push(c, wn, clampi(i - 3, 0, c.S - 1), g_ds, g_sd);
+  }
+}
+
+// step s: push position s+3, return the saturated (dx, dy)
 // SAT = false leaves the saturation to the caller (pack_gradient does it while packing)
 template <bool VERT, int K, bool SAT = true>
 __device__ __forceinline__ void window_step(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
-  across_taps(c, clampi(s + 3, 0, c.S - 1), wn.d[(K + 6) % 7], wn.s[(K + 6) % 7]);
-  // along axis: smooth the derivative, differentiate the smooth
-  const int g_ds = (wn.d[K % 7] + wn.d[(K + 6) % 7]) + 6 * (wn.d[(K + 1) % 7] + wn.d[(K + 5) % 7]) +
-                   15 * (wn.d[(K + 2) % 7] + wn.d[(K + 4) % 7]) + 20 * wn.d[(K + 3) % 7];
-  const int g_sd = (wn.s[(K + 6) % 7] - wn.s[K % 7]) + 4 * (wn.s[(K + 5) % 7] - wn.s[(K + 1) % 7]) +
-                   5 * (wn.s[(K + 4) % 7] - wn.s[(K + 2) % 7]);
+  int g_ds, g_sd;  // along axis: the derivative smoothed, the smooth differentiated
+  window_push(c, wn, clampi(s + 3, 0, c.S - 1), g_ds, g_sd);
   // top/bottom boxes: across = x  => dx = g_ds, dy = g_sd ; left/right boxes: across = y
   dx = SAT ? clampi(VERT ? g_sd : g_ds, -32768, 32767) : (VERT ? g_sd : g_ds);
   dy = SAT ? clampi(VERT ? g_ds : g_sd, -32768, 32767) : (VERT ? g_ds : g_sd);
@@ -139,17 +171,9 @@ __device__ __forceinline__ int add_abs_sat(uint32_t g, int acc) {
   return (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, lifted), 0x80008000u, (uint32_t)acc);
 }
 
-// the same step with the slot arithmetic left to constant folding: for fully unrolled walks
 template <bool VERT, bool SAT = true>
 __device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
-  const int k = s % 7;
-  across_taps(c, clampi(s + 3, 0, c.S - 1), wn.d[(k + 6) % 7], wn.s[(k + 6) % 7]);
-  const int g_ds = (wn.d[k % 7] + wn.d[(k + 6) % 7]) + 6 * (wn.d[(k + 1) % 7] + wn.d[(k + 5) % 7]) +
-                   15 * (wn.d[(k + 2) % 7] + wn.d[(k + 4) % 7]) + 20 * wn.d[(k + 3) % 7];
-  const int g_sd = (wn.s[(k + 6) % 7] - wn.s[k % 7]) + 4 * (wn.s[(k + 5) % 7] - wn.s[(k + 1) % 7]) +
-                   5 * (wn.s[(k + 4) % 7] - wn.s[(k + 2) % 7]);
-  dx = SAT ? clampi(VERT ? g_sd : g_ds, -32768, 32767) : (VERT ? g_sd : g_ds);
-  dy = SAT ? clampi(VERT ? g_ds : g_sd, -32768, 32767) : (VERT ? g_ds : g_sd);
+  window_step<VERT, 0, SAT>(c, wn, s, dx, dy);
 }
 
 // lane - 1 / lane + 1 of the wave by DPP (wave_shr:1 / wave_shl:1; the end lanes, which own no pixel, read 0):
@@ -278,12 +302,20 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   // consecutive bytes.
   {
     const int wpr = ((bp.x + w - 1) >> 2) - (bp.x >> 2) + 1;  // global words per image row
+#ifdef DMZ_DETECT_SAMEFRAME  /* developer ablation: every workgroup reads one of 64 frames (L2 hits, the same arithmetic) */
+    const uint8_t *plane = planes + (size_t)(frame & 63) * frame_stride;
+#else
     const uint8_t *plane = planes + (size_t)frame * frame_stride;
+#endif
     // the descriptor covers the rows of the box; cvSetImageROI clipped the box to the image
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(plane + (size_t)bp.y * row_stride), 0, (unsigned)(h * row_stride), 0x00020000);
     const bool aligned = ((((uintptr_t)plane) | (uintptr_t)row_stride) & 3) == 0;
+#ifdef DMZ_DETECT_NOLOAD  /* developer ablation: the tile keeps whatever LDS held (timing only) */
+    if (frame < 0) {
+#else
     if (!aligned) {
+#endif
       // plane base / row stride not 4-byte aligned: words assembled from bytes, one word per thread
       for (int i = tid; i < wpr * h; i += NT) {
         const int r = i / wpr, j = i - r * wpr;
@@ -296,6 +328,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
           if (cc >= 0 && cc < w) tile[VERT ? cc * sp + off + r : r * sp + off + cc] = (unsigned char)(v >> (8 * k));
         }
       }
+#ifndef DMZ_DETECT_NOLOAD
     } else if (!VERT) {
       for (int r = wave; r < h; r += NT / 64) {
         const int soff = r * row_stride;
@@ -309,10 +342,16 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
         const int voff = r * row_stride + (bp.x >> 2) * 4;
         unsigned char *tcol = tile + off + r - (bp.x & 3) * sp;
         for (int j0 = 0; j0 < wpr; j0 += kChunk) {
+          // a lane's row piece as three 16-byte loads: lanes are rows (640 B apart), so every load instruction touches 64
+          // separate cache lines whatever its width -- a quarter of the instructions, a quarter of the address-unit time
+          // (words past the box are never stored; past the end of the descriptor they read as 0)
           uint32_t v[kChunk];
+          typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-          for (int j = 0; j < kChunk; j++)
-            v[j] = j0 + j < wpr ? __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 4 * (j0 + j), 0) : 0u;
+          for (int j = 0; j < kChunk; j += 4) {
+            const u32x4v q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 4 * (j0 + j), 0);
+            v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
+          }
 #pragma unroll
           for (int j = 0; j < kChunk; j++) {
 #pragma unroll
@@ -324,6 +363,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
           }
         }
       }
+#endif
     }
     if (tid < 4) s_int[tid] = 0;
     __syncthreads();
