@@ -46,10 +46,16 @@ import __graft_entry__ as entry  # noqa: E402
 SEED = 0xCA4D10
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # vector == f32-MFMA peak
-# VALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles and SIMD at the 2.4 GHz peak clock
-# (tools/ubench/valu_rates.hip: integer / fp64 / logic instructions issue at 4.5 - 5.3 "2.4 GHz cycles", plain f32 at 2.9,
-# transcendentals at 9.3; the sustained clock under these kernels is 1.8 - 2.2 GHz) -- in wave-instructions ("slots") per s
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
+# VALU issue roof, in the counters' own units (no clock assumption).  SQ_ACTIVE_INST_VALU counts one quad-cycle per wave64
+# VALU instruction (two for transcendentals), SQ_BUSY_CU_CYCLES the quad-cycles a CU had work.  Calibrated on saturated
+# single-opcode loops (tools/dev/valu_counter_calibration.sh, profiles/r4_valu_counter_calibration.txt): the ratio of the
+# two reaches 1.807 for the full-rate class (v_mov / add / sub / and / or / xor / ashr, f32 add / mul / fma: a wave64
+# instruction every 2 cycles per SIMD) and 0.966 for the half-rate class (everything else incl. fp64, dot4, packed 16-bit,
+# conversions, compares, DPP / SDWA forms: one every 4 cycles; profiles/r4_valu_table_gfx950.txt).  `valu_issue_frac` is
+# the ratio over the full-rate ceiling, so it can never exceed 1; a kernel made of half-rate instructions saturates at
+# 0.966 / 1.807 = 0.535, which `valu_halfrate_saturation` (ratio / 0.966, meaningful for such kernels only) shows.
+VALU_RATIO_FULL_RATE = 1.807
+VALU_RATIO_HALF_RATE = 0.966
 # ALGORITHMIC bytes / flops per frame and per kernel.
 ALGO = {
     #            bytes/frame                flop/frame
@@ -89,7 +95,12 @@ CONFIGS = {
             workload="full pipeline detect->warp->vseg->hseg->digits->expiry, BASELINE configs[3]",
             stages=tuple(ALGO)),
 }
-FRAMES_PER_GPU_MULTI = 131072  # 8 GPUs x 131 072 = the 1 048 576-frame corpus of BASELINE configs[4]
+# BASELINE configs[4]: the 1 048 576-frame corpus, frame-sharded.  Two ways to run it (--scaling):
+#   weak   (default; what the driver's N = 1, 2, 4, 8 runs compare): the SAME per-GPU batch at every N -- configs[3]'s 65 536
+#          frames per GPU per step -- so value(N) / value(1) is like for like; the corpus is N x 65 536 frames per step;
+#   strong the whole corpus every step at every N: each rank owns corpus / N frames and takes them as (corpus / N) / 65 536
+#          passes over its resident 65 536-frame batch (one GPU: sixteen passes).
+CORPUS_FRAMES = 1048576
 
 
 # ---------------------------------------------------------------------------------------------
@@ -160,6 +171,58 @@ def stage_valu(valu, stage):
         return None
     hit = [valu[k] for k in STAGE_KERNELS[stage] if k in valu]
     return sum(hit) if hit else None
+
+
+def load_pmc_issue():
+    """{kernel base name: {counter: sum over the kernel's dispatches of one pipeline pass}} from the committed SQ issue
+    pass named by profiles/CURRENT (SQ_BUSY_CU_CYCLES, SQ_ACTIVE_INST_VALU, SQ_VALU_MFMA_BUSY_CYCLES, ...; rocprofv3
+    --pmc, kernel-trace only, tools/profile_round.sh; template instances add up)."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        tag = open(os.path.join(pdir, "CURRENT")).read().split()[0]
+    except OSError:
+        return None
+    files = glob.glob(os.path.join(pdir, "%s_pmc_SQ_issue_batch*.txt" % tag))
+    if not files:
+        return None
+    out, cols = {}, None
+    for line in open(files[0]):
+        if line.startswith("#"):
+            continue
+        toks = line.split()
+        if toks and toks[0] == "kernel":
+            cols = toks[1:]
+            continue
+        if cols is None or len(toks) < len(cols) + 1:
+            continue
+        try:
+            vals = [float(t) for t in toks[-len(cols):]]  # counted from the right: names may contain blanks
+        except ValueError:
+            continue
+        name = line[:34].strip().split("<")[0].split("(")[0]
+        ent = out.setdefault(name, dict.fromkeys(cols, 0.0))
+        for c, v in zip(cols, vals):
+            ent[c] += v
+    return out
+
+
+def stage_issue(issue, stage):
+    """VALU / matrix-pipe occupancy of the kernels behind a stage timer from the counters: dict or None.
+    valu_issue_frac = (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES) / 1.807 (share of the full-rate issue ceiling, <= 1 by
+    calibration); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) (cycles over quad-cycles)."""
+    if not issue:
+        return None
+    hit = [issue[k] for k in STAGE_KERNELS[stage] if k in issue]
+    busy = sum(h.get("SQ_BUSY_CU_CYCLES", 0.0) for h in hit)
+    if not hit or busy <= 0:
+        return None
+    act = sum(h.get("SQ_ACTIVE_INST_VALU", 0.0) for h in hit)
+    mfma = sum(h.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for h in hit)
+    return {"valu_active_per_busy": round(act / busy, 4),
+            "valu_issue_frac": round(act / busy / VALU_RATIO_FULL_RATE, 4),
+            "valu_halfrate_saturation": round(min(1.0, act / busy / VALU_RATIO_HALF_RATE), 4),
+            "mfma_busy_frac": round(mfma / (4.0 * busy), 4),
+            "_act": act, "_busy": busy, "_mfma": mfma}
 
 
 def stage_traffic(pmc, stage):
@@ -296,9 +359,14 @@ def main():
     ap.add_argument("--corpus", choices=("cards", "mixed"), default="cards",
                     help="cards: every frame shows a card (the metric's corpus); mixed: 40 %% card-less, 10 %% upside-down, "
                          "50 %% cards (config 4 only; a second line for the gated throughput, not the headline metric)")
-    ap.add_argument("--gather", choices=("auto", "capi", "torch"), default="auto",
-                    help="N > 1: gather of the records on rank 0 through the C-ABI (dmz_hip_gather_records over RCCL) or "
-                         "through torch.distributed; auto = capi when librccl loads and the communicator comes up")
+    ap.add_argument("--gather", choices=("auto", "capi", "torch"), default="torch",
+                    help="N > 1: gather of the records on rank 0 through torch.distributed (default: the path that has run on "
+                         "hardware) or through the C-ABI (dmz_hip_gather_records over RCCL; auto = capi when librccl loads on "
+                         "every rank and the communicator comes up).  The C-ABI path is VERIFIED after the timed loop against a "
+                         "torch.distributed gather of the same records, and the run fails on a mismatch.")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the same per-GPU batch at every N (like-for-like curve); strong: the 1 048 576-frame corpus of "
+                         "BASELINE configs[4] every step at every N (config 4 only)")
     ap.add_argument("--dry-run", action="store_true", help="no device: shard / gather / timing logic on CPU over gloo")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -315,7 +383,15 @@ def main():
                  "--gpus %d ...`" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
 
     cfg = CONFIGS[args.config]
-    B = args.batch or (cfg["batch"] if world == 1 or args.config != 4 else FRAMES_PER_GPU_MULTI)
+    B = args.batch or cfg["batch"]  # resident units per GPU: the same at every N
+    passes = 1                      # passes over the resident batch per step
+    if args.scaling == "strong":
+        if args.config != 4:
+            sys.exit("bench.py: --scaling strong goes with --config 4")
+        corpus = CORPUS_FRAMES if not args.batch else 16 * args.batch  # (a small corpus for the CPU dry run)
+        if corpus % (world * B):
+            sys.exit("bench.py: the corpus (%d frames) is not a whole number of %d-frame batches on %d GPUs" % (corpus, B, world))
+        passes = corpus // (world * B)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not args.dry_run:
@@ -356,21 +432,24 @@ def main():
     use_capi = False
     root_dst = None
     if world > 1 and ctx is not None and args.gather in ("auto", "capi"):
-        uid = [None]
+        # every rank first agrees that librccl loads everywhere: a rank that entered ncclCommInitRank alone would hang the others
+        have = torch.ones(1, dtype=torch.int32, device=dev)
         try:
-            if rank == 0:
-                uid[0] = pkg.comm_unique_id()
+            probe_uid = pkg.comm_unique_id()  # loads librccl in this process
         except pkg.DmzHipError:
-            uid[0] = None
-        dist.broadcast_object_list(uid, src=0)
+            probe_uid = None
+            have.zero_()
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        uid = [probe_uid if rank == 0 else None]
         ok = torch.zeros(1, dtype=torch.int32, device=dev)
-        if uid[0] is not None:
+        if bool(have.item()):
+            dist.broadcast_object_list(uid, src=0)
             try:
                 ctx.comm_init(world, rank, uid[0])
                 ok += 1
             except pkg.DmzHipError as e:
                 print("bench.py: rank %d: C-ABI communicator failed (%s)" % (rank, e), file=sys.stderr)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         use_capi = bool(ok.item())
         if not use_capi:
             if args.gather == "capi":
@@ -448,6 +527,12 @@ def main():
         elif world > 1:
             gatherer.wait()
 
+    one_pass = step
+
+    def step():  # strong scaling: a rank's share of the corpus is `passes` passes over its resident batch
+        for _ in range(passes):
+            one_pass()
+
     for _ in range(args.warmup):
         step()
     gather_drain()
@@ -473,6 +558,26 @@ def main():
         elapsed = float(t.item())
     dev_ms = ev0.elapsed_time(ev1) if ctx is not None else elapsed * 1e3
 
+    # The C-ABI gather has no second implementation inside the timed loop to compare with: afterwards the LAST step's records
+    # travel once more through torch.distributed and rank 0 compares the two destinations byte for byte.  A wrong offset or
+    # count, or a second RCCL beside torch's, fails the run instead of producing a plausible frames/s figure.
+    if world > 1 and use_capi:
+        last = (step_no[0] - 1) % nbuf
+        ref = sharding.RootGatherer(world)
+        want_r = ref.submit(results_b[last], slot=0)
+        want_x = ref.submit(expiry_b[last], slot=1) if with_expiry else None
+        ref.wait()
+        torch.cuda.synchronize(dev)
+        same = torch.ones(1, dtype=torch.int32, device=dev)
+        if rank == 0:
+            if not torch.equal(root_dst[last][0].view(-1), want_r.view(-1)):
+                same.zero_()
+            if with_expiry and not torch.equal(root_dst[last][1].view(-1), want_x.view(-1)):
+                same.zero_()
+        dist.broadcast(same, src=0)
+        if not bool(same.item()):
+            sys.exit("bench.py: the C-ABI gather's records differ from the torch.distributed gather of the same step")
+
     if args.dry_run:
         ok = True
         if rank == 0 and world > 1:
@@ -486,7 +591,8 @@ def main():
                     ok = ok and bool((gx[g] == ((g * 16 + step_no[0] + 7) & 255)).all())
         if rank == 0:
             print(json.dumps({"metric": cfg["metric"], "dry_run": True, "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "frames_per_gpu": B, "gather_ok": ok,
+                              "warmup": args.warmup, "frames_per_gpu": B, "units_per_gpu": B * passes,
+                              "corpus_frames": world * B * passes, "scaling": args.scaling, "gather_ok": ok,
                               "shard": [lo, hi], "backend": "gloo" if world > 1 else "none"}), flush=True)
         if world > 1:
             dist.barrier()
@@ -556,28 +662,36 @@ def main():
                 ent["traffic_over_algorithmic"] = round((tr[0] + tr[1]) / by, 3)
             per_stage[name] = ent
         valu = load_pmc_valu()
+        issue = load_pmc_issue()
         for name, ent in per_stage.items():
             sv = stage_valu(valu, name)
             if sv is not None:
-                ent["valu_slots_per_unit"] = round(sv)
-                ent["valu_issue_frac"] = round(sv * B / (ent["ms_per_step"] * 1e-3) / VALU_ISSUE_PEAK, 4)
-            # stages whose matrix work runs on bf16 operand splits (vseg, slash MLP, digit and expiry convolutions): the
-            # flop figure counts the fp32 product they reproduce, not the bf16 instructions issued
-            ent["TFLOPs_is"] = "fp32-equivalent algorithmic flops"
+                ent["valu_instructions_per_unit"] = round(sv)
+            si = stage_issue(issue, name)
+            if si is not None:
+                ent.update({k: v for k, v in si.items() if not k.startswith("_")})
+            # stages whose matrix work runs on bf16 / f16 operand splits (vseg, slash MLP, digit and expiry convolutions): the
+            # flop figure counts the fp32 product they reproduce, not the instructions issued -- it is NOT divided by any peak;
+            # the matrix pipe's occupancy is mfma_busy_frac (counters)
+            ent["TFLOPs_is"] = "fp32-equivalent algorithmic flops (information; no fraction of a peak is derived from it)"
         dom = max(per_stage, key=lambda k: per_stage[k]["ms_per_step"])
         hbm_frac = per_stage[dom]["GBps"] / HBM_PEAK_GBPS
-        fl_frac = per_stage[dom]["TFLOPs"] / FP32_PEAK_TFLOPS
+        mf_frac = per_stage[dom].get("mfma_busy_frac", 0.0)
         vi_frac = per_stage[dom].get("valu_issue_frac", 0.0)
-        if hbm_frac >= fl_frac:
+        if hbm_frac >= mf_frac:
             roof = {"bound": "hbm", "achieved": per_stage[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": None}
         else:
+            # matrix-bound kernel: achieved = the fp32 product it reproduces per second, peak = the f32 matrix peak, and frac
+            # = the matrix pipe's measured busy share (split-operand kernels issue more, narrower instructions than the
+            # flop figure counts, so achieved / peak would not be a fraction of anything)
             roof = {"bound": "mfma", "achieved": per_stage[dom]["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fl_frac, 5), "traffic": None}
-        # The contract's two roofs (HBM bytes, matrix flops) are reported as `achieved / peak / frac`; the roof that
-        # actually binds these kernels is VALU instruction issue: reported beside them, and named in `bound` when it is the
-        # largest of the three fractions.
-        if vi_frac > max(hbm_frac, fl_frac):
+                    "unit": "TFLOP/s", "frac": round(mf_frac, 5), "traffic": None,
+                    "frac_is": "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the committed PMC pass"}
+        # The contract's two roofs (HBM bytes, matrix pipe) are reported as `achieved / peak / frac`; the roof that actually
+        # binds these kernels is VALU instruction issue: reported beside them (`valu_issue`), and named in `bound` when its
+        # saturation is the largest of the three.
+        if per_stage[dom].get("valu_halfrate_saturation", 0.0) > max(hbm_frac, mf_frac):
             roof["bound_of_contract_roofs"] = roof["bound"]
             roof["bound"] = "valu_issue"
         roof["kernel"] = STAGE_KERNELS[dom][0]
@@ -589,7 +703,7 @@ def main():
             roof["traffic"] = round((tr[0] + tr[1]) * B)
             roof["traffic_over_algorithmic"] = round((tr[0] + tr[1]) / ALGO[dom][0], 3)
             roof["traffic_source"] = "profiles/%s_pmc_{FETCH,WRITE}_SIZE_*.txt (FETCH_SIZE doubled: gfx950 correction)" % pmc_tag
-        value = world * B * args.steps / elapsed
+        value = world * B * passes * args.steps / elapsed
         roof["pipeline_GBps"] = round(value / world * cfg["bytes"] / 1e9, 2)
         roof["pipeline_frac_of_hbm"] = round(value / world * cfg["bytes"] / 1e9 / HBM_PEAK_GBPS, 5)
         if pmc:
@@ -597,17 +711,21 @@ def main():
             if all(t is not None for t in tot):
                 roof["pipeline_traffic_B_per_unit"] = round(sum(t[0] + t[1] for t in tot))
                 roof["pipeline_traffic_over_algorithmic"] = round(sum(t[0] + t[1] for t in tot) / cfg["bytes"], 3)
-        if valu:
-            sv_all = [stage_valu(valu, s) for s in per_stage]
-            if all(v is not None for v in sv_all):
-                slots = sum(sv_all)
+        if issue:
+            si_all = [stage_issue(issue, s) for s in per_stage]
+            if all(v is not None for v in si_all):
+                act, busy = sum(v["_act"] for v in si_all), sum(v["_busy"] for v in si_all)
+                sv_all = [stage_valu(valu, s) for s in per_stage] if valu else []
                 roof["valu_issue"] = {
-                    "slots_per_unit": round(slots), "achieved": round(value / world * slots, 1), "peak": VALU_ISSUE_PEAK,
-                    "unit": "wave64 VALU instructions/s", "frac": round(value / world * slots / VALU_ISSUE_PEAK, 4),
-                    "dominant_kernel": {"kernel": STAGE_KERNELS[dom][0], "slots_per_unit": per_stage[dom].get("valu_slots_per_unit"),
-                                        "frac": per_stage[dom].get("valu_issue_frac")},
-                    "source": "profiles/%s_pmc_SQ_insts_*.txt (SQ_INSTS_VALU per kernel / batch); peak = 1024 SIMDs x 2.4 GHz / 4 "
-                              "cycles per wave64 instruction" % pmc_tag}
+                    "active_per_busy": round(act / busy, 4), "frac": round(act / busy / VALU_RATIO_FULL_RATE, 4),
+                    "halfrate_saturation": round(min(1.0, act / busy / VALU_RATIO_HALF_RATE), 4),
+                    "instructions_per_unit": round(sum(sv_all)) if sv_all and all(v is not None for v in sv_all) else None,
+                    "dominant_kernel": {"kernel": STAGE_KERNELS[dom][0],
+                                        **{k: per_stage[dom].get(k) for k in ("valu_active_per_busy", "valu_issue_frac",
+                                                                              "valu_halfrate_saturation", "mfma_busy_frac")}},
+                    "unit": "SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES, summed over the pipeline's kernels; frac = that over 1.807 "
+                            "(the full-rate class's saturated ratio), halfrate_saturation = over 0.966 (the half-rate class's)",
+                    "source": "profiles/%s_pmc_SQ_issue_*.txt; calibration profiles/r4_valu_counter_calibration.txt" % pmc_tag}
         out = {
             "metric": cfg["metric"],
             "value": round(value, 1),
@@ -617,7 +735,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8 (int32 accumulators; f32 model scores; f64 warp coordinates)",
             "data": "synthetic",
@@ -628,7 +746,9 @@ def main():
                 **({"corpus": "mixed: 40 % card-less frames, 10 % upside-down cards, 50 % cards (not the metric's corpus: the gated "
                               "throughput line of SURVEY section 7)"} if args.corpus == "mixed" else {}),
                 **({"gather": "C-ABI dmz_hip_gather_records (RCCL send/recv)" if use_capi else "torch.distributed gather"} if world > 1 else {}),
-                "units_per_gpu": B,
+                "units_per_gpu": B * passes,
+                "corpus_frames": world * B * passes,
+                **({"resident_batch": B, "passes_per_step": passes} if passes > 1 else {}),
                 "algorithmic_bytes_per_unit": cfg["bytes"],
                 "parallelism": "frame-sharded x%d, asynchronous gather of the 1 KiB result%s records on rank 0"
                                % (world, " + 1.6 KiB expiry" if with_expiry else ""),

@@ -37,6 +37,8 @@
 // leave four workgroups per CU).  The top/bottom boxes and other box sizes take the
 // two-walk form (sum pass, NMS pass), which recomputes the gradients instead of
 // parking 44 KB of them per workgroup in LDS (see DMZ_DETECT_SINGLE_H below).
+#include <mutex>
+
 #include "dmz_hip_internal.h"
 #include "dmz_wave.h"
 
@@ -785,13 +787,17 @@ __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DE
 template <bool VERT, int NT, int SC, int RG>
 int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
                 const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask, int lds_bytes) {
+  // (contexts may be driven from one host thread each: the once-per-geometry configuration below is serialised)
+  static std::mutex mu;
   static int configured_lds = 0;  // per instantiation
+  std::unique_lock<std::mutex> lk(mu);
   if (lds_bytes > configured_lds) {
     hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT, SC, RG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
     configured_lds = lds_bytes;
   }
+  lk.unlock();
   hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC, RG>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
                      frame_stride, row_stride, p, hits, skip_mask);
   return 0;
@@ -816,6 +822,8 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
     // (21.6 KB instead of 30 KB for the left/right boxes of a 640 x 480 frame).
     // What the device holds, asked once: LDS per CU, and how many workgroups of this kernel the register file and the wave
     // slots admit (the occupancy query with no dynamic LDS).  No literals: a different part or compiler changes the answer.
+    static std::mutex mu;  // the cached device answers and the per-geometry check: one thread at a time
+    std::unique_lock<std::mutex> lk(mu);
     static int lds_cu = 0, wgs_regs = 0;
     const void *kfn = (const void *)k_detect_walk<VERT, kNt, kSteps, kRegs>;
     if (lds_cu == 0) {
@@ -868,6 +876,7 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
       checked_total = total;
     }
     if (!checked_ok) (void)layout(false);
+    lk.unlock();
     return launch_pair<VERT, kNt, kSteps, kRegs>(s, planes, frame_stride, row_stride, n, q, hits, skip_mask, total);
   }
   if (nt <= 256) return launch_pair<VERT, 256, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);

@@ -106,13 +106,12 @@ struct DmzExpiryTables {
 namespace dmzx {
 constexpr int SLASH_W1T = 0;                      // [176][80]  (input-major)
 constexpr int CONV2_P = SLASH_W1T + 176 * 80;     // [1252][48]: tap-major, zero-padded to the MFMA tile grid
-constexpr int FC1_T = CONV2_P + 1252 * 48;        // [120][176]
 // conv2 for the bf16 matrix-core variants (v_mfma_f32_16x16x32_bf16): K ordered tap-major with the 50
 // maps of a tap padded to 56 (seven runs of eight), 44 k-steps of 32; B fragments stored exactly as
 // the lanes load them, [k-step 44][n-tile 3][lane 64][8 bf16], once as the bf16 rounding of the
 // weights (HI) and once as the bf16 rounding of the remainder (LO)
 constexpr int C2_KSTEPS = 44, C2_MAPS_PAD = 56;
-constexpr int CONV2_BH = FC1_T + 120 * 176;                  // C2_KSTEPS * 3 * 64 * 8 bf16 = 33,792 floats
+constexpr int CONV2_BH = CONV2_P + 1252 * 48;                // C2_KSTEPS * 3 * 64 * 8 bf16 = 33,792 floats
 constexpr int CONV2_BL = CONV2_BH + C2_KSTEPS * 3 * 64 * 4;
 // slash MLP hidden layer for v_mfma_f32_16x16x32_bf16: W1 / 255 split into three bf16 parts (hi, mid, lo),
 // fragments [part 3][k-step 6][n-tile 5][lane 64][8 bf16]; K = 176 padded to 192

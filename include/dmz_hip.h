@@ -178,7 +178,8 @@ int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t
  *           scores agree with the fp32 variant and the CPU oracle to ~2e-6, inside the reference's own
  *           known-answer tolerance 1e-5 (tests/test_gpu_expiry.py, bench.py).  Range: the layer-1 activations are
  *           bounded by 16.4 max|x| for this model (sum of |conv1 weights| + |bias| per map), far inside f16 for the
- *           pipeline's inputs (|x| < 1); dmz_hip_apply_expiry_model with |x| beyond ~4000 needs F32 / BF16X3;
+ *           pipeline's inputs (|x| < 1); dmz_hip_apply_expiry_model checks HOST inputs and runs a call whose |x| exceeds
+ *           2048 (or is not finite) in the F32 variant; device inputs beyond ~4000 need F32 / BF16X3 set by the caller;
  *   F32     v_mfma_f32_16x16x4_f32 / packed FMAs, the reference's k-ordered fp32 accumulation;
  *   BF16X3  the same three products on bf16 parts (16 bits): ~2^-16 per product, scores within the 1e-4 contract
  *           (the default up to round 2);

@@ -62,6 +62,21 @@ def test_expiry_models_match_oracle_on_random_batches(ctx, oracle):
         ctx.set_expiry_conv(pkg.EXPIRY_CONV_F16X3)
 
 
+def test_expiry_model_entry_accepts_inputs_outside_the_f16_range(ctx, oracle):
+    """dmz_hip_apply_expiry_model takes arbitrary floats like applyc_bf4dd6c8 (models/expiry/modelc_bf4dd6c8.cpp:13457): the
+    default f16-split convolutions hold layer-1 activations in f16 (|x| < ~4000), so host inputs beyond 2048 run the call
+    in the fp32 variant -- finite scores that agree with the oracle, not inf / NaN."""
+    rng = np.random.default_rng(77)
+    x = (rng.integers(0, 256, (5, 176)) / np.float32(255)).astype(np.float32)
+    x[:, 40], x[:, 100] = 3000.0, -3000.0  # (beyond ~5000 the reference's own soft-max overflows to NaN)
+    got = ctx.apply_expiry_model(x)
+    want = np.stack([oracle.applyc_expiry(v)[0] for v in x])
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 1e-4
+    # and the next call with ordinary inputs is back on the default arithmetic (the KAT still holds)
+    assert np.abs(ctx.apply_expiry_model(KATS["expiry_in"])[0] - KATS["expiry_out"]).max() <= 1e-5
+
+
 def test_expiry_conv_variants_against_fp32(ctx, pkg, oracle):
     """BASELINE configs[3] "bf16 conv with fp32 parity check": the CNN's convolutions on the 16-bit matrix core with
     split operands (F16X3, the default: two f16 parts, three products; BF16X3: two bf16 parts) against the fp32

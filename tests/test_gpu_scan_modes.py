@@ -169,3 +169,67 @@ def test_capi_gather_at_world_size_one(ctx, pkg):
         ctx.gather_records(res.ptr, 1024, n, 0, dst[0][0].ptr)  # no communicator
     for b in (y, res, exp, cards, dst[0][0], dst[0][1], dst[1][0], dst[1][1]):
         b.free()
+
+
+def test_two_contexts_driven_from_two_host_threads(pkg, ctx):
+    """one process OR ONE THREAD per GPU.  Two contexts (here on the one GPU a test box has), each
+    driven from its own host thread at the same time: context creation of the second one inside its thread, the whole
+    pipeline, communicator of one rank (librccl is loaded lazily -- both threads reach the loader together, as the collective
+    ncclCommInitRank makes every thread of a multi-GPU host do) and the gather of both record types.  Every thread's bytes
+    must equal what one thread alone produces."""
+    import threading
+    n, rounds = 1536, 3
+    frames = ctx.alloc(n * pkg.FRAME_BYTES)
+    ctx.synth_frames(SEED, 52000, n, frames.ptr)
+    host_frames = frames.download(np.uint8)
+    want_res = np.zeros(n, pkg.RESULT_DTYPE)
+    want_exp = np.zeros(n, pkg.EXPIRY_DTYPE)
+    ctx.pipeline_expiry(frames.ptr, n, want_res, want_exp)
+    frames.free()
+    try:
+        uid_ok = pkg.comm_unique_id() is not None
+    except pkg.DmzHipError:
+        uid_ok = False
+    out, errors = {}, []
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            start.wait()
+            c = pkg.Context(0)
+            try:
+                y = c.alloc(n * pkg.FRAME_BYTES).upload(host_frames)
+                res, exp, cards = c.alloc(n * 1024), c.alloc(n * pkg.EXPIRY_DTYPE.itemsize), c.alloc(n * pkg.CARD_BYTES)
+                dst = (c.alloc(n * 1024), c.alloc(n * pkg.EXPIRY_DTYPE.itemsize))
+                start.wait()
+                c.comm_init(1, 0, pkg.comm_unique_id() if uid_ok else None)
+                got = []
+                for _ in range(rounds):
+                    c.pipeline_expiry(y.ptr, n, res.ptr, exp.ptr, cards.ptr)
+                    c.gather_records(res.ptr, 1024, n, 0, dst[0].ptr, slot=0)
+                    c.gather_records(exp.ptr, pkg.EXPIRY_DTYPE.itemsize, n, 0, dst[1].ptr, slot=1)
+                    c.gather_wait(-1, host_sync=True)
+                    got.append((dst[0].download(np.uint8).copy(), dst[1].download(np.uint8).copy()))
+                c.comm_destroy()
+                out[t] = got
+                for b in (y, res, exp, cards, dst[0], dst[1]):
+                    b.free()
+            finally:
+                c.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+            try:
+                start.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    for t in range(2):
+        for r, x in out[t]:
+            assert r.tobytes() == want_res.tobytes(), t
+            assert x.tobytes() == want_exp.tobytes(), t

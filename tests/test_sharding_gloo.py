@@ -108,12 +108,26 @@ def test_bench_starts_its_own_ranks_when_run_plainly():
         assert rc == 0, err[-2000:]
         assert line["n_gpus"] == 2 and line["dry_run"] and line["gather_ok"] and line["steps"] == steps
         assert line["frames_per_gpu"] == 48 and line["shard"] == [0, 48] and line["backend"] == "gloo"
+        # weak scaling: the per-GPU batch does not depend on the number of ranks (the curve is like for like)
+        assert line["scaling"] == "weak" and line["units_per_gpu"] == 48 and line["corpus_frames"] == 96
 
 
-def test_bench_default_corpus_at_8_ranks_is_one_million_frames():
+def test_bench_strong_scaling_runs_the_same_corpus_at_every_n():
+    """--scaling strong: the corpus is fixed (16 resident batches), each rank takes corpus / N frames as passes over its batch"""
+    seen = {}
+    for n in (1, 2):
+        rc, line, err = _run_bench(["--gpus", str(n), "--dry-run", "--batch", "16", "--steps", "2", "--scaling", "strong"])
+        assert rc == 0, err[-2000:]
+        assert line["scaling"] == "strong" and line["gather_ok"]
+        seen[n] = (line["units_per_gpu"], line["corpus_frames"])
+    assert seen[1] == (256, 256) and seen[2] == (128, 256)
+
+
+def test_bench_per_gpu_batch_is_the_same_at_every_n():
     import bench
-    assert 8 * bench.FRAMES_PER_GPU_MULTI == 1048576
+    assert bench.CORPUS_FRAMES == 1048576 and bench.CORPUS_FRAMES % (8 * bench.CONFIGS[4]["batch"]) == 0
     assert bench.CONFIGS[4]["bytes"] == 423784 and bench.CONFIGS[2]["batch"] == 4096 and bench.CONFIGS[3]["batch"] == 65536
+    assert not hasattr(bench, "FRAMES_PER_GPU_MULTI")  # (round 3 ran 131 072 frames per GPU at N > 1 against 65 536 at N = 1)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
