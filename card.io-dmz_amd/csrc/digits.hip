@@ -416,43 +416,50 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
       if (4 * wave + dj < nd && lane < 57) {
         unsigned int *hc = hq + (dj * 4 + (lane & 3)) * 64;
 #pragma unroll
-        for (int k = 0; k < 9; k++) atomicAdd(&hc[gv[dj][k] >> 2], 1u << ((gv[dj][k] & 3) * 8));
+        // value v -> byte v >> 6 of dword v & 63: neighbouring VALUES (neighbouring lanes see similar gradients) fall into
+        // different dwords / banks; only equal values, or values 64 apart, still meet in one counter word
+        for (int k = 0; k < 9; k++) atomicAdd(&hc[gv[dj][k] & 63], 1u << ((gv[dj][k] >> 6) * 8));
       }
     __builtin_amdgcn_wave_barrier();
     if (DMZ_DP_STOP == 3) return;
-    uint2 lut[4];
+    uint32_t lutb[4][4];
 #pragma unroll
     for (int dj = 0; dj < 4; dj++) {
-      // values 4 lane .. 4 lane + 3: dword `lane` of each copy; even and odd bytes added as 16-bit fields
+      // lane l holds the counts of the values l, l + 64, l + 128, l + 192 (the four bytes of dword l of every copy, added as
+      // 16-bit fields); the cumulative counts are two wave scans over packed pairs plus the totals of the quarters below
       unsigned int ev = 0u, od = 0u;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const unsigned int cq = hq[(dj * 4 + q) * 64 + lane];
-        ev += cq & 0x00FF00FFu;
-        od += (cq >> 8) & 0x00FF00FFu;
+        ev += cq & 0x00FF00FFu;         // {count(l), count(l + 128)}
+        od += (cq >> 8) & 0x00FF00FFu;  // {count(l + 64), count(l + 192)}
       }
-      const int h0 = ev & 0xffff, h1 = od & 0xffff, h2 = ev >> 16, h3 = od >> 16;
-      const int tot = h0 + h1 + h2 + h3;
-      const int incl = dmzwave::inclusive_scan_i32(tot);
-      const int excl = incl - tot;
+      const int p01 = (int)((ev & 0xffffu) | (od << 16)), p23 = (int)((ev >> 16) | (od & 0xffff0000u));
+      const int i01 = dmzwave::inclusive_scan_i32(p01), i23 = dmzwave::inclusive_scan_i32(p23);  // (fields <= 513: no carry)
+      const int t01 = __builtin_amdgcn_readlane(i01, 63), t23 = __builtin_amdgcn_readlane(i23, 63);
+      const int T0 = t01 & 0xffff, T1 = (int)((unsigned)t01 >> 16), T2 = t23 & 0xffff;
       const float scale = 255.f / (19 * 27);
-      const int c0 = excl + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
+      const int c0 = i01 & 0xffff, c1 = T0 + (int)((unsigned)i01 >> 16), c2 = T0 + T1 + (i23 & 0xffff),
+                c3 = T0 + T1 + T2 + (int)((unsigned)i23 >> 16);
       int l0 = __float2int_rn((float)c0 * scale), l1 = __float2int_rn((float)c1 * scale),
           l2 = __float2int_rn((float)c2 * scale), l3 = __float2int_rn((float)c3 * scale);
       l0 = imin(255, imax(0, l0)); l1 = imin(255, imax(0, l1));
       l2 = imin(255, imax(0, l2)); l3 = imin(255, imax(0, l3));
       if (lane == 0) l0 = 0;  // lut[0] = 0 (stats.cpp:151)
       // the LUT holds the equalised value as a bf16 number (the upper half of its float)
-      const uint32_t b0 = __float_as_uint((float)l0) >> 16, b1 = __float_as_uint((float)l1) & 0xffff0000u;
-      const uint32_t b2 = __float_as_uint((float)l2) >> 16, b3 = __float_as_uint((float)l3) & 0xffff0000u;
-      lut[dj] = make_uint2(b0 | b1, b2 | b3);
+      lutb[dj][0] = __float_as_uint((float)l0) >> 16, lutb[dj][1] = __float_as_uint((float)l1) >> 16;
+      lutb[dj][2] = __float_as_uint((float)l2) >> 16, lutb[dj][3] = __float_as_uint((float)l3) >> 16;
     }
     __builtin_amdgcn_wave_barrier();
     // the LUTs (256 bf16 each) over the first half of the wave's region
     constexpr int HW = 128;
     unsigned int *hd = hq;
 #pragma unroll
-    for (int dj = 0; dj < 4; dj++) *(uint2 *)(hd + dj * HW + 2 * lane) = lut[dj];
+    for (int dj = 0; dj < 4; dj++) {
+      unsigned short *l16 = (unsigned short *)(hd + dj * HW);
+#pragma unroll
+      for (int q = 0; q < 4; q++) l16[lane + 64 * q] = (unsigned short)lutb[dj][q];
+    }
     __builtin_amdgcn_wave_barrier();
     if (DMZ_DP_STOP == 4) return;
 #pragma unroll
