@@ -87,6 +87,7 @@ EXPORTS = (
     "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv", "dmz_hip_set_two_queues",
     "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
     "dmz_hip_gather_records", "dmz_hip_gather_wait", "dmz_hip_expiry_sort_positions",
+    "dmz_hip_categorize_expiry_groups_batch", "dmz_hip_scharr3_dx_abs",
 )
 
 
@@ -155,6 +156,8 @@ def load_library():
     lib.dmz_hip_apply_slash_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_apply_expiry_model.argtypes = [vp, vp, i, vp]
     lib.dmz_hip_expiry_sort_positions.argtypes = [vp, vp, vp, vp, i, i, i, vp, vp]
+    lib.dmz_hip_categorize_expiry_groups_batch.argtypes = [vp, vp, sz, i, vp]
+    lib.dmz_hip_scharr3_dx_abs.argtypes = [vp, vp, i, i, i, vp, i]
     lib.dmz_hip_calc_persp_transform.argtypes = [vp, vp, vp, vp]
     lib.dmz_hip_warp_perspective_batch.argtypes = [vp, vp, sz, i, i, i, i, vp, vp, sz]
     lib.dmz_hip_apply_vseg_model.argtypes = [vp, vp, i, vp]
@@ -384,6 +387,18 @@ class Context:
         x = np.ascontiguousarray(x, np.float32).reshape(-1, 176)
         out = np.empty((x.shape[0], 10), np.float32)
         self._check(self.lib.dmz_hip_apply_expiry_model(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def categorize_expiry_groups(self, cards, n, expiry):
+        """scores of caller-supplied groups (host records, in / out): dmz_hip_categorize_expiry_groups_batch"""
+        assert isinstance(expiry, np.ndarray)
+        self._check(self.lib.dmz_hip_categorize_expiry_groups_batch(self.h, _ptr(cards), CARD_BYTES, n, expiry.ctypes.data))
+
+    def scharr3_dx_abs(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(img.shape, np.int16)
+        self._check(self.lib.dmz_hip_scharr3_dx_abs(self.h, img.ctypes.data, img.shape[1], img.shape[1], img.shape[0],
+                                                    out.ctypes.data, img.shape[1]))
         return out
 
     def expiry_sort_positions(self, keys, lens, kind=0, marks=None):

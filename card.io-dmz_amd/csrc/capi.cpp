@@ -1267,6 +1267,79 @@ int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t
   return DMZ_HIP_OK;
 }
 
+int dmz_hip_categorize_expiry_groups_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                                           dmz_hip_expiry_result *expiry) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!cards || !expiry || n <= 0 || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT ||
+      (((uintptr_t)cards | card_stride) & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad categorise request");
+  if (is_device_ptr(expiry)) return fail(ctx, DMZ_HIP_EINVAL, "the group records of this entry are host memory");
+  // the staging k_expiry_seg would have left: every group in the first stripe's slot, the frame usable
+  std::vector<DmzExpiryStage> st((size_t)n * 3);
+  std::vector<dmz_hip_frame_result> res((size_t)n);
+  std::vector<dmz_hip_expiry_result> rec(expiry, expiry + n);
+  memset(st.data(), 0, sizeof(DmzExpiryStage) * st.size());
+  memset(res.data(), 0, sizeof(dmz_hip_frame_result) * res.size());
+  for (int f = 0; f < n; f++) {
+    const int ng = rec[f].n_groups;
+    if (ng < 0 || ng > DMZ_HIP_EXPIRY_MAX_GROUPS) return fail(ctx, DMZ_HIP_EINVAL, "n_groups out of range");
+    for (int g = 0; g < ng; g++) {
+      const dmz_hip_expiry_group &gr = rec[f].groups[g];
+      for (int c = 0; c < 5; c++)
+        if (gr.char_left[c] < 0 || gr.char_left[c] + 11 > DMZ_CARD_WIDTH || gr.char_top[c] < 0 || gr.char_top[c] + 16 > DMZ_CARD_HEIGHT)
+          return fail(ctx, DMZ_HIP_EINVAL, "character rectangle outside the card");
+      memcpy(st[(size_t)f * 3].hdr[g], &gr, sizeof(short) * 16);
+    }
+    st[(size_t)f * 3].n = ng;
+    rec[f].n_stripes = ng > 0 ? 1 : 0;
+    res[f].flags = DMZ_HIP_FLAG_VSEG_OK | DMZ_HIP_FLAG_USABLE;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dc = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_cards, cards, card_stride * (size_t)(n - 1) + (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT, &dc))) return rc;
+  if ((rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * st.size()))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_res, sizeof(dmz_hip_frame_result) * res.size()))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_exp, sizeof(dmz_hip_expiry_result) * rec.size()))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->xstage.p, st.data(), sizeof(DmzExpiryStage) * st.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_res.p, res.data(), sizeof(dmz_hip_frame_result) * res.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_exp.p, rec.data(), sizeof(dmz_hip_expiry_result) * rec.size(), hipMemcpyHostToDevice, ctx->stream));
+  dmz_launch_expiry(ctx->stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, (const uint8_t *)dc, card_stride, n,
+                    (const dmz_hip_frame_result *)ctx->stage_res.p, (DmzExpiryStage *)ctx->xstage.p,
+                    (dmz_hip_expiry_result *)ctx->stage_exp.p, nullptr, ctx->expiry_conv, 2);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(rec.data(), ctx->stage_exp.p, sizeof(dmz_hip_expiry_result) * rec.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int f = 0; f < n; f++)
+    for (int g = 0; g < expiry[f].n_groups; g++) memcpy(expiry[f].groups[g].scores, rec[f].groups[g].scores, sizeof(float) * 40);
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_scharr3_dx_abs(dmz_hip_context *ctx, const uint8_t *src, int src_stride, int width, int height, int16_t *dst,
+                           int dst_stride) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!src || !dst || width <= 0 || height <= 0 || src_stride < width || dst_stride < width || (int64_t)width * height > (1 << 26))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad scharr request");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *ds = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_in, src, (size_t)src_stride * (height - 1) + width, &ds))) return rc;
+  const bool out_dev = is_device_ptr(dst);
+  int16_t *dd = dst;
+  const size_t ob = sizeof(int16_t) * ((size_t)dst_stride * (height - 1) + width);
+  if (!out_dev) {
+    if ((rc = ensure(ctx, ctx->misc, ob))) return rc;
+    dd = (int16_t *)ctx->misc.p;
+  }
+  dmz_launch_scharr3_dx_abs(ctx->stream, (const uint8_t *)ds, src_stride, width, height, dd, dst_stride);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!out_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(dst, dd, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
 int dmz_hip_pipeline_expiry_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
                                   int width, int height, int n, int orientation, int options, uint8_t *cards,
                                   size_t card_stride, dmz_hip_frame_result *results,

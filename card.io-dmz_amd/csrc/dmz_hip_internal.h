@@ -220,6 +220,7 @@ void dmz_launch_ycbcr_to_rgb(hipStream_t s, const uint8_t *y, const uint8_t *cb,
                              int channels, uint8_t *rgb);
 void dmz_launch_scores(hipStream_t s, const uint8_t *y, size_t frame_stride, int row_stride, int n, int rx, int ry,
                        int rw, int rh, float *focus, float *brightness);
+void dmz_launch_scharr3_dx_abs(hipStream_t s, const uint8_t *src, int src_stride, int w, int h, int16_t *dst, int dst_stride);
 void dmz_launch_blur_cards(hipStream_t s, uint8_t *rgb, size_t card_stride, int channels, int n,
                            const dmz_hip_session_result *sessions, int unblur_digits);
 int dmz_configure_expiry(void);

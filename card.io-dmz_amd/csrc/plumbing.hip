@@ -269,7 +269,30 @@ __global__ __launch_bounds__(256) void k_blur_cards(uint8_t *__restrict__ rgb, s
   }
 }
 
+// llcv_scharr3_dx_abs (cv/sobel.cpp:706-804, the x86 scalar branch; dmz_scharr3_dx_abs of the Cython flavour, dmz.h:105):
+// |right - left| with the column index clamped at the image edge, then 3 / 10 / 3 down the column with the row index clamped.
+// One thread per output pixel; a diagnostic / compatibility entry (the scan path computes the same operator inside
+// k_expiry_seg, on the rows it needs).
+__global__ __launch_bounds__(256) void k_scharr3_dx_abs(const uint8_t *__restrict__ src, int src_stride, int w, int h,
+                                                        int16_t *__restrict__ dst, int dst_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h) return;
+  const int r = i / w, c = i - r * w;
+  const int cl = c == 0 ? 0 : c - 1, cr = c == w - 1 ? w - 1 : c + 1;
+  const int rt = r == 0 ? 0 : r - 1, rb = r == h - 1 ? h - 1 : r + 1;
+  auto inter = [&](int rr) {
+    const uint8_t *row = src + (size_t)rr * src_stride;
+    const int d = (int)row[cr] - (int)row[cl];
+    return d < 0 ? -d : d;
+  };
+  dst[(size_t)r * dst_stride + c] = (int16_t)(3 * (inter(rt) + inter(rb)) + 10 * inter(r));
+}
+
 }  // namespace
+
+void dmz_launch_scharr3_dx_abs(hipStream_t s, const uint8_t *src, int src_stride, int w, int h, int16_t *dst, int dst_stride) {
+  hipLaunchKernelGGL(k_scharr3_dx_abs, dim3((unsigned)((w * h + 255) / 256)), dim3(256), 0, s, src, src_stride, w, h, dst, dst_stride);
+}
 
 void dmz_launch_blur_cards(hipStream_t s, uint8_t *rgb, size_t card_stride, int channels, int n,
                            const dmz_hip_session_result *sessions, int unblur_digits) {

@@ -301,6 +301,47 @@ bool dmz_passes_luhn_checksum(uint8_t *number_array, uint8_t number_length);
 dmz_card_info dmz_card_info_for_prefix_and_length(uint8_t *number_array, uint8_t number_length,
                                                   bool allow_incomplete_number);
 
+// ---- the Cython flavour's extra entry points (dmz.h:103-119 under CYTHON_DMZ, scan/expiry_types.h:94-117, mz.h:37-52) ----
+#define IPL_DEPTH_16S ((int)0x80000000 | 16)
+typedef struct {
+  int top;
+  int left;
+} CythonCharacterRect;
+typedef float CythonGroupScores[kExpiryMaxValidLength][10];
+typedef struct {
+  int top;
+  int left;
+  int width;
+  int height;
+  int character_width;
+  uint8_t pattern;
+  CythonGroupScores scores;
+  int recently_seen_count;
+  int total_seen_count;
+  int number_of_character_rects;
+  CythonCharacterRect *character_rects;
+} CythonGroupedRects;
+// dmz.h:105 -- src 8U one channel, dst 16S one channel of the same size (ROIs honoured as image extents)
+void dmz_scharr3_dx_abs(IplImage *src, IplImage *dst);
+// dmz.h:110 -- *expiry_groups is malloc'ed (and each group's character_rects), as in the reference; the caller frees
+void dmz_best_expiry_seg(IplImage *card_y, uint16_t starting_y_offset, CythonGroupedRects **expiry_groups, uint16_t *number_of_groups);
+// dmz.h:111-114 -- categorises the digits of the new groups, aggregates them into the session's groups (both arrays are
+// re-allocated to their new sizes as in dmz.cpp:625-655) and picks the stable month / year
+void dmz_expiry_extract(IplImage *card_y, uint16_t *number_of_expiry_groups, CythonGroupedRects **cython_expiry_groups,
+                        uint16_t *number_of_new_groups, CythonGroupedRects **cython_new_groups, int *expiry_month,
+                        int *expiry_year);
+// dmz.h:115-119
+void dmz_expiry_extract_group(IplImage *card_y, CythonGroupedRects &cython_group, CythonGroupScores cython_scores,
+                              int *expiry_month, int *expiry_year);
+// mz.h:37-52: image headers over caller data (no Python object is involved in these signatures)
+IplImage *py_mz_create_from_cv_image_data(char *image_data, int image_size, int width, int height, int64_t depth,
+                                          int n_channels, int roi_x_offset, int roi_y_offset, int roi_width, int roi_height);
+void py_mz_release_ipl_image(IplImage *image);
+void py_mz_get_cv_image_data(IplImage *source, char **image_data, int *image_size, int *width, int *height, int64_t *depth,
+                             int *n_channels, int *roi_x_offset, int *roi_y_offset, int *roi_width, int *roi_height);
+void py_mz_cvSetImageROI(IplImage *image, int left, int top, int width, int height);
+void py_mz_cvResetImageROI(IplImage *image);
+
 // image helpers standing in for cvCreateImage / cvReleaseImage on 8-bit images
 // (dmz_transform_card allocates *transformed when it is NULL; the caller frees it)
 IplImage *dmz_create_image_8u(int width, int height, int channels);

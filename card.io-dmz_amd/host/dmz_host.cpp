@@ -793,6 +793,210 @@ void dmz_blur_card(IplImage *cardImageRGB, ScannerState *state, int unblurDigits
   }
 }
 
+// ---- the Cython flavour's entry points (dmz.cpp:517-674, mz.cpp: py_mz_*) ----------------------------------
+static void image_extent(const IplImage *im, int *x, int *y, int *w, int *h) {
+  *x = im->roi ? im->roi->xOffset : 0, *y = im->roi ? im->roi->yOffset : 0;
+  *w = im->roi ? im->roi->width : im->width, *h = im->roi ? im->roi->height : im->height;
+}
+
+void dmz_scharr3_dx_abs(IplImage *src, IplImage *dst) {  // llcv_scharr3_dx_abs (cv/sobel.cpp:706-804)
+  dmz_hip_context *ctx = hip_of(NULL);
+  if (!ctx || !src || !dst || src->nChannels != 1 || dst->nChannels != 1 || src->depth != IPL_DEPTH_8U) return;
+  int sx, sy, sw, sh, dx, dy, dw, dh;
+  image_extent(src, &sx, &sy, &sw, &sh);
+  image_extent(dst, &dx, &dy, &dw, &dh);
+  if (sw != dw || sh != dh) return;  // (the reference asserts)
+  const uint8_t *sp = (const uint8_t *)src->imageData + (size_t)sy * src->widthStep + sx;
+  int16_t *dp = (int16_t *)(dst->imageData + (size_t)dy * dst->widthStep) + dx;
+  if (dmz_hip_scharr3_dx_abs(ctx, sp, src->widthStep, sw, sh, dp, dst->widthStep / 2) != DMZ_HIP_OK)
+    fprintf(stderr, "dmz (HIP): scharr failed: %s\n", dmz_hip_last_error(ctx));
+}
+
+static CythonGroupedRects to_cython_group(const GroupedRects &g) {  // dmz.cpp:546-577
+  CythonGroupedRects c;
+  memset(&c, 0, sizeof(c));
+  c.top = g.top, c.left = g.left, c.width = g.width, c.height = g.height;
+  c.character_width = g.character_width;
+  c.pattern = (uint8_t)g.pattern;
+  for (int i = 0; i < kExpiryMaxValidLength; i++)
+    for (int d = 0; d < 10; d++) c.scores[i][d] = g.scores(i, d);
+  c.recently_seen_count = g.recently_seen_count;
+  c.total_seen_count = g.total_seen_count;
+  c.number_of_character_rects = (int)g.character_rects.size();
+  c.character_rects = (CythonCharacterRect *)malloc(sizeof(CythonCharacterRect) * (g.character_rects.size() + 1));
+  for (size_t i = 0; i < g.character_rects.size(); i++)
+    c.character_rects[i].top = g.character_rects[i].top, c.character_rects[i].left = g.character_rects[i].left;
+  return c;
+}
+static GroupedRects from_cython_group(const CythonGroupedRects *c) {  // dmz.cpp:580-601
+  GroupedRects g;
+  g.top = c->top, g.left = c->left, g.width = c->width, g.height = c->height;
+  g.grouped_yet = false;
+  g.sum = 0;
+  g.character_width = c->character_width;
+  g.pattern = (ExpiryPattern)c->pattern;
+  for (int i = 0; i < kExpiryMaxValidLength; i++)
+    for (int d = 0; d < 10; d++) g.scores(i, d) = c->scores[i][d];
+  g.recently_seen_count = c->recently_seen_count;
+  g.total_seen_count = c->total_seen_count;
+  for (int i = 0; i < c->number_of_character_rects; i++)
+    g.character_rects.push_back(CharacterRect(c->character_rects[i].top, c->character_rects[i].left, 0));
+  return g;
+}
+
+// the card as the packed 428 x 270 bytes the device entries take (NULL: not a card image)
+static uint8_t *card_bytes(IplImage *card_y, bool *owned) {
+  if (!card_y || card_y->roi || card_y->width != kCreditCardTargetWidth || card_y->height != kCreditCardTargetHeight ||
+      card_y->nChannels != 1 || card_y->depth != IPL_DEPTH_8U)
+    return NULL;
+  return packed_rows(card_y, 1, owned);
+}
+
+void dmz_best_expiry_seg(IplImage *card_y, uint16_t starting_y_offset, CythonGroupedRects **expiry_groups,
+                         uint16_t *number_of_groups) {
+  if (expiry_groups) *expiry_groups = NULL;
+  if (number_of_groups) *number_of_groups = 0;
+  dmz_hip_context *ctx = hip_of(NULL);
+  bool owned = false;
+  uint8_t *p = ctx && expiry_groups && number_of_groups ? card_bytes(card_y, &owned) : NULL;
+  if (!p) return;
+  // best_expiry_seg (expiry_seg.cpp:707-902) runs whenever the number row is known (frame.cpp:71-73); no digit is categorised
+  dmz_hip_frame_result r;
+  dmz_hip_expiry_result x;
+  memset(&r, 0, sizeof(r));
+  memset(&x, 0, sizeof(x));
+  r.flags = DMZ_HIP_FLAG_VSEG_OK;
+  r.vseg_y_offset = starting_y_offset;
+  if (dmz_hip_scan_expiry_batch(ctx, p, (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight, 1, &r, &x) == DMZ_HIP_OK) {
+    GroupedRectsList groups;
+    fill_expiry_groups(x, &groups);
+    *expiry_groups = (CythonGroupedRects *)malloc(sizeof(CythonGroupedRects) * (groups.size() + 1));
+    for (size_t i = 0; i < groups.size(); i++) (*expiry_groups)[i] = to_cython_group(groups[i]);
+    *number_of_groups = (uint16_t)groups.size();
+  } else {
+    fprintf(stderr, "dmz (HIP): expiry segmentation failed: %s\n", dmz_hip_last_error(ctx));
+  }
+  if (owned) free(p);
+}
+
+// categorize_expiry_digits (expiry_categorize.cpp:138-160) for caller-supplied groups: characters 0, 1, 3, 4 of every group
+static bool categorize_groups(IplImage *card_y, GroupedRectsList &groups) {
+  dmz_hip_context *ctx = hip_of(NULL);
+  bool owned = false;
+  uint8_t *p = ctx ? card_bytes(card_y, &owned) : NULL;
+  if (!p) return false;
+  bool ok = true;
+  for (size_t base = 0; base < groups.size() && ok; base += DMZ_HIP_EXPIRY_MAX_GROUPS) {
+    dmz_hip_expiry_result x;
+    memset(&x, 0, sizeof(x));
+    const size_t m = groups.size() - base < (size_t)DMZ_HIP_EXPIRY_MAX_GROUPS ? groups.size() - base : DMZ_HIP_EXPIRY_MAX_GROUPS;
+    for (size_t i = 0; i < m && ok; i++) {
+      const GroupedRects &g = groups[base + i];
+      ok = g.character_rects.size() == 5;  // ExpiryPatternMMsYY: the only pattern the segmentation produces
+      for (int c = 0; c < 5 && ok; c++)
+        x.groups[i].char_top[c] = (int16_t)g.character_rects[c].top, x.groups[i].char_left[c] = (int16_t)g.character_rects[c].left;
+    }
+    x.n_groups = (int)m;
+    ok = ok && dmz_hip_categorize_expiry_groups_batch(ctx, p, (size_t)kCreditCardTargetWidth * kCreditCardTargetHeight, 1, &x) == DMZ_HIP_OK;
+    for (size_t i = 0; i < m && ok; i++) {
+      memset(&groups[base + i].scores, 0, sizeof(ExpiryGroupScores));
+      for (int row = 0; row < 4; row++)
+        memcpy(groups[base + i].scores.v[row < 2 ? row : row + 1], x.groups[i].scores[row], sizeof(float) * 10);
+    }
+  }
+  if (owned) free(p);
+  return ok;
+}
+
+void dmz_expiry_extract(IplImage *card_y, uint16_t *number_of_expiry_groups, CythonGroupedRects **cython_expiry_groups,
+                        uint16_t *number_of_new_groups, CythonGroupedRects **cython_new_groups, int *expiry_month,
+                        int *expiry_year) {
+  if (!number_of_expiry_groups || !cython_expiry_groups || !number_of_new_groups || !cython_new_groups || !expiry_month || !expiry_year)
+    return;
+  GroupedRectsList expiry_groups, new_groups;
+  for (int i = 0; i < *number_of_expiry_groups; i++) expiry_groups.push_back(from_cython_group(*cython_expiry_groups + i));
+  for (int i = 0; i < *number_of_new_groups; i++) new_groups.push_back(from_cython_group(*cython_new_groups + i));
+  // expiry_extract (expiry_categorize.cpp:448-501)
+  if (!new_groups.empty() && categorize_groups(card_y, new_groups)) {
+    expiry_aggregate_grouped_rects(expiry_groups, new_groups);
+    for (GroupedRectsList::iterator group = expiry_groups.begin(); group != expiry_groups.end(); ++group) {
+      if (group->total_seen_count < 3) continue;
+      get_stable_expiry_month_and_year(*group, expiry_month, expiry_year);
+    }
+  }
+  // back to the caller's arrays, re-allocated to the new sizes (dmz.cpp:643-655); unlike the reference the character
+  // rectangle arrays of the replaced entries are released
+  for (int i = 0; i < *number_of_expiry_groups; i++) free((*cython_expiry_groups)[i].character_rects);
+  for (int i = 0; i < *number_of_new_groups; i++) free((*cython_new_groups)[i].character_rects);
+  *cython_expiry_groups = (CythonGroupedRects *)realloc(*cython_expiry_groups, sizeof(CythonGroupedRects) * (expiry_groups.size() + 1));
+  *cython_new_groups = (CythonGroupedRects *)realloc(*cython_new_groups, sizeof(CythonGroupedRects) * (new_groups.size() + 1));
+  for (size_t i = 0; i < expiry_groups.size(); i++) (*cython_expiry_groups)[i] = to_cython_group(expiry_groups[i]);
+  for (size_t i = 0; i < new_groups.size(); i++) (*cython_new_groups)[i] = to_cython_group(new_groups[i]);
+  *number_of_expiry_groups = (uint16_t)expiry_groups.size();
+  *number_of_new_groups = (uint16_t)new_groups.size();
+}
+
+void dmz_expiry_extract_group(IplImage *card_y, CythonGroupedRects &cython_group, CythonGroupScores cython_scores,
+                              int *expiry_month, int *expiry_year) {
+  // expiry_extract_group (expiry_categorize.cpp:504-522): this frame's scores blended into the group's old ones
+  GroupedRectsList one(1, from_cython_group(&cython_group));
+  const ExpiryGroupScores old_scores = one[0].scores;
+  if (!categorize_groups(card_y, one)) return;
+  GroupedRects &group = one[0];
+  for (int i = 0; i < kExpiryMaxValidLength; i++)
+    for (int d = 0; d < 10; d++) group.scores(i, d) = (old_scores(i, d) * kExpiryDecayFactor) + (group.scores(i, d) * (1 - kExpiryDecayFactor));
+  get_stable_expiry_month_and_year(group, expiry_month, expiry_year);
+  for (int i = 0; i < kExpiryMaxValidLength; i++)
+    for (int d = 0; d < 10; d++) cython_scores[i][d] = group.scores(i, d);
+}
+
+// mz.h:37-52 (cython_dmz/mz.cpp): an IplImage header over the caller's pixels
+IplImage *py_mz_create_from_cv_image_data(char *image_data, int image_size, int width, int height, int64_t depth,
+                                          int n_channels, int roi_x_offset, int roi_y_offset, int roi_width, int roi_height) {
+  IplImage *im = (IplImage *)calloc(1, sizeof(IplImage));
+  if (!im) return NULL;
+  im->nSize = (int)sizeof(IplImage);
+  im->nChannels = n_channels;
+  im->depth = (int)depth;
+  im->align = 4;
+  im->width = width;
+  im->height = height;
+  im->widthStep = height > 0 ? image_size / height : 0;
+  im->imageSize = image_size;
+  im->imageData = im->imageDataOrigin = image_data;
+  if (roi_width > 0 && roi_height > 0 && (roi_x_offset || roi_y_offset || roi_width != width || roi_height != height))
+    py_mz_cvSetImageROI(im, roi_x_offset, roi_y_offset, roi_width, roi_height);
+  return im;
+}
+void py_mz_release_ipl_image(IplImage *image) {  // the header only: the pixels are the caller's
+  if (!image) return;
+  free(image->roi);
+  free(image);
+}
+void py_mz_get_cv_image_data(IplImage *source, char **image_data, int *image_size, int *width, int *height, int64_t *depth,
+                             int *n_channels, int *roi_x_offset, int *roi_y_offset, int *roi_width, int *roi_height) {
+  *image_data = source->imageData;
+  *image_size = source->imageSize;
+  *width = source->width, *height = source->height;
+  *depth = source->depth;
+  *n_channels = source->nChannels;
+  int x, y, w, h;
+  image_extent(source, &x, &y, &w, &h);
+  *roi_x_offset = x, *roi_y_offset = y, *roi_width = w, *roi_height = h;
+}
+void py_mz_cvSetImageROI(IplImage *image, int left, int top, int width, int height) {
+  if (!image) return;
+  if (!image->roi) image->roi = (IplROI *)calloc(1, sizeof(IplROI));
+  image->roi->coi = 0;
+  image->roi->xOffset = left, image->roi->yOffset = top, image->roi->width = width, image->roi->height = height;
+}
+void py_mz_cvResetImageROI(IplImage *image) {
+  if (image && image->roi) {
+    free(image->roi);
+    image->roi = NULL;
+  }
+}
+
 // ---- flat-array hook for the host-logic tests (tests/test_host_logic.py): replays a session's
 // expiry_extract calls (expiry_categorize.cpp:332-376) on caller-supplied per-frame groups ----
 extern "C" int dmz_hip_host_expiry_session_replay(int n_frames, const int *groups_per_frame, const int16_t *tops,

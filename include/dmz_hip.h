@@ -170,6 +170,21 @@ int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_
 int dmz_hip_scan_expiry_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
                               const dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry);
 
+/* categorize_expiry_digits (scan/expiry_categorize.cpp:138-160) on CALLER-SUPPLIED groups: for every frame the records'
+ * n_groups and the five character rectangles of each group (char_top / char_left, 11 x 16 px, inside the card) are read,
+ * the scores[4][10] of each group are written (characters 0, 1, 3, 4); nothing else of the record changes.  This is
+ * the half of expiry_extract (expiry_categorize.cpp:448-501; Cython flavour dmz_expiry_extract*, dmz.h:110-119) that needs the
+ * device when the groups come from the caller instead of from dmz_hip_scan_expiry_batch.  cards: device or host;
+ * expiry: HOST records (in / out). */
+int dmz_hip_categorize_expiry_groups_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                                           dmz_hip_expiry_result *expiry);
+
+/* llcv_scharr3_dx_abs (cv/sobel.cpp:706-804; Cython flavour dmz_scharr3_dx_abs, dmz.h:105): |right - left| with clamped
+ * columns, then 3 / 10 / 3 down the column with clamped rows, 8U -> 16S.  Device or host pointers; strides in elements
+ * of their type. */
+int dmz_hip_scharr3_dx_abs(dmz_hip_context *ctx, const uint8_t *src, int src_stride, int width, int height, int16_t *dst,
+                           int dst_stride);
+
 /* Arithmetic of the expiry CNN's convolutions (applyc_bf4dd6c8, models/expiry/modelc_bf4dd6c8.cpp:
  * 12688-12724: conv2 is 72 x 1250 x 40 per group, the largest contraction of the path), BASELINE configs[3]
  * "bf16 conv with fp32 parity check":

@@ -85,6 +85,58 @@ int main(int argc, char **argv) {
            cr.hseg.n_offsets);
     for (int d = 0; d < cr.hseg.n_offsets; d++) printf(" %d", cr.hseg.offsets[d]);
     printf("\n");
+    // the Cython flavour's expiry calls (dmz.h:105-119) on the same card, three times like three frames of a session:
+    // dmz_best_expiry_seg, then dmz_expiry_extract with the groups it returned; and the Scharr image through py_mz_* headers
+    IplImage *card = NULL;
+    if (dmz_detect_edges(&y, NULL, NULL, FrameOrientationLandscapeRight, &edges, &corners))
+      dmz_transform_card(dmz, &y, corners, FrameOrientationLandscapeRight, false, &card);
+    if (card) {
+      uint16_t n_session = 0;
+      CythonGroupedRects *session = NULL;
+      int month = 0, year = 0;
+      for (int rep = 0; rep < 3; rep++) {
+        uint16_t n_new = 0;
+        CythonGroupedRects *fresh = NULL;
+        dmz_best_expiry_seg(card, cr.vseg.y_offset, &fresh, &n_new);
+        if (rep == 0) {
+          printf("cyseg %d", n_new);
+          for (int g = 0; g < n_new; g++) {
+            printf(" [%d %d %d %d :", fresh[g].top, fresh[g].left, fresh[g].width, fresh[g].height);
+            for (int c = 0; c < fresh[g].number_of_character_rects; c++) printf(" %d,%d", fresh[g].character_rects[c].left, fresh[g].character_rects[c].top);
+            printf("]");
+          }
+          printf("\n");
+        }
+        dmz_expiry_extract(card, &n_session, &session, &n_new, &fresh, &month, &year);
+        if (rep == 0) {
+          printf("cycat %d", n_new);
+          for (int g = 0; g < n_new; g++)
+            for (int ch = 0; ch < 5; ch++) {
+              if (ch == 2) continue;
+              int best = 0;
+              for (int d = 1; d < 10; d++) if (fresh[g].scores[ch][d] > fresh[g].scores[ch][best]) best = d;
+              printf(" %d:%.6f", best, fresh[g].scores[ch][best]);
+            }
+          printf("\n");
+        }
+        for (int g = 0; g < n_new; g++) free(fresh[g].character_rects);
+        free(fresh);
+      }
+      printf("cysession groups %d month %d year %d\n", n_session, month, year);
+      for (int g = 0; g < n_session; g++) free(session[g].character_rects);
+      free(session);
+      // dmz_scharr3_dx_abs on rows 180..269 of the card, through image headers made by the py_mz_* helpers
+      std::vector<int16_t> sch((size_t)428 * 90);
+      IplImage *src = py_mz_create_from_cv_image_data(card->imageData, card->imageSize, 428, 270, IPL_DEPTH_8U, 1, 0, 180, 428, 90);
+      IplImage *dst = py_mz_create_from_cv_image_data((char *)sch.data(), 428 * 90 * 2, 428, 90, IPL_DEPTH_16S, 1, 0, 0, 428, 90);
+      dmz_scharr3_dx_abs(src, dst);
+      long long ssum = 0, wsum = 0;
+      for (size_t i = 0; i < sch.size(); i++) ssum += sch[i], wsum += (long long)sch[i] * (long long)(i % 997 + 1);
+      printf("cyscharr %lld %lld\n", ssum, wsum);
+      py_mz_release_ipl_image(src);
+      py_mz_release_ipl_image(dst);
+      dmz_release_image(&card);
+    }
   }
   float m[9];
   dmz_point s[4] = {{106, 105}, {533, 105}, {106, 374}, {533, 374}}, d[4];

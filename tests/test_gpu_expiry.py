@@ -300,6 +300,41 @@ def test_expiry_gates_and_edge_cards(ctx, pkg, oracle):
         _compare(pkg, exp[i], want, "forced %d" % i)
 
 
+def test_scharr_and_categorise_entries(ctx, pkg, oracle):
+    """the two entries behind the Cython flavour's dmz_scharr3_dx_abs / dmz_expiry_extract (dmz.h:105-119): the Scharr operator
+    on images of several sizes, and categorize_expiry_digits on caller-supplied groups (the oracle's own segmentation of
+    synthetic cards), both against the oracle"""
+    rng = np.random.default_rng(1905)
+    for shape in ((1, 1), (2, 7), (90, 428), (33, 130), (270, 428)):
+        img = rng.integers(0, 256, shape).astype(np.uint8)
+        assert np.array_equal(ctx.scharr3_dx_abs(img), oracle.scharr3_dx_abs(img)), shape
+    n = 24
+    cards = np.ascontiguousarray(np.stack([oracle.synth_card(SEED, 700 + i)[0] for i in range(n)]))
+    recs = np.zeros(n, pkg.EXPIRY_DTYPE)
+    want = []
+    for i in range(n):
+        res = oracle.scan_card_image(cards[i], warped=False)
+        res["flags"] = res["flags"] | pkg.FLAG_USABLE
+        w = oracle.scan_card_expiry(cards[i], res)
+        want.append(w)
+        recs[i]["n_groups"] = w["n_groups"]
+        for g in range(int(w["n_groups"])):
+            recs[i]["groups"][g]["char_top"] = w["groups"][g]["char_top"]
+            recs[i]["groups"][g]["char_left"] = w["groups"][g]["char_left"]
+    ctx.categorize_expiry_groups(cards, n, recs)
+    groups = 0
+    for i in range(n):
+        for g in range(int(want[i]["n_groups"])):
+            groups += 1
+            assert np.abs(recs[i]["groups"][g]["scores"] - want[i]["groups"][g]["scores"]).max() <= 1e-4, (i, g)
+    assert groups >= 8
+    bad = recs[:1].copy()
+    bad[0]["n_groups"] = 1
+    bad[0]["groups"][0]["char_left"][:] = 425  # a character rectangle that leaves the card
+    with pytest.raises(pkg.DmzHipError):
+        ctx.categorize_expiry_groups(cards, 1, bad)
+
+
 def test_expiry_bad_arguments(ctx, pkg):
     res = np.zeros(1, pkg.RESULT_DTYPE)
     exp = np.zeros(1, pkg.EXPIRY_DTYPE)

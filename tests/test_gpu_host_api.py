@@ -61,8 +61,39 @@ def test_sdk_style_call_sequence(tmp_path, oracle, ctx):
     assert cy[0] == "cython" and int(cy[2]) == usable and int(cy[4]) == int(want["vseg_y_offset"])
     assert int(cy[6]) == int(want["pattern_type"]) and int(cy[8]) == int(want["n_offsets"])
     assert [int(v) for v in cy[10:]] == [int(v) for v in want["offsets"][: int(want["n_offsets"])]]
+    # the Cython flavour's expiry entry points (dmz.h:105-119) on the same card
+    seg = out[n + 3]
+    assert seg.split()[0] == "cyseg"
+    seg_only = oracle.best_expiry_seg(wcard, int(want["vseg_y_offset"]))
+    assert int(seg.split()[1]) == int(seg_only["n_groups"])
+    for g in range(int(seg_only["n_groups"])):
+        grp = seg_only["groups"][g]
+        want_txt = "[%d %d %d %d : %s]" % (grp["top"], grp["left"], grp["width"], grp["height"],
+                                           " ".join("%d,%d" % (l, tp) for l, tp in zip(grp["char_left"], grp["char_top"])))
+        assert want_txt in seg, (want_txt, seg)
+    cat = out[n + 4].split()
+    assert cat[0] == "cycat" and int(cat[1]) == int(seg_only["n_groups"])
+    forced = want.copy()
+    forced["flags"] = 5  # usable + vseg ok: the digits of every group are categorised
+    wcat = oracle.scan_card_expiry(wcard, forced)
+    k = 2
+    for g in range(int(wcat["n_groups"])):
+        for row in range(4):
+            best, score = cat[k].split(":")
+            k += 1
+            assert int(best) == int(wcat["groups"][g]["scores"][row].argmax())
+            assert abs(float(score) - float(wcat["groups"][g]["scores"][row].max())) <= 1e-4
+    sess = out[n + 5].split()
+    assert sess[0] == "cysession"
+    if int(wcat["n_groups"]) > 0:
+        assert int(sess[2]) >= 1  # three sightings of the same groups: aggregated, not tripled
+        assert int(sess[2]) <= int(wcat["n_groups"])
+    sch = oracle.scharr3_dx_abs(wcard[180:270]).astype(np.int64).reshape(-1)
+    cys = out[n + 6].split()
+    assert cys[0] == "cyscharr" and int(cys[1]) == int(sch.sum())
+    assert int(cys[2]) == int((sch * (np.arange(sch.size) % 997 + 1)).sum())
     m = oracle.calc_persp_transform([106, 105, 533, 105, 106, 374, 533, 374], [0, 0, 427, 0, 0, 269, 427, 269])
-    p = out[n + 3].split()
+    p = out[n + 7].split()
     assert np.float32(p[1]) == m[0] and np.float32(p[2]) == m[2] and np.float32(p[3]) == m[5]
 
 
@@ -84,5 +115,9 @@ def test_host_library_exports_reference_names(pkg):
                  "dmz_deinterleave_uint8_c2(", "dmz_deinterleave_RGBA_to_R(", "dmz_YCbCr_to_RGB(", "dmz_focus_score(",
                  "dmz_brightness_score(", "dmz_blur_card(", "dmz_create_point(", "dmz_create_rect(", "dmz_rect_get_points(",
                  # scan/frame.h:30-46
-                 "scan_card_image(", "cython_scan_card_image("):
+                 "scan_card_image(", "cython_scan_card_image(",
+                 # the Cython flavour: dmz.h:105-119, mz.h:37-52
+                 "dmz_scharr3_dx_abs(", "dmz_best_expiry_seg(", "dmz_expiry_extract(", "dmz_expiry_extract_group(",
+                 "py_mz_create_from_cv_image_data(", "py_mz_release_ipl_image(", "py_mz_get_cv_image_data(",
+                 "py_mz_cvSetImageROI(", "py_mz_cvResetImageROI("):
         assert name in syms, name
