@@ -552,7 +552,66 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     const bool overflow = s_int[3] != 0;
     constexpr int NW = NT / 64;
     const int nwords = S * NW;
-    if (overflow && nwords * 16 <= list_cap * 2) {
+    if (overflow && S <= 64 && NW * 64 <= list_cap * 2) {
+      // ---- dense candidates: flood on bitmaps held in REGISTERS.  Lane a of wave w holds the two 64-bit words of step a:
+      // `cand` = NMS survivors above the low threshold (seeds included), `edge` starts as the seeds; bits 1..62 own a pixel.
+      // One local step: an edge bit spreads to the candidate bits among its eight neighbours -- the rows above and below are the
+      // neighbouring LANES (two DPP moves each), the columns across a wave boundary arrive as halo bits -- then along the row
+      // through runs of candidates by carry propagation.  A wave repeats the step until nothing changes WITHOUT a barrier;
+      // then the waves trade their border columns (one byte per step through LDS) and repeat, until no wave changed: the same
+      // fixed point as the stack flood fill.  (Round 3's form kept the words in LDS, one thread per word and one barrier
+      // per row of propagation: 12 - 17 passes of 2 - 4 k cycles on a noise frame.) ----
+      unsigned char *bord = (unsigned char *)list;  // [wave][step]: bit 0 = edge at lane 1, bit 1 = edge at lane 62
+      unsigned long long C = 0ull, E = 0ull;
+      for (int a = 0; a < S; a++) {
+        const int fl = inbox ? (int)map[a * L + c.l] : 0;
+        const unsigned long long bc = __ballot((fl & MAP_CAND) != 0) & 0x7ffffffffffffffeull,
+                                 be = __ballot((fl & MAP_EDGE) != 0) & 0x7ffffffffffffffeull;
+        if (lane == a) C = bc, E = be;
+      }
+      auto lane_dn = [](unsigned long long v) {  // the word of lane - 1 (0 at lane 0)
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, true);
+        return ((unsigned long long)hi << 32) | lo;
+      };
+      auto lane_up = [](unsigned long long v) {  // the word of lane + 1 (0 at lane 63)
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x130, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x130, 0xf, 0xf, true);
+        return ((unsigned long long)hi << 32) | lo;
+      };
+      for (;;) {
+        if (lane < S) bord[wave * 64 + lane] = (unsigned char)(((E >> 1) & 1ull) | (((E >> 62) & 1ull) << 1));
+        __syncthreads();
+        unsigned long long halo = 0ull;  // lane 62 of the wave below = our lane 0, lane 1 of the wave above = our lane 63
+        if (lane < S) {
+          if (wave > 0) halo |= (unsigned long long)((bord[(wave - 1) * 64 + lane] >> 1) & 1);
+          if (wave < NW - 1) halo |= (unsigned long long)(bord[(wave + 1) * 64 + lane] & 1) << 63;
+        }
+        int any = 0;
+        for (;;) {
+          const unsigned long long x = E | halo;
+          const unsigned long long t = x | lane_dn(x) | lane_up(x);
+          unsigned long long g = ((t | (t << 1) | (t >> 1)) & C) | E;
+          {
+            const unsigned long long up = C & (C ^ (C + g));
+            const unsigned long long rc = __builtin_bitreverse64(C), rg = __builtin_bitreverse64(g);
+            g |= up | __builtin_bitreverse64(rc & (rc ^ (rc + rg)));
+          }
+          const bool ch = g != E;
+          E = g;
+          if (__ballot(ch) == 0ull) break;
+          any = 1;
+        }
+        if (!__syncthreads_or(any)) break;
+      }
+      for (int a = 0; a < S; a++) {
+        const unsigned long long be = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(E >> 32), a) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)E, a);
+        if (owner && ((be >> lane) & 1ull)) map[a * L + c.l] = (unsigned char)(map[a * L + c.l] | MAP_EDGE);
+      }
+      __syncthreads();
+    } else if (overflow && nwords * 16 <= list_cap * 2) {
+      // (boxes of more than 64 steps: the same flood with the words in LDS, one thread per word, one barrier per pass)
       // ---- dense candidates: flood on bitmaps.  Word (s, w) = the 64 lanes of wave w at step s (bits 1..62 own a pixel);
       // `cand` = NMS survivors above the low threshold (seeds included), `edge` starts as the seeds.  One pass: an edge bit
       // spreads to the candidate bits among its eight neighbours (three rows, the word's neighbours lend their border bits),
@@ -569,7 +628,14 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
         }
       }
       __syncthreads();
+#ifdef DMZ_DT_TIMING
+      int dt_passes = 0;
+      const long long dt_h0 = clock64();
+#endif
       for (;;) {
+#ifdef DMZ_DT_TIMING
+        dt_passes++;
+#endif
         int changed = 0;
         for (int t = tid; t < nwords; t += NT) {
           const int a = t / NW, w = t - a * NW;
@@ -581,12 +647,15 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
             if (w < NW - 1) x |= ((bedge[r * NW + w + 1] >> 1) & 1ull) << 63;  // lane 1 of the wave above = our lane 63
             d |= x | (x << 1) | (x >> 1);
           }
-          unsigned long long g = (d & cm) | mine, pl = cm, pr = cm;
-#pragma unroll
-          for (int sh = 1; sh < 64; sh <<= 1) {
-            g |= (pl & (g << sh)) | (pr & (g >> sh));
-            pl &= pl << sh;
-            pr &= pr >> sh;
+          // along the row through runs of candidates, by carry propagation instead of a Kogge-Stone fill: adding the seeds to the
+          // run mask clears every run from its lowest seed upwards (and sets the bit above the run), so cm ^ (cm + seeds) marks
+          // exactly those stretches; the downward direction is the same on the bit-reversed words (~25 instead of ~120 operations)
+          unsigned long long g = (d & cm) | mine;
+          {
+            const unsigned long long up = cm & (cm ^ (cm + g));
+            const unsigned long long rc = __builtin_bitreverse64(cm), rg = __builtin_bitreverse64(g);
+            const unsigned long long dn = __builtin_bitreverse64(rc & (rc ^ (rc + rg)));
+            g |= up | dn;
           }
           if (g != mine) {
             bedge[t] = g;
@@ -595,6 +664,9 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
         }
         if (!__syncthreads_or(changed)) break;
       }
+#ifdef DMZ_DT_TIMING
+      if (tid == 0 && blockIdx.x == gridDim.x / 2) printf("bitmap flood %s: %d passes, %lld cycles (build %lld)\n", VERT ? "vert" : "hz", dt_passes, clock64() - dt_h0, dt_h0 - g_dt_t[VERT ? 1 : 0][3]);
+#endif
       for (int a = 0; a < S; a++) {
         const unsigned long long be = bedge[a * NW + wave];
         if (owner && ((be >> lane) & 1ull)) map[a * L + c.l] = (unsigned char)(map[a * L + c.l] | MAP_EDGE);
