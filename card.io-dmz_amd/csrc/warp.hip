@@ -490,7 +490,10 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     fast_xy(cB, Xb, Yb);
     uint32_t lo16;
     unsigned long long amb;
-    asm("v_min3_u16 %0, %2, %3, %4\n\t"
+    // (three two-operand v_min_u16: the 16-bit VOP2 forms issue at full rate on gfx950, the three-operand v_min3_u16 at a
+    // quarter of it -- profiles/r4_valu_table_gfx950.txt: 2.4 against 8.5 cycles)
+    asm("v_min_u16 %0, %2, %3\n\t"
+        "v_min_u16 %0, %0, %4\n\t"
         "v_min_u16 %0, %0, %5\n\t"
         "v_cmp_eq_u16 %1, 0, %0"
         : "=&v"(lo16), "=s"(amb)

@@ -48,6 +48,42 @@ OP32(k_and, "v_and_b32 %0, %0, %1")
 OP32(k_xor, "v_xor_b32 %0, %0, %1")
 OP32(k_lshl, "v_lshlrev_b32 %0, 1, %0")
 OP32(k_ashr, "v_ashrrev_i32 %0, 1, %0")
+OP32(k_lshr, "v_lshrrev_b32 %0, 1, %0")
+OP32(k_lshr_v, "v_lshrrev_b32 %0, %1, %0")
+OP32(k_ashr_v, "v_ashrrev_i32 %0, %1, %0")
+OP32(k_lshl_v, "v_lshlrev_b32 %0, %1, %0")
+OP32(k_or, "v_or_b32 %0, %0, %1")
+OP32(k_not, "v_not_b32 %0, %0")
+OP32(k_subrev, "v_subrev_u32 %0, %0, %1")
+OP32(k_xad, "v_xad_u32 %0, %0, %1, %2")
+OP32(k_bcnt, "v_bcnt_u32_b32 %0, %0, %1")
+OP32(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
+OP32(k_bfrev, "v_bfrev_b32 %0, %0")
+OP32(k_add_lit, "v_add_u32 %0, 0x12345, %0")
+OP32(k_and_lit, "v_and_b32 %0, 0xfffff, %0")
+OP32(k_mul_u24_vop2, "v_mul_u32_u24 %0, %0, %1")
+OP32(k_max_u16, "v_max_u16 %0, %0, %1")
+OP32(k_add_u16, "v_add_u16 %0, %0, %1")
+OP32(k_min_u16, "v_min_u16 %0, %0, %1")
+OP32(k_max_i16, "v_max_i16 %0, %0, %1")
+OP32(k_sub_u16, "v_sub_u16 %0, %0, %1")
+OP32(k_mul_lo_u16, "v_mul_lo_u16 %0, %0, %1")
+OP32(k_lshl_b16, "v_lshlrev_b16 %0, 1, %0")
+OP32(k_lshr_b16, "v_lshrrev_b16 %0, 1, %0")
+OP32(k_mad_u16, "v_mad_u16 %0, %0, %1, %2")
+OP32(k_cmp_u16, "v_cmp_gt_u16 vcc, %0, %1")
+OP32(k_cmp_u16_e64, "v_cmp_gt_u16 s[20:21], %0, %1")
+OP32(k_cmp_eq_u32, "v_cmp_eq_u32 vcc, %0, %1")
+OP32(k_max3_u16, "v_max3_u16 %0, %0, %1, %2")
+OP32(k_med3_u16, "v_med3_u16 %0, %0, %1, %2")
+OP32(k_add_f16, "v_add_f16 %0, %0, %1")
+OP32(k_max_f16, "v_max_f16 %0, %0, %1")
+OP32(k_mul_f16, "v_mul_f16 %0, %0, %1")
+OP32(k_cvt_f16_u16, "v_cvt_f16_u16 %0, %0")
+OP32(k_sub_f32, "v_sub_f32 %0, %0, %1")
+OP32(k_min_f32, "v_min_f32 %0, %0, %1")
+OP32(k_mul_legacy, "v_mul_legacy_f32 %0, %0, %1")
+OP32(k_readlane, "v_readlane_b32 s20, %0, 5")
 OP32(k_max_i32, "v_max_i32 %0, %0, %1")
 OP32(k_min_u32, "v_min_u32 %0, %0, %1")
 OP32(k_add3, "v_add3_u32 %0, %0, %1, %2")
@@ -135,7 +171,7 @@ static void run(const char *name, kern_t k, int per_asm) {
 #define RUN2(K) run(#K + 2, K, 2)
 
 int main() {
-  RUN(k_mov); RUN(k_add_u32); RUN(k_sub_u32); RUN(k_and); RUN(k_xor); RUN(k_lshl); RUN(k_ashr); RUN(k_max_i32); RUN(k_min_u32);
+  RUN(k_mov); RUN(k_add_u32); RUN(k_sub_u32); RUN(k_and); RUN(k_xor); RUN(k_lshl); RUN(k_ashr); RUN(k_lshr); RUN(k_lshr_v); RUN(k_ashr_v); RUN(k_lshl_v); RUN(k_or); RUN(k_not); RUN(k_subrev); RUN(k_xad); RUN(k_bcnt); RUN(k_mbcnt); RUN(k_bfrev); RUN(k_add_lit); RUN(k_and_lit); RUN(k_mul_u24_vop2); RUN(k_max_u16); RUN(k_add_u16); RUN(k_min_u16); RUN(k_max_i16); RUN(k_sub_u16); RUN(k_mul_lo_u16); RUN(k_lshl_b16); RUN(k_lshr_b16); RUN(k_mad_u16); RUN(k_cmp_u16); RUN(k_cmp_u16_e64); RUN(k_cmp_eq_u32); RUN(k_max3_u16); RUN(k_med3_u16); RUN(k_add_f16); RUN(k_max_f16); RUN(k_mul_f16); RUN(k_cvt_f16_u16); RUN(k_sub_f32); RUN(k_min_f32); RUN(k_mul_legacy); RUN(k_readlane); RUN(k_max_i32); RUN(k_min_u32);
   RUN(k_add3); RUN(k_lshl_add); RUN(k_lshl_or); RUN(k_and_or); RUN(k_bfe); RUN(k_bfi); RUN(k_cndmask); RUN(k_cmp_i32);
   RUN2(k_cmp_cnd); RUN(k_mul_i24); RUN(k_mad_i24); RUN(k_mad_u24); RUN(k_mul_lo); RUN(k_med3_i32); RUN(k_max3_i32);
   RUN(k_sad_u8); RUN(k_sad_u16); RUN(k_perm); RUN(k_alignbyte); RUN(k_dot4); RUN(k_dot2_u16); RUN(k_pk_add_u16);
