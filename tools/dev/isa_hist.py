@@ -6,8 +6,12 @@ import collections
 import re
 import sys
 
-FAST = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_ashrrev_i32",
-        "v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_co_u32", "v_accvgpr_read_b32", "v_accvgpr_write_b32"}
+FAST = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_ashrrev_i32",
+        "v_lshrrev_b32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_mul_legacy_f32", "v_fma_f32", "v_fmac_f32", "v_add_co_u32",
+        "v_accvgpr_read_b32", "v_accvgpr_write_b32",
+        # the two-operand 16-bit forms (the three-operand ones, v_mad_u16 / v_max3_u16 / v_med3_u16, are quarter rate)
+        "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_u16", "v_max_i16", "v_min_i16", "v_mul_lo_u16", "v_lshlrev_b16",
+        "v_lshrrev_b16", "v_ashrrev_i16", "v_add_f16", "v_sub_f16", "v_mul_f16", "v_max_f16", "v_min_f16"}
 COST = {"fast": 2.5, "slow": 4.3, "f64": 5.3, "trans": 8.2}
 
 
@@ -19,7 +23,8 @@ def klass(op):
         return "fast"
     if "_f64" in base or base.startswith("v_pk_") and base.endswith("_f32"):
         return "f64"
-    if base in ("v_exp_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_log_f32", "v_rcp_f64", "v_fma_f16"):
+    if base in ("v_exp_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_log_f32", "v_rcp_f64", "v_fma_f16", "v_mad_u16",
+                "v_max3_u16", "v_min3_u16", "v_med3_u16", "v_max3_i16", "v_min3_i16", "v_med3_i16", "v_mad_i16"):
         return "trans"
     return "slow"
 
