@@ -89,13 +89,30 @@ __device__ float hseg_score_t(const float *__restrict__ g, float width, int off,
   const bool live = in_bounds;
   const int first = c[0];
   float s = 0.0f;
+  // A term that lies outside the lane's segment must leave the sum as it is.  The reference's "j < len ? a : 0" costs a compare
+  // and a select per term (both half-rate instructions, profiles/r4_valu_table_gfx950.txt); here the term is multiplied by
+  // m = clamp(len - j) = 1 inside / 0 outside INSIDE the addition: fma(|a|, m, s) rounds a + s once, i.e. it IS s + a
+  // for m = 1 and s for m = 0 (a is finite: g is padded with zeros) -- the same bits from full-rate instructions only.
+  // (v_add_f32 with the clamp modifier, spelled out: the compiler turns min(max(x, 0), 1) into v_max_f32 ... clamp, a half-rate opcode)
+  auto clamp01 = [](float x) {
+    float m;
+    asm("v_add_f32_e64 %0, %1, 0 clamp" : "=v"(m) : "v"(x));
+    return m;
+  };
   // leading gap: columns [0, first) against pattern value 0
   {
     const int len = live ? first : 0;
     const int mx = wave_max(len);
-    for (int j = 0; j < mx; j++) {
-      const float a = fabsf(g[j] - 0.0f);
-      s = s + (j < len ? a : 0.0f);
+    float rem = (float)len;  // len - j
+    for (int j = 0; j < mx; j += 8) {  // (eight reads in flight; g is padded, and past the segment the mask is 0)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = g[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        s = __builtin_fmaf(fabsf(v[u]), clamp01(rem), s);
+        rem -= 1.0f;
+      }
     }
   }
   // digit segments in slot order; segment k covers [c_k, c_next) (c_next = 428 for the last)
@@ -103,20 +120,34 @@ __device__ float hseg_score_t(const float *__restrict__ g, float width, int off,
   for (int k = 0; k < nd; k++) {
     const int cn = k + 1 < nd ? c[k + 1] : 428;
     const int len = live ? cn - c[k] : 0;
+    const float lenf = (float)len;
     const float *gp = g + (live ? c[k] : 0);
     // the first 16 taps are inside every live lane's segment (digit spacing >= 16); the sum of a
     // lane that is not live is discarded below, so it needs no masking here
 #pragma unroll
     for (int j = 0; j < 16; j++) s = s + fabsf(gp[j] - HSEG_T(j));
-#pragma unroll
-    for (int j = 16; j < 19; j++) {
-      const float a = fabsf(gp[j] - HSEG_T(j));
-      s = s + (j < len ? a : 0.0f);
-    }
+    // clamp(len - 16), clamp(len - 17), clamp(len - 18): one v_add_f32 each (-1.0 and -2.0 are inline constants); written out
+    // because the compiler rewrites (float)len - (float)j as an integer subtraction and a half-rate conversion per term
+    float x16, m16, m17, m18;
+    asm("v_add_f32_e32 %0, 0xc1800000, %1" : "=v"(x16) : "v"(lenf));  // len - 16
+    asm("v_add_f32_e64 %0, %1, 0 clamp" : "=v"(m16) : "v"(x16));
+    asm("v_add_f32_e64 %0, %1, -1.0 clamp" : "=v"(m17) : "v"(x16));
+    asm("v_add_f32_e64 %0, %1, -2.0 clamp" : "=v"(m18) : "v"(x16));
+    s = __builtin_fmaf(fabsf(gp[16] - HSEG_T(16)), m16, s);
+    s = __builtin_fmaf(fabsf(gp[17] - HSEG_T(17)), m17, s);
+    s = __builtin_fmaf(fabsf(gp[18] - HSEG_T(18)), m18, s);
     const int mx = wave_max(len);
-    for (int j = 19; j < mx; j++) {
-      const float a = fabsf(gp[j] - 0.0f);
-      s = s + (j < len ? a : 0.0f);
+    float rem;
+    asm("v_add_f32_e32 %0, 0xc0400000, %1" : "=v"(rem) : "v"(x16));  // len - 19
+    for (int j = 19; j < mx; j += 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = gp[j + u];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        s = __builtin_fmaf(fabsf(v[u]), clamp01(rem), s);
+        rem -= 1.0f;
+      }
     }
   }
   return live ? s : FLT_MAX;

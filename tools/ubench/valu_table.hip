@@ -83,6 +83,12 @@ OP32(k_cvt_f16_u16, "v_cvt_f16_u16 %0, %0")
 OP32(k_sub_f32, "v_sub_f32 %0, %0, %1")
 OP32(k_min_f32, "v_min_f32 %0, %0, %1")
 OP32(k_mul_legacy, "v_mul_legacy_f32 %0, %0, %1")
+OP32(k_add_f32_clamp, "v_add_f32_e64 %0, %0, %1 clamp")
+OP32(k_add_f32_abs, "v_add_f32_e64 %0, %0, |%1|")
+OP32(k_fma_f32_abs, "v_fma_f32 %0, |%0|, %1, %2")
+OP32(k_add_f32_e64, "v_add_f32_e64 %0, %0, %1")
+OP32(k_mul_f32_lit, "v_mul_f32 %0, 0x3f8ccccd, %0")
+OP32(k_add_f32_sgpr, "v_add_f32 %0, s20, %0")
 OP32(k_readlane, "v_readlane_b32 s20, %0, 5")
 OP32(k_max_i32, "v_max_i32 %0, %0, %1")
 OP32(k_min_u32, "v_min_u32 %0, %0, %1")
@@ -171,7 +177,7 @@ static void run(const char *name, kern_t k, int per_asm) {
 #define RUN2(K) run(#K + 2, K, 2)
 
 int main() {
-  RUN(k_mov); RUN(k_add_u32); RUN(k_sub_u32); RUN(k_and); RUN(k_xor); RUN(k_lshl); RUN(k_ashr); RUN(k_lshr); RUN(k_lshr_v); RUN(k_ashr_v); RUN(k_lshl_v); RUN(k_or); RUN(k_not); RUN(k_subrev); RUN(k_xad); RUN(k_bcnt); RUN(k_mbcnt); RUN(k_bfrev); RUN(k_add_lit); RUN(k_and_lit); RUN(k_mul_u24_vop2); RUN(k_max_u16); RUN(k_add_u16); RUN(k_min_u16); RUN(k_max_i16); RUN(k_sub_u16); RUN(k_mul_lo_u16); RUN(k_lshl_b16); RUN(k_lshr_b16); RUN(k_mad_u16); RUN(k_cmp_u16); RUN(k_cmp_u16_e64); RUN(k_cmp_eq_u32); RUN(k_max3_u16); RUN(k_med3_u16); RUN(k_add_f16); RUN(k_max_f16); RUN(k_mul_f16); RUN(k_cvt_f16_u16); RUN(k_sub_f32); RUN(k_min_f32); RUN(k_mul_legacy); RUN(k_readlane); RUN(k_max_i32); RUN(k_min_u32);
+  RUN(k_mov); RUN(k_add_u32); RUN(k_sub_u32); RUN(k_and); RUN(k_xor); RUN(k_lshl); RUN(k_ashr); RUN(k_lshr); RUN(k_lshr_v); RUN(k_ashr_v); RUN(k_lshl_v); RUN(k_or); RUN(k_not); RUN(k_subrev); RUN(k_xad); RUN(k_bcnt); RUN(k_mbcnt); RUN(k_bfrev); RUN(k_add_lit); RUN(k_and_lit); RUN(k_mul_u24_vop2); RUN(k_max_u16); RUN(k_add_u16); RUN(k_min_u16); RUN(k_max_i16); RUN(k_sub_u16); RUN(k_mul_lo_u16); RUN(k_lshl_b16); RUN(k_lshr_b16); RUN(k_mad_u16); RUN(k_cmp_u16); RUN(k_cmp_u16_e64); RUN(k_cmp_eq_u32); RUN(k_max3_u16); RUN(k_med3_u16); RUN(k_add_f16); RUN(k_max_f16); RUN(k_mul_f16); RUN(k_cvt_f16_u16); RUN(k_sub_f32); RUN(k_min_f32); RUN(k_mul_legacy); RUN(k_add_f32_clamp); RUN(k_add_f32_abs); RUN(k_fma_f32_abs); RUN(k_add_f32_e64); RUN(k_mul_f32_lit); RUN(k_add_f32_sgpr); RUN(k_readlane); RUN(k_max_i32); RUN(k_min_u32);
   RUN(k_add3); RUN(k_lshl_add); RUN(k_lshl_or); RUN(k_and_or); RUN(k_bfe); RUN(k_bfi); RUN(k_cndmask); RUN(k_cmp_i32);
   RUN2(k_cmp_cnd); RUN(k_mul_i24); RUN(k_mad_i24); RUN(k_mad_u24); RUN(k_mul_lo); RUN(k_med3_i32); RUN(k_max3_i32);
   RUN(k_sad_u8); RUN(k_sad_u16); RUN(k_perm); RUN(k_alignbyte); RUN(k_dot4); RUN(k_dot2_u16); RUN(k_pk_add_u16);
