@@ -19,6 +19,10 @@
 
 #include "dmz_wave.h"
 
+#ifdef DMZ_XSEG_DBG  /* developer counters (tools/dev/xseg_dbg.py) */
+__device__ unsigned long long g_xs_dbg[16];
+#endif
+
 namespace dmzsort {
 
 template <int SH>
@@ -246,15 +250,19 @@ __device__ __forceinline__ bool wave_mark_partitions(unsigned *v, const int n, c
     if (depth == 0) return false;
     --depth;
     const int len = L - F;
-    int mL, mR, cut;
-#if defined(DMZ_SORT_ONE_FORM)  /* developer ablation: one instantiation (code size) */
-    cut = partition_range<7, SH, KMASK>(v, F, L, lane, T, mL, mR);
-#else
-    if (len <= 64) cut = partition_range<1, SH, KMASK>(v, F, L, lane, T, mL, mR);
-    else if (len <= 128) cut = partition_range<2, SH, KMASK>(v, F, L, lane, T, mL, mR);
-    else if (len <= 256) cut = partition_range<4, SH, KMASK>(v, F, L, lane, T, mL, mR);
-    else cut = partition_range<7, SH, KMASK>(v, F, L, lane, T, mL, mR);
+#ifdef DMZ_XSEG_DBG
+    if (lane == 0) atomicAdd(&g_xs_dbg[8], 1ull), atomicAdd(&g_xs_dbg[9], (unsigned long long)((len + 63) >> 6));
 #endif
+    int mL, mR, cut;
+    switch ((len + 63) >> 6) {  // straight-line code per range size: 64 positions per slot
+      case 1: cut = partition_range<1, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+      case 2: cut = partition_range<2, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+      case 3: cut = partition_range<3, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+      case 4: cut = partition_range<4, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+      case 5: cut = partition_range<5, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+      case 6: cut = partition_range<6, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+      default: cut = partition_range<7, SH, KMASK>(v, F, L, lane, T, mL, mR); break;
+    }
     const bool goL = cut - F > 16 && mL >= 2, goR = L - cut > 16 && mR >= 2;
     if (goL && goR) {
       if (lane == 0) stack[sp] = (unsigned)cut | ((unsigned)L << 10) | ((unsigned)depth << 20);

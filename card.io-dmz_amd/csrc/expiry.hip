@@ -239,9 +239,7 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
     if (lane == 0) sg->n = (int)(expr) & 0;    \
     return;                                    \
   }
-#ifdef DMZ_XSEG_DBG  /* developer timing of the pick (tools/dev/xseg_dbg.py): stripes, re-ordered stripes, cycles */
-__device__ unsigned long long g_xs_dbg[8];
-#endif
+// (developer timing of the pick, -DDMZ_XSEG_DBG: the counters g_xs_dbg[] live in dmz_stdsort.h; tools/dev/xseg_dbg.py)
 constexpr int IROWS = 23;    // inter rows: image rows base-4 .. base+18 (clamped to the ROI)
 constexpr int ISTRIDE = 428; // bytes per inter row (107 dwords)
 constexpr int XT_PITCH = 20; // bytes per row of a thresholded character tile (19 used)
@@ -515,12 +513,13 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   // repeat with the position after the library's partition phase as tie-break: the sequential greedy in the sorted order.
   unsigned key[7];
   unsigned picked = 0u;  // bit j: the rect at column 7 lane + j was picked
-  auto pick_rounds = [&](bool watch) -> bool {
+  unsigned tiemask = 0u;  // bit j: the pick at slot j had a live candidate of its own sum to its right (an OPEN tie)
+  auto pick_rounds = [&](bool watch, unsigned resolved) -> bool {
     // lane - 1 / lane + 1 of the wave (DPP wave_shr:1 / wave_shl:1), 0 at the ends
     auto below = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); };
     auto above = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); };
     auto umax = [](unsigned a, unsigned b) { return a > b ? a : b; };
-    bool tie = false;
+    tiemask = 0u;
     picked = 0u;
     for (;;) {
       unsigned alive = key[0];
@@ -548,7 +547,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
         now |= pick ? 1u << j : 0u;
         if (watch) {
           if (j < 6) right = umax(right, suf[j + 1]);
-          tie |= pick && ((right ^ key[j]) >> 9) == 0u;  // (a dead neighbour's key is 0: its sum field differs from a live one's)
+          // (a dead neighbour's key is 0: its sum field differs from a live one's; windows whose order among equal sums is
+          // already the library's -- `resolved` -- are settled)
+          tiemask |= (pick && ((right ^ key[j]) >> 9) == 0u && !((resolved >> j) & 1u)) ? 1u << j : 0u;
         }
       }
       picked |= now;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 #pragma unroll
       for (int j = 0; j < 7; j++) key[j] = ((near >> j) & 0x1FFFFu) ? 0u : key[j];
     }
-    return __builtin_amdgcn_ballot_w64(tie) != 0ull;
+    return __builtin_amdgcn_ballot_w64(tiemask != 0u) != 0ull;
   };
 #pragma unroll
   for (int j = 0; j < 7; j++) {
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   }
 #ifdef DMZ_XSEG_DBG
   const long long dbg_t0 = __builtin_readcyclecounter();
-  const bool dbg_tie = pick_rounds(true);
+  const bool dbg_tie = pick_rounds(true, 0u);
   const long long dbg_t1 = __builtin_readcyclecounter();
   if (lane == 0) {
     atomicAdd(&g_xs_dbg[0], 1ull);
@@ -577,34 +578,38 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   }
   if (dbg_tie) {
 #else
-  if (pick_rounds(DMZ_XSEG_TIES >= 1) && DMZ_XSEG_TIES >= 2 && (DMZ_XSEG_TIES != 3 || n == -12345)) {  // (3: the code is there, never run)
+  if (pick_rounds(DMZ_XSEG_TIES >= 1, 0u) && DMZ_XSEG_TIES >= 2 && (DMZ_XSEG_TIES != 3 || n == -12345)) {  // (3: the code is there, never run)
 #endif
-    // Whose order can matter: candidates with an equal sum within eight columns (only such a pair can ever be a pick and
-    // its live neighbour, in this run or in the repeated one).  Bit j of `mark`: the window at column 7 lane + j.
-    unsigned mark = 0u;
-    {
+    // An open tie: the order of equal sums matters.  It is settled LEVEL BY LEVEL from the top: the greedy walks the sums in
+    // descending order, so everything above the highest open tie is already what the reference picks; the windows of that
+    // sum are MARKED, the library's order is computed for the marked windows (dmz_stdsort.h follows only the ranges that hold
+    // two of them), and the rounds repeat with it as their tie-break -- still watching: an open tie further down (one run in five)
+    // adds its level to the marks.  After three levels whatever could ever tie is marked at once: candidates with an
+    // equal-sum candidate within eight columns (only such a pair can be a pick and its live neighbour).
+    unsigned cs[7];  // candidate sums (0: not a candidate; a candidate's sum is >= 1)
+#pragma unroll
+    for (int j = 0; j < 7; j++) cs[j] = (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2) ? (unsigned)rs7[j] : 0u;
+    auto near_tie_marks = [&]() -> unsigned {
       auto below = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); };
       auto above = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); };
-      unsigned cs[7], nx[7];  // candidate sums (0: not a candidate; a candidate's sum is >= 1), the next lane's
+      unsigned m = 0u, nx[7];
 #pragma unroll
-      for (int j = 0; j < 7; j++) cs[j] = (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2) ? (unsigned)rs7[j] : 0u;
-#pragma unroll
-      for (int j = 0; j < 7; j++) nx[j] = above(cs[j]);
-      const unsigned nx2 = above(nx[0]);  // column 7 (lane + 2)
-      unsigned fwd1 = 0u, fwd2 = 0u;      // partners found in the next lane's slots / in slot 0 of the lane after it
+      for (int j = 0; j < 7; j++) nx[j] = above(cs[j]);  // the next lane's
+      const unsigned nx2 = above(nx[0]);                  // column 7 (lane + 2)
+      unsigned fwd1 = 0u, fwd2 = 0u;                      // partners found in the next lane's slots / in slot 0 of the lane after it
 #pragma unroll
       for (int j = 0; j < 7; j++) {
         if (cs[j] == 0u) continue;
 #pragma unroll
         for (int k = j + 1; k < 7; k++)  // columns c + 1 .. within the own lane
-          if (cs[k] == cs[j]) mark |= (1u << j) | (1u << k);
+          if (cs[k] == cs[j]) m |= (1u << j) | (1u << k);
 #pragma unroll
         for (int k = 0; k <= (j < 6 ? j + 1 : 6); k++)  // columns 7 (lane + 1) + k <= c + 8
-          if (nx[k] == cs[j]) mark |= 1u << j, fwd1 |= 1u << k;
-        if (j == 6 && nx2 == cs[j]) mark |= 1u << j, fwd2 = 1u;
+          if (nx[k] == cs[j]) m |= 1u << j, fwd1 |= 1u << k;
+        if (j == 6 && nx2 == cs[j]) m |= 1u << j, fwd2 = 1u;
       }
-      mark |= below(fwd1) | below(below(fwd2));
-    }
+      return m | below(fwd1) | below(below(fwd2));
+    };
     // rect_list: the windows above the first threshold in column order (expiry_seg.cpp:461-470); std::sort (:496).
     // The partition phase needs a table of 210 dwords beside the list: the first 210 column sums of colB (kept for
     // regrid_group) wait in registers meanwhile.
@@ -613,6 +618,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     int keep[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) keep[i] = lane + 64 * i < dmzsort::TPAIRS ? L.colB[lane + 64 * i] : 0;
+    unsigned mark = 0u;
     auto fill_list = [&](bool marks) {
       unsigned pos = 0u;
 #pragma unroll
@@ -626,42 +632,51 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           sv[pos++] = ((unsigned)rs7[j] << 9) | (unsigned)(7 * lane + j) | ((marks && ((mark >> j) & 1u)) ? dmzsort::MARK : 0u);
       __syncthreads();
     };
-    fill_list(true);
-    if (!dmzsort::wave_mark_partitions<9, 0xFFFFFu>(sv, cnt, lane, tb, L.u.s.stack)) {
-      // the depth limit of the introsort loop (adversarial lists only): the library's whole sort on one lane, every
-      // window then carries its final position
-      __syncthreads();
-      fill_list(false);
-      if (lane == 0) dmzsort::serial_sort<9>(sv, cnt, L.u.s.stack);
-      mark = 0x7Fu;
-    }
-    __syncthreads();
-    unsigned short *const sq = (unsigned short *)tb;  // position of a column's window in that order (marked windows)
-    for (int p = lane; p < cnt; p += 64) {
-      const unsigned el = sv[p];
-      sq[el & 511u] = (unsigned short)p;
-    }
-    __syncthreads();
+    for (int level = 0;; level++) {
+      bool last = level >= 3;
+      if (!last) {
+        unsigned lv = 0u;  // the highest sum with an open tie
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-      key[j] = 0u;
-      if (lane < 60 && (float)rs7[j] > thr1 && (float)rs7[j] > thr2)
-        key[j] = ((unsigned)rs7[j] << 9) | (511u - (((mark >> j) & 1u) ? (unsigned)sq[7 * lane + j] : (unsigned)(7 * lane + j)));
+        for (int j = 0; j < 7; j++) lv = ((tiemask >> j) & 1u) && cs[j] > lv ? cs[j] : lv;
+        lv = wave_max_u32(lv);
+#pragma unroll
+        for (int j = 0; j < 7; j++) mark |= (cs[j] == lv) ? 1u << j : 0u;
+      } else {
+        mark |= near_tie_marks();
+      }
+      fill_list(true);
+      if (!dmzsort::wave_mark_partitions<9, 0xFFFFFu>(sv, cnt, lane, tb, L.u.s.stack)) {
+        // the depth limit of the introsort loop (adversarial lists only): the library's whole sort on one lane, every
+        // window then carries its final position
+        __syncthreads();
+        fill_list(false);
+        if (lane == 0) dmzsort::serial_sort<9>(sv, cnt, L.u.s.stack);
+        mark = 0x7Fu;
+        last = true;
+      }
+      __syncthreads();
+      unsigned short *const sq = (unsigned short *)tb;  // position of a column's window in that order (marked windows)
+      for (int p = lane; p < cnt; p += 64) {
+        const unsigned el = sv[p];
+        sq[el & 511u] = (unsigned short)p;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        key[j] = cs[j] ? (cs[j] << 9) | (511u - (((mark >> j) & 1u) ? (unsigned)sq[7 * lane + j] : (unsigned)(7 * lane + j))) : 0u;
+      __syncthreads();
+      if (!pick_rounds(!last, mark) || last) {
+#ifdef DMZ_XSEG_DBG
+        if (lane == 0) atomicAdd(&g_xs_dbg[4], (unsigned long long)(level + 1)), atomicAdd(&g_xs_dbg[7], last ? 1ull : 0ull);
+#endif
+        break;
+      }
     }
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (lane + 64 * i < dmzsort::TPAIRS) L.colB[lane + 64 * i] = keep[i];
 #ifdef DMZ_XSEG_DBG
-    const long long dbg_t2 = __builtin_readcyclecounter();
-#endif
-    pick_rounds(false);
-#ifdef DMZ_XSEG_DBG
-    const long long dbg_t3 = __builtin_readcyclecounter();
-    if (lane == 0) {
-      atomicAdd(&g_xs_dbg[3], (unsigned long long)(dbg_t2 - dbg_t1));
-      atomicAdd(&g_xs_dbg[4], (unsigned long long)(dbg_t3 - dbg_t2));
-    }
+    if (lane == 0) atomicAdd(&g_xs_dbg[3], (unsigned long long)(__builtin_readcyclecounter() - dbg_t1));
 #endif
   }
   XSEG_STOP(4, picked)
@@ -1899,9 +1914,9 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
 #ifdef DMZ_XSEG_DBG
 extern "C" void dmz_dbg_xseg(unsigned long long *out, int reset) {
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xs_dbg), sizeof(unsigned long long) * 8);
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xs_dbg), sizeof(unsigned long long) * 16);
   if (reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_xs_dbg), z, sizeof(z));
   }
 }
