@@ -1684,6 +1684,7 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
     }
   }
   if (!(flags & DMZ_HIP_FLAG_USABLE)) return;  // scan.cpp:57-59
+  if (DMZ_XCAT_STOP == 0) return;  // (developer ablation: the cost of the workgroups that have nothing to categorise)
 #ifdef DMZ_XC_TIMING
   if (tid == 0 && f > n / 2 && S.n_groups > 0) atomicCAS(&g_xc_block, -1, f);
   __syncthreads();
