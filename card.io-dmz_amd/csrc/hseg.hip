@@ -19,6 +19,13 @@
 //     [c_k, c_{k+1}) in order (the same column order as 0..427), so the template tap index
 //     j is wave-uniform (template values are instruction literals) and only the LDS
 //     address differs per lane; lanes whose segment is shorter add +0.0f.
+//   * round 4: the search is FILTERED.  A candidate's score is sum_c |g_c| + sum_digits W_L[c_k] with
+//     W_L[c] = sum_{j<L} (|g_{c+j} - T_j| - |g_{c+j}|) (L = the digit's segment length, 16..19): one table of 428 x 4 floats
+//     per card turns a candidate into sixteen LDS reads and additions instead of 428 ordered terms.  That value is within a
+//     proven distance of the reference's ordered float sum (hseg_filter_eps below), so whenever the best candidate leads every
+//     candidate with OTHER digit positions by more than that distance the pass is decided without any ordered sum; otherwise
+//     (measured: < 1 % of the passes) the pass runs in its ordered form.  The winner's ordered sum is evaluated once at the end:
+//     hseg.score keeps the reference's bits.
 #include <float.h>
 
 #include "dmz_hip_internal.h"
@@ -157,15 +164,32 @@ __device__ __forceinline__ float hseg_score(const float *__restrict__ g, int pt,
   return pt == 2 ? hseg_score_t<2>(g, width, off, has) : hseg_score_t<1>(g, width, off, has);
 }
 
+// developer counters (-DDMZ_HSEG_DBG; tools/dev/hseg_dbg.py): passes, passes that ran in the ordered form
+#ifdef DMZ_HSEG_DBG
+__device__ unsigned long long g_hs_dbg[4];
+#endif
+
+// developer probe (-DDMZ_HSEG_TIMING): the phase timeline of one wave
+#ifdef DMZ_HSEG_TIMING
+#define HS_T(i) if (blockIdx.x == gridDim.x / 2) hs_t[i] = (long long)__builtin_readcyclecounter();
+#else
+#define HS_T(i)
+#endif
+
 struct HsegBest {
-  float score;
+  float score;     // the reference's ordered float sum of the incumbent -- valid when `exact`
   float width;
   int offset;
+  // filtered search: the incumbent's table score and digit-position signature
+  float approx;
+  int sig_off;     // -1 = the initial incumbent (score 428, no positions)
+  unsigned sig_a, sig_b;
+  bool exact, improved;
 };
 
-// one pass of best_n_hseg_constrained; every lane carries an identical copy of `best`
-__device__ void hseg_pass(const float *__restrict__ g, int pt, float wmin, float wmax, float wstep,
-                          int omin, int omax, int ostep, HsegBest &best, int lane) {
+// one pass of best_n_hseg_constrained in its ordered form; every lane carries an identical copy of `best`
+__device__ __forceinline__ HsegBest hseg_pass(const float *__restrict__ g, int pt, float wmin, float wmax, float wstep,
+                                           int omin, int omax, int ostep, HsegBest best, int lane) {
   const int plen = pattern_len(pt);
   int total = 0;
   for (float width = wmin; width < wmax; width += wstep)
@@ -196,14 +220,192 @@ __device__ void hseg_pass(const float *__restrict__ g, int pt, float wmin, float
       best.score = smin;
       best.width = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), wl));
       best.offset = __builtin_amdgcn_readlane(my_off, wl);
+      best.improved = true;
     }
+  }
+  return best;
+}
+
+// ---- the filtered search ---------------------------------------------------------------------------------------------------
+// Notation: a_c = |g_c|, b_{c,j} = fl(|g_{c+j} - T_j|) (the reference's float term), S* = the REAL sum of a candidate's 428 float
+// terms, S_ref = the reference's ordered float sum of them, S^ = the table score below.  u = 2^-24.
+//   |S_ref - S*| <= gamma S*, gamma = 429 u (427 additions of non-negative terms: (1 + u)^427 - 1 < 428.01 u).
+//   |S^ - S*|   <= delta = u (4500 + 30 G):  a table entry is the float sum of <= 19 differences fl(b - a), each within u |b - a|
+//                  and |b - a| <= T_j, so an entry is within 20 u sum(T) < 151 u of its real value; G = sum a_c by seven additions per
+//                  lane and a six-level tree is within 13 u G; the sixteen additions G + W + W + ... have partial sums below
+//                  G + 16 sum(T) < G + 121: 16 u (G + 121).  Together u (16 x 151 + 13 G + 16 G + 1936) < u (4500 + 30 G).
+// Candidate i cannot beat candidate j in the reference (S_ref,i > S_ref,j) when S*_i (1 - gamma) > S*_j (1 + gamma), which
+// holds when  S^_i > S^_j + 2 delta + 2.1 gamma (S^_j + delta).  With j = the smallest table score of the pass (the incumbent
+// included) every candidate above that threshold is out; if the ones below it all have the same digit positions they have the
+// same terms, hence the same S_ref, and the reference keeps the earliest of them (the incumbent first: strict <).  Otherwise the
+// pass is repeated in the ordered form.
+struct HsegFilter {
+  float G;       // sum of |g_c|
+  float e1, e2;  // threshold = m + e1 + e2 m
+};
+
+template <int PT>
+__device__ __forceinline__ float hseg_table_score_t(const float *__restrict__ W, float G, float width, int off, bool has,
+                                                    unsigned &sig_a, unsigned &sig_b) {
+  constexpr int plen = PT == 1 ? 19 : 17;
+  constexpr unsigned mask = PT == 1 ? 0x7BDEFu : 0x1F7EFu;
+  constexpr int nd = PT == 1 ? 16 : 15;
+  int c[nd];
+  int dpi[nd];  // pattern slots between digit k and digit k + 1 (compile-time)
+  {
+    int k = 0, last = 0;
+#pragma unroll
+    for (int pi = 0; pi < plen; pi++)
+      if ((mask >> pi) & 1u) {
+        c[k] = slot_center(off, pi, width);
+        if (k > 0) dpi[k - 1] = pi - last;
+        last = pi;
+        k++;
+      }
+    dpi[nd - 1] = 1;
+  }
+  bool live = has;
+#pragma unroll
+  for (int k = 0; k < nd; k++)
+    if (!(c[k] + 19 < 428)) live = false;
+  float s = G;
+  unsigned long long sig = 0ull;
+#pragma unroll
+  for (int k = 0; k < nd; k++) {
+    const int sp = k + 1 < nd ? c[k + 1] - c[k] : 19;
+    // the signature holds the spacing in four bits (16 .. 31 between neighbours, 32 .. 47 across a gap); anything else
+    // (never with the widths of the four passes) makes the candidate unfit for the filter
+    const int d = sp - 16 * dpi[k];
+    if (d < 0 || d > 15 || sp < 16) live = false;
+    if (k + 1 < nd) sig |= (unsigned long long)(unsigned)(d & 15) << (4 * k);
+    const int L = imin(sp, 19) - 16;
+    s = s + W[(live ? c[k] : 0) * 4 + (live ? L : 0)];
+  }
+  sig_a = (unsigned)sig;
+  sig_b = (unsigned)(sig >> 32);
+  return live ? s : __builtin_inff();
+}
+__device__ __forceinline__ float hseg_table_score(const float *__restrict__ W, float G, int pt, float width, int off, bool has,
+                                                  unsigned &sig_a, unsigned &sig_b) {
+  return pt == 2 ? hseg_table_score_t<2>(W, G, width, off, has, sig_a, sig_b)
+                 : hseg_table_score_t<1>(W, G, width, off, has, sig_a, sig_b);
+}
+
+// the incumbent's ordered sum, where a pass needs it (one lane's worth of work)
+__device__ __noinline__ float hseg_ordered_score(const float *__restrict__ g, int pt, float width, int offset, int lane) {
+  const float sc = hseg_score(g, pt, width, offset, lane == 0);
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc)));
+}
+__device__ __forceinline__ void hseg_make_exact(const float *__restrict__ g, int pt, HsegBest &best, int lane) {
+  if (best.exact) return;
+  best.score = hseg_ordered_score(g, pt, best.width, best.offset, lane);
+  best.exact = true;
+}
+
+// one pass of best_n_hseg_constrained, filtered
+__device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, const float *__restrict__ W, const HsegFilter &flt, int pt,
+                                   float wmin, float wmax, float wstep, int omin, int omax, int ostep, HsegBest &best,
+                                   int lane) {
+  const int plen = pattern_len(pt);
+  int total = 0;
+  for (float width = wmin; width < wmax; width += wstep)
+    total += offsets_for_width(plen, width, omin, omax, ostep);
+  if (total == 0) return;
+  bool decided = false;
+  if (total <= 128) {
+    float sc[2], cw[2];
+    int co[2];
+    unsigned sa[2], sb[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int my = 64 * j + lane;
+      float my_w = 0.0f;
+      int my_off = 0, idx = 0;
+      bool has = false;
+      if (64 * j < total)
+        for (float width = wmin; width < wmax; width += wstep) {
+          const int cnt = offsets_for_width(plen, width, omin, omax, ostep);
+          if (!has && my >= idx && my < idx + cnt) {
+            has = true;
+            my_w = width;
+            my_off = omin + (my - idx) * ostep;
+          }
+          idx += cnt;
+        }
+      cw[j] = my_w;
+      co[j] = my_off;
+      sa[j] = sb[j] = 0u;
+      sc[j] = __builtin_inff();
+      if (64 * j < total) sc[j] = hseg_table_score(W, flt.G, pt, my_w, my_off, has, sa[j], sb[j]);
+    }
+    // (non-negative floats and +inf order like their bit patterns)
+    const unsigned mine = __float_as_uint(sc[0] < sc[1] ? sc[0] : sc[1]);
+    unsigned mu = dmzwave::min_u32(mine);
+    const unsigned inc = __float_as_uint(best.approx);
+    if (inc < mu) mu = inc;
+    const float m = __uint_as_float(mu);
+    const float thr = (m + (flt.e1 + flt.e2 * m)) * 1.000001f;
+    if (m < 3.0e38f) {
+      const bool n0 = sc[0] <= thr, n1 = sc[1] <= thr, ninc = best.approx <= thr;
+      const unsigned long long b0 = __builtin_amdgcn_ballot_w64(n0), b1 = __builtin_amdgcn_ballot_w64(n1);
+      // the earliest of them: the incumbent, else the first candidate in iteration order
+      int r_off = best.sig_off;
+      unsigned r_a = best.sig_a, r_b = best.sig_b;
+      float r_w = best.width, r_s = best.approx;
+      if (!ninc) {
+        const int j = b0 ? 0 : 1;
+        const int wl = b0 ? (int)__builtin_ctzll(b0) : (int)__builtin_ctzll(b1);
+        r_off = __builtin_amdgcn_readlane(j ? co[1] : co[0], wl);
+        r_a = (unsigned)__builtin_amdgcn_readlane((int)(j ? sa[1] : sa[0]), wl);
+        r_b = (unsigned)__builtin_amdgcn_readlane((int)(j ? sb[1] : sb[0]), wl);
+        r_w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j ? cw[1] : cw[0]), wl));
+        r_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j ? sc[1] : sc[0]), wl));
+      }
+      const bool other = (n0 && (co[0] != r_off || sa[0] != r_a || sb[0] != r_b)) ||
+                         (n1 && (co[1] != r_off || sa[1] != r_a || sb[1] != r_b));
+      if (__builtin_amdgcn_ballot_w64(other) == 0ull) {
+        decided = true;
+        if (!ninc) {
+          best.width = r_w;
+          best.offset = r_off;
+          best.approx = r_s;
+          best.sig_off = r_off;
+          best.sig_a = r_a;
+          best.sig_b = r_b;
+          best.exact = false;
+          best.improved = true;
+        }
+      }
+    } else {
+      decided = true;  // no candidate in bounds and the incumbent is the initial one: nothing changes
+    }
+  }
+#ifdef DMZ_HSEG_DBG
+  if (lane == 0) atomicAdd(&g_hs_dbg[0], 1ull), atomicAdd(&g_hs_dbg[1], decided ? 0ull : 1ull);
+#endif
+  if (decided) return;
+  // the ordered form of the pass
+  hseg_make_exact(g, pt, best, lane);
+  const float before_w = best.width;
+  const int before_o = best.offset;
+  const float before_s = best.score;
+  best = hseg_pass(g, pt, wmin, wmax, wstep, omin, omax, ostep, best, lane);
+  if (best.score != before_s || best.width != before_w || best.offset != before_o) {
+    unsigned a, b;
+    const float t = hseg_table_score(W, flt.G, pt, best.width, best.offset, true, a, b);
+    best.approx = t;  // (+inf for positions the filter does not take: every later pass is then ordered as well)
+    best.sig_off = best.offset;
+    best.sig_a = a;
+    best.sig_b = b;
   }
 }
 
 __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, size_t card_stride,
                                               int n, dmz_hip_frame_result *__restrict__ results) {
   __shared__ float g[428 + 64];
-  __shared__ int colsum[428];
+  // the filter's table W[c][L - 16]; its first 428 words hold the integer column sums until g is built
+  __shared__ __attribute__((aligned(16))) float W[428 * 4];
+  int *colsum = (int *)W;
 
   const int f = blockIdx.x;
   if (f >= n) return;
@@ -214,18 +416,36 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
   const int pt = res->pattern_type;
   const uint32_t *strip = (const uint32_t *)(cards + (size_t)f * card_stride + (size_t)y_off * DMZ_CARD_WIDTH);
 
+#ifdef DMZ_HSEG_TIMING
+  long long hs_t[12];
+#endif
+  HS_T(0)
   // ---- cross gradient clamped at the strip (ROI) edge + column sums (n_hseg.cpp:90-95) ----
+  // A lane owns dword q of every row (columns 4q .. 4q+3); its two neighbour bytes come from the neighbour lanes (DPP wave shifts)
+  // and, at the ends of the 64-lane pass, from a wave-uniform load of the dword next to the pass.  All 27 + 27 loads of a pass are
+  // issued before the first row is used: one memory latency per pass (the row-by-row form waited ~1.7 k cycles for each of the
+  // 2 x 27 rows: 90 k of a wave's 140 k cycles, -DDMZ_HSEG_TIMING).
   int lmin = 1 << 30, lmax = -1;
-  for (int q = lane; q < 107; q += 64) {  // dword q = columns 4q .. 4q+3
-    int sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0;
-    uint32_t up, mid, dn, lw, rw;
-    mid = strip[q];
-    up = mid;  // row -1 replicates row 0
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int q = 64 * pass + lane;
+    const bool on = q < 107;
+    uint32_t col[27], edge[27];
+#pragma unroll
     for (int r = 0; r < 27; r++) {
-      const uint32_t *row = strip + r * 107;
-      dn = r < 26 ? row[107 + q] : mid;  // row 27 replicates row 26
-      lw = q > 0 ? row[q - 1] : 0u;
-      rw = q < 106 ? row[q + 1] : 0u;
+      col[r] = strip[r * 107 + (on ? q : 106)];
+      edge[r] = strip[r * 107 + (pass == 0 ? 64 : 63)];  // wave-uniform: dword 64 right of pass 0, dword 63 left of pass 1
+    }
+    int sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0;
+    uint32_t up = col[0], mid = col[0];  // row -1 replicates row 0
+#pragma unroll
+    for (int r = 0; r < 27; r++) {
+      uint32_t dn = col[r < 26 ? r + 1 : 26];  // row 27 replicates row 26
+      // lane - 1's dword into this lane, lane + 1's dword into this lane (wave_shr:1 / wave_shl:1)
+      uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid, 0x138, 0xf, 0xf, false);
+      uint32_t rw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid, 0x130, 0xf, 0xf, false);
+      if (pass == 0 && lane == 63) rw = edge[r];
+      if (pass == 1 && lane == 0) lw = edge[r];
       const int c0 = mid & 255, c1 = (mid >> 8) & 255, c2 = (mid >> 16) & 255, c3 = mid >> 24;
       const int wl = q > 0 ? (int)(lw >> 24) : c0;          // column -1 replicates column 0
       const int er = q < 106 ? (int)(rw & 255) : c3;        // column 428 replicates column 427
@@ -235,12 +455,16 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
       sum1 += max5(n1, c0, c1, c2, s1) - min5(n1, c0, c1, c2, s1);
       sum2 += max5(n2, c1, c2, c3, s2) - min5(n2, c1, c2, c3, s2);
       sum3 += max5(n3, c2, c3, er, s3) - min5(n3, c2, c3, er, s3);
+      // row by row: left alone the compiler first moves the neighbour dwords of all 27 rows (199 registers)
+      asm volatile("" : "+v"(sum0), "+v"(sum1), "+v"(sum2), "+v"(sum3), "+v"(dn));
       up = mid;
       mid = dn;
     }
-    colsum[4 * q + 0] = sum0; colsum[4 * q + 1] = sum1; colsum[4 * q + 2] = sum2; colsum[4 * q + 3] = sum3;
-    lmin = imin(lmin, imin(imin(sum0, sum1), imin(sum2, sum3)));
-    lmax = imax(lmax, imax(imax(sum0, sum1), imax(sum2, sum3)));
+    if (on) {
+      *(int4 *)(colsum + 4 * q) = make_int4(sum0, sum1, sum2, sum3);
+      lmin = imin(lmin, imin(imin(sum0, sum1), imin(sum2, sum3)));
+      lmax = imax(lmax, imax(imax(sum0, sum1), imax(sum2, sum3)));
+    }
   }
   lmin = (int)dmzwave::min_u32((unsigned)lmin);  // column sums are >= 0; idle lanes hold 2^30 / -1 -> 0
   lmax = (int)dmzwave::max_u32((unsigned)imax(lmax, 0));
@@ -255,23 +479,69 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
   }
   __syncthreads();
 
+  HS_T(1)
+  // ---- the filter's table and constants ----
+  HsegFilter flt;
+  {
+    float ga = 0.0f;
+    for (int c = lane; c < 428; c += 64) ga = ga + fabsf(g[c]);
+    // wave sum (any order: inside delta)
+    ga += __int_as_float(DMZ_DPP_SHR0(__float_as_int(ga), 1));
+    ga += __int_as_float(DMZ_DPP_SHR0(__float_as_int(ga), 2));
+    ga += __int_as_float(DMZ_DPP_SHR0(__float_as_int(ga), 4));
+    ga += __int_as_float(DMZ_DPP_SHR0(__float_as_int(ga), 8));
+    flt.G = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ga), 15)) +
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ga), 31))) +
+            (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ga), 47)) +
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ga), 63)));
+    const float u = 5.9604645e-8f;  // 2^-24
+    const float delta = u * (4500.0f + 30.0f * flt.G) * 1.001f;
+    const float gam2 = 2.1f * 429.0f * u;
+    flt.e1 = 2.0f * delta + gam2 * delta;
+    flt.e2 = gam2;
+  }
+  __syncthreads();  // (colsum is dead: W takes its place)
+  for (int c = lane; c < 428; c += 64) {
+    float acc = 0.0f, w16 = 0.0f, w17 = 0.0f, w18 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 19; j++) {
+      const float gv = g[c + j];
+      acc = acc + (fabsf(gv - HSEG_T(j)) - fabsf(gv));
+      if (j == 15) w16 = acc;
+      if (j == 16) w17 = acc;
+      if (j == 17) w18 = acc;
+    }
+    *(float4 *)(W + 4 * c) = make_float4(w16, w17, w18, acc);
+  }
+  __syncthreads();
+
+  HS_T(2)
   HsegBest best;
   best.score = 428.0f;
   best.width = 0.0f;
   best.offset = 0;
-  hseg_pass(g, pt, 17.1f, 19.7f, 0.5f, 0, 0xFFFF, 10, best, lane);
-  {
+  best.approx = 428.0f;
+  best.sig_off = -1;
+  best.sig_a = best.sig_b = 0u;
+  best.exact = true;
+  best.improved = false;
+  for (int pass = 0; pass < 4; pass++) {  // n_hseg.cpp:106-139
     const int po = best.offset;
-    hseg_pass(g, pt, best.width - 0.5f, best.width + 0.5f, 0.2f, po < 10 ? 0 : po - 10, po + 10, 1, best, lane);
+    const float hw = pass == 1 ? 0.5f : (pass == 2 ? 0.2f : 0.1f);
+    const int r = pass == 1 ? 10 : 3;
+    const float wmin = pass == 0 ? 17.1f : best.width - hw, wmax = pass == 0 ? 19.7f : best.width + hw;
+    const float wstep = pass == 0 ? 0.5f : (pass == 1 ? 0.2f : (pass == 2 ? 0.1f : 0.05f));
+    const int omin = pass == 0 ? 0 : (po < r ? 0 : po - r), omax = pass == 0 ? 0xFFFF : po + r;
+    hseg_pass_filtered(g, W, flt, pt, wmin, wmax, wstep, omin, omax, pass == 0 ? 10 : 1, best, lane);
+    HS_T(3 + pass)
   }
-  {
-    const int po = best.offset;
-    hseg_pass(g, pt, best.width - 0.2f, best.width + 0.2f, 0.1f, po < 3 ? 0 : po - 3, po + 3, 1, best, lane);
-  }
-  {
-    const int po = best.offset;
-    hseg_pass(g, pt, best.width - 0.1f, best.width + 0.1f, 0.05f, po < 3 ? 0 : po - 3, po + 3, 1, best, lane);
-  }
+  hseg_make_exact(g, pt, best, lane);
+  HS_T(7)
+#ifdef DMZ_HSEG_TIMING
+  if (lane == 0 && blockIdx.x == gridDim.x / 2)
+    printf("hseg wave: gradient %lld  table %lld  passes %lld %lld %lld %lld  ordered score %lld\n", hs_t[1] - hs_t[0],
+           hs_t[2] - hs_t[1], hs_t[3] - hs_t[2], hs_t[4] - hs_t[3], hs_t[5] - hs_t[4], hs_t[6] - hs_t[5], hs_t[7] - hs_t[6]);
+#endif
   if (lane == 0) {
     res->n_offsets = number_len(pt);
     res->hseg_score = best.score;
@@ -282,7 +552,7 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
     // offsets of the winner (n_hseg.cpp:60,68,75); unused slots are 0.  A search that never
     // improved on the initial 428 keeps the zero offsets of n_hseg.cpp:104.
     int value = 0;
-    if (best.score < 428.0f) {
+    if (best.improved) {
       const unsigned mask = pattern_mask(pt);
       int k = 0;
       for (int pi = 0; pi < pattern_len(pt); pi++) {
@@ -296,6 +566,17 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
 }
 
 }  // namespace
+
+#ifdef DMZ_HSEG_DBG
+extern "C" void dmz_dbg_hseg(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hs_dbg), sizeof(unsigned long long) * 4);
+  if (reset) {
+    unsigned long long z[4] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_hs_dbg), z, sizeof(z));
+  }
+}
+#endif
 
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results) {
