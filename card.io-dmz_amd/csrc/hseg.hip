@@ -291,6 +291,60 @@ __device__ __forceinline__ float hseg_table_score(const float *__restrict__ W, f
                  : hseg_table_score_t<1>(W, G, width, off, has, sig_a, sig_b);
 }
 
+// The winner's ordered sum at the end of the search, when the table is no longer needed: the 428 terms in parallel (the pattern is
+// pasted into LDS digit by digit in slot order, a later digit over an earlier one's tail: the memcpy of n_hseg.cpp:62-63), then
+// one chain of 428 additions over them -- four terms per LDS read, every lane the same chain (~600 instructions where the
+// lane-per-candidate form spends ~1 400 on its one live lane).
+__device__ const float k_hseg_template[19] = {0.26228655f, 0.30289554f, 0.34632607f, 0.38725636f, 0.42745813f, 0.45875135f,
+                                              0.46498017f, 0.45258447f, 0.43045216f, 0.42430462f, 0.44796554f, 0.47726529f,
+                                              0.48471646f, 0.46457738f, 0.42799847f, 0.38851183f, 0.33966308f, 0.28802608f,
+                                              0.25377602f};
+template <int PT>
+__device__ __forceinline__ float hseg_ordered_chain_t(const float *__restrict__ g, float *__restrict__ pat /* 448 floats */,
+                                                      float width, int off, int lane) {
+  constexpr int plen = PT == 1 ? 19 : 17;
+  constexpr unsigned mask = PT == 1 ? 0x7BDEFu : 0x1F7EFu;
+  const float tl = k_hseg_template[lane < 19 ? lane : 18];
+#pragma unroll
+  for (int i = 0; i < 7; i++) pat[lane + 64 * i] = 0.0f;
+#pragma unroll
+  for (int pi = 0; pi < plen; pi++)
+    if ((mask >> pi) & 1u) {
+      const int c = slot_center(off, pi, width);  // (in bounds: the winner passed the test of n_hseg.cpp:61)
+      if (lane < 19) pat[c + lane] = tl;
+    }
+  __syncthreads();  // (one wave, but lanes read what other lanes wrote: without it the compiler forwards a lane's own zero)
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    const int c = lane + 64 * i;  // (g is padded with zeros behind column 427)
+    pat[c] = g[c] - pat[c];
+  }
+  __syncthreads();
+  float s = 0.0f;  // (0 + |t_0| = |t_0|: the reference starts from the first term)
+  const float4 *p4 = (const float4 *)pat;
+  for (int q = 0; q < 104; q += 4) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) t[u] = p4[q + u];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      s = s + fabsf(t[u].x);
+      s = s + fabsf(t[u].y);
+      s = s + fabsf(t[u].z);
+      s = s + fabsf(t[u].w);
+    }
+  }
+#pragma unroll
+  for (int q = 104; q < 107; q++) {
+    const float4 t = p4[q];
+    s = s + fabsf(t.x);
+    s = s + fabsf(t.y);
+    s = s + fabsf(t.z);
+    s = s + fabsf(t.w);
+  }
+  return s;
+}
+
 // the incumbent's ordered sum, where a pass needs it (one lane's worth of work)
 __device__ __noinline__ float hseg_ordered_score(const float *__restrict__ g, int pt, float width, int offset, int lane) {
   const float sc = hseg_score(g, pt, width, offset, lane == 0);
@@ -307,12 +361,35 @@ __device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, 
                                    float wmin, float wmax, float wstep, int omin, int omax, int ostep, HsegBest &best,
                                    int lane) {
   const int plen = pattern_len(pt);
+  // the widths of the pass and their offset counts, once (wave-uniform; the float loop increments of n_hseg.cpp:45).  The
+  // four passes have at most six widths; a seventh or more sends the pass to the ordered form.
+  constexpr int kMaxW = 7;
+  float wv[kMaxW];
+  int cn[kMaxW];
   int total = 0;
-  for (float width = wmin; width < wmax; width += wstep)
-    total += offsets_for_width(plen, width, omin, omax, ostep);
-  if (total == 0) return;
+  float width = wmin;
+#pragma unroll
+  for (int i = 0; i < kMaxW; i++) {
+    const bool in = width < wmax;
+    wv[i] = width;
+    int cnt = 0;
+    if (in) {
+      // offsets_for_width with the division spelled out for the two steps the search uses
+      const float pw = (float)plen * width;
+      unsigned short pom = (unsigned short)omax;
+      const unsigned short maxo = (unsigned short)(428 - __float2int_rn(pw));
+      if (pom == 0xFFFF || pom > maxo) pom = maxo;
+      const int d = (int)pom - omin;
+      cnt = d > 0 ? (ostep == 1 ? d : (ostep == 10 ? (d + 9) / 10 : (d + ostep - 1) / ostep)) : 0;
+      width += wstep;
+    }
+    cn[i] = cnt;
+    total += cnt;
+  }
+  const bool more_widths = width < wmax;
+  if (total == 0 && !more_widths) return;
   bool decided = false;
-  if (total <= 128) {
+  if (total <= 128 && !more_widths) {
     float sc[2], cw[2];
     int co[2];
     unsigned sa[2], sb[2];
@@ -322,16 +399,18 @@ __device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, 
       float my_w = 0.0f;
       int my_off = 0, idx = 0;
       bool has = false;
-      if (64 * j < total)
-        for (float width = wmin; width < wmax; width += wstep) {
-          const int cnt = offsets_for_width(plen, width, omin, omax, ostep);
-          if (!has && my >= idx && my < idx + cnt) {
+      if (64 * j < total) {
+#pragma unroll
+        for (int i = 0; i < kMaxW; i++) {
+          const int rel = my - idx;
+          if ((unsigned)rel < (unsigned)cn[i]) {  // (counts are disjoint ranges: at most one hit)
             has = true;
-            my_w = width;
-            my_off = omin + (my - idx) * ostep;
+            my_w = wv[i];
+            my_off = omin + rel * ostep;
           }
-          idx += cnt;
+          idx += cn[i];
         }
+      }
       cw[j] = my_w;
       co[j] = my_off;
       sa[j] = sb[j] = 0u;
@@ -535,7 +614,11 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
     hseg_pass_filtered(g, W, flt, pt, wmin, wmax, wstep, omin, omax, pass == 0 ? 10 : 1, best, lane);
     HS_T(3 + pass)
   }
-  hseg_make_exact(g, pt, best, lane);
+  if (!best.exact) {  // (W is dead: its LDS holds the terms)
+    best.score = pt == 2 ? hseg_ordered_chain_t<2>(g, W, best.width, best.offset, lane)
+                         : hseg_ordered_chain_t<1>(g, W, best.width, best.offset, lane);
+    best.exact = true;
+  }
   HS_T(7)
 #ifdef DMZ_HSEG_TIMING
   if (lane == 0 && blockIdx.x == gridDim.x / 2)
