@@ -185,6 +185,7 @@ struct HsegBest {
   int sig_off;     // -1 = the initial incumbent (score 428, no positions)
   unsigned sig_a, sig_b;
   bool exact, improved;
+  bool fit;        // the incumbent has a table score (false: every later pass runs in the ordered form)
 };
 
 // one pass of best_n_hseg_constrained in its ordered form; every lane carries an identical copy of `best`
@@ -244,46 +245,47 @@ struct HsegFilter {
   float e1, e2;  // threshold = m + e1 + e2 m
 };
 
+// The table score of candidate (width, off) and its digit-position signature (the offset apart).  For widths in [16.05, 23.5) --
+// the caller checks the pass' range -- neighbouring digits are 16 .. 24 columns apart and digits across a gap 32 .. 47, so the
+// positions grow with the slot (the last digit decides the bounds test of n_hseg.cpp:61), a spacing less its smallest value fits
+// four bits, and a digit's segment has 16 .. 19 template taps (19 across a gap and for the last digit).
 template <int PT>
 __device__ __forceinline__ float hseg_table_score_t(const float *__restrict__ W, float G, float width, int off, bool has,
                                                     unsigned &sig_a, unsigned &sig_b) {
   constexpr int plen = PT == 1 ? 19 : 17;
   constexpr unsigned mask = PT == 1 ? 0x7BDEFu : 0x1F7EFu;
   constexpr int nd = PT == 1 ? 16 : 15;
-  int c[nd];
+  int r[nd];    // digit k's column less the offset (n_hseg.cpp:60)
   int dpi[nd];  // pattern slots between digit k and digit k + 1 (compile-time)
   {
     int k = 0, last = 0;
 #pragma unroll
     for (int pi = 0; pi < plen; pi++)
       if ((mask >> pi) & 1u) {
-        c[k] = slot_center(off, pi, width);
+        r[k] = pi == 0 ? 0 : __float2int_rn((float)pi * width);
         if (k > 0) dpi[k - 1] = pi - last;
         last = pi;
         k++;
       }
-    dpi[nd - 1] = 1;
+    dpi[nd - 1] = 2;
   }
-  bool live = has;
-#pragma unroll
-  for (int k = 0; k < nd; k++)
-    if (!(c[k] + 19 < 428)) live = false;
   float s = G;
-  unsigned long long sig = 0ull;
+  unsigned sa = 0u, sb = 0u, base_a = 0u, base_b = 0u;
 #pragma unroll
   for (int k = 0; k < nd; k++) {
-    const int sp = k + 1 < nd ? c[k + 1] - c[k] : 19;
-    // the signature holds the spacing in four bits (16 .. 31 between neighbours, 32 .. 47 across a gap); anything else
-    // (never with the widths of the four passes) makes the candidate unfit for the filter
-    const int d = sp - 16 * dpi[k];
-    if (d < 0 || d > 15 || sp < 16) live = false;
-    if (k + 1 < nd) sig |= (unsigned long long)(unsigned)(d & 15) << (4 * k);
-    const int L = imin(sp, 19) - 16;
-    s = s + W[(live ? c[k] : 0) * 4 + (live ? L : 0)];
+    int L = 19;
+    if (k + 1 < nd) {
+      const int sp = r[k + 1] - r[k];
+      if (dpi[k] == 1) L = imin(sp, 19);
+      // sum of (spacing << 4 k); less the same sum of the smallest spacings it is the packed four-bit differences
+      if (k < 8) sa += (unsigned)sp << (4 * k), base_a += (unsigned)(16 * dpi[k]) << (4 * k);
+      else sb += (unsigned)sp << (4 * (k - 8)), base_b += (unsigned)(16 * dpi[k]) << (4 * (k - 8));
+    }
+    s = s + W[(off + r[k]) * 4 + (L - 16)];
   }
-  sig_a = (unsigned)sig;
-  sig_b = (unsigned)(sig >> 32);
-  return live ? s : __builtin_inff();
+  sig_a = sa - base_a;
+  sig_b = sb - base_b;
+  return (has && off + r[nd - 1] + 19 < 428) ? s : __builtin_inff();
 }
 __device__ __forceinline__ float hseg_table_score(const float *__restrict__ W, float G, int pt, float width, int off, bool has,
                                                   unsigned &sig_a, unsigned &sig_b) {
@@ -389,15 +391,17 @@ __device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, 
   const bool more_widths = width < wmax;
   if (total == 0 && !more_widths) return;
   bool decided = false;
-  if (total <= 128 && !more_widths) {
+  // (the table's precondition on the widths, and offsets that keep every table index inside the table: an offset is below
+  // 428 - plen x width, so the last digit starts before column 428 - 16)
+  if (total <= 128 && !more_widths && wmin >= 16.05f && wmax <= 23.5f && omin >= 0 && best.fit) {
     float sc[2], cw[2];
     int co[2];
     unsigned sa[2], sb[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int my = 64 * j + lane;
-      float my_w = 0.0f;
-      int my_off = 0, idx = 0;
+      float my_w = wv[0];  // (lanes without a candidate score the first one: any valid table index)
+      int my_off = omin, idx = 0;
       bool has = false;
       if (64 * j < total) {
 #pragma unroll
@@ -470,16 +474,19 @@ __device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, 
   const float before_s = best.score;
   best = hseg_pass(g, pt, wmin, wmax, wstep, omin, omax, ostep, best, lane);
   if (best.score != before_s || best.width != before_w || best.offset != before_o) {
-    unsigned a, b;
-    const float t = hseg_table_score(W, flt.G, pt, best.width, best.offset, true, a, b);
-    best.approx = t;  // (+inf for positions the filter does not take: every later pass is then ordered as well)
-    best.sig_off = best.offset;
-    best.sig_a = a;
-    best.sig_b = b;
+    // (an in-bounds winner of a width the table takes: its digits start before column 409)
+    best.fit = best.width >= 16.05f && best.width < 23.5f && best.offset >= 0;
+    if (best.fit) {
+      unsigned a, b;
+      best.approx = hseg_table_score(W, flt.G, pt, best.width, best.offset, true, a, b);
+      best.sig_off = best.offset;
+      best.sig_a = a;
+      best.sig_b = b;
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, size_t card_stride,
+__global__ __launch_bounds__(64, 5) void k_hseg(const uint8_t *__restrict__ cards, size_t card_stride,
                                               int n, dmz_hip_frame_result *__restrict__ results) {
   __shared__ float g[428 + 64];
   // the filter's table W[c][L - 16]; its first 428 words hold the integer column sums until g is built
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(64) void k_hseg(const uint8_t *__restrict__ cards, 
   best.sig_a = best.sig_b = 0u;
   best.exact = true;
   best.improved = false;
+  best.fit = true;
   for (int pass = 0; pass < 4; pass++) {  // n_hseg.cpp:106-139
     const int po = best.offset;
     const float hw = pass == 1 ? 0.5f : (pass == 2 ? 0.2f : 0.1f);
