@@ -507,43 +507,47 @@ __global__ __launch_bounds__(64, 5) void k_hseg(const uint8_t *__restrict__ card
 #endif
   HS_T(0)
   // ---- cross gradient clamped at the strip (ROI) edge + column sums (n_hseg.cpp:90-95) ----
-  // A lane owns dword q of every row (columns 4q .. 4q+3); its two neighbour bytes come from the neighbour lanes (DPP wave shifts)
-  // and, at the ends of the 64-lane pass, from a wave-uniform load of the dword next to the pass.  All 27 + 27 loads of a pass are
-  // issued before the first row is used: one memory latency per pass (the row-by-row form waited ~1.7 k cycles for each of the
-  // 2 x 27 rows: 90 k of a wave's 140 k cycles, -DDMZ_HSEG_TIMING).
+  // A lane owns one dword (four columns) of every row; the neighbour columns come from the neighbour lanes (DPP wave shifts).
+  // Two passes of 64 lanes with a halo lane at each end: pass 0 = dwords -1 .. 62 (results for 0 .. 61), pass 1 = dwords 61 .. 107
+  // (results for 62 .. 106); the "dwords" -1 and 107 are dwords 0 and 106 with the edge column copied into the byte the neighbour
+  // reads (the replicated border of cv/morph.cpp:190-220), so the row loop has no edge cases.  All 27 loads of a pass are issued
+  // before the first row is used: one memory latency per pass (the row-by-row form waited ~1.7 k cycles for each of its 2 x 27
+  // rows: 90 k of a wave's 140 k cycles, -DDMZ_HSEG_TIMING).
+  // (Measured and rejected: the five-tap max / min on packed 16-bit pairs -- even columns in one register, odd ones in another,
+  // v_pk_max_u16 / v_pk_min_u16: 805 instead of 1 230 instructions per pass and 12 % SLOWER, 0.56 vs 0.50 ms.)
   int lmin = 1 << 30, lmax = -1;
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
-    const int q = 64 * pass + lane;
-    const bool on = q < 107;
-    uint32_t col[27], edge[27];
+    const int di = pass == 0 ? imax(lane - 1, 0) : imin(61 + lane, 106);
+    const int q = pass == 0 ? lane - 1 : 61 + lane;
+    const bool on = pass == 0 ? (lane >= 1 && lane <= 62) : (lane >= 1 && lane <= 45);
+    // byte 3 := byte 0 in the lane of "dword -1", byte 0 := byte 3 in the lane of "dword 107"
+    const unsigned fix = (pass == 0 && lane == 0) ? 0x00020100u : ((pass == 1 && lane == 46) ? 0x03020103u : 0x03020100u);
+    uint32_t col[27];
 #pragma unroll
-    for (int r = 0; r < 27; r++) {
-      col[r] = strip[r * 107 + (on ? q : 106)];
-      edge[r] = strip[r * 107 + (pass == 0 ? 64 : 63)];  // wave-uniform: dword 64 right of pass 0, dword 63 left of pass 1
-    }
+    for (int r = 0; r < 27; r++) col[r] = strip[r * 107 + di];
+#pragma unroll
+    for (int r = 0; r < 27; r++) col[r] = __builtin_amdgcn_perm(col[r], col[r], fix);
     int sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0;
-    uint32_t up = col[0], mid = col[0];  // row -1 replicates row 0
+    uint32_t mid = col[0];
+    int c0 = mid & 255, c1 = (mid >> 8) & 255, c2 = (mid >> 16) & 255, c3 = mid >> 24;
+    int n0 = c0, n1 = c1, n2 = c2, n3 = c3;  // row -1 = row 0
 #pragma unroll
     for (int r = 0; r < 27; r++) {
-      uint32_t dn = col[r < 26 ? r + 1 : 26];  // row 27 replicates row 26
-      // lane - 1's dword into this lane, lane + 1's dword into this lane (wave_shr:1 / wave_shl:1)
-      uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid, 0x138, 0xf, 0xf, false);
-      uint32_t rw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid, 0x130, 0xf, 0xf, false);
-      if (pass == 0 && lane == 63) rw = edge[r];
-      if (pass == 1 && lane == 0) lw = edge[r];
-      const int c0 = mid & 255, c1 = (mid >> 8) & 255, c2 = (mid >> 16) & 255, c3 = mid >> 24;
-      const int wl = q > 0 ? (int)(lw >> 24) : c0;          // column -1 replicates column 0
-      const int er = q < 106 ? (int)(rw & 255) : c3;        // column 428 replicates column 427
-      const int n0 = up & 255, n1 = (up >> 8) & 255, n2 = (up >> 16) & 255, n3 = up >> 24;
+      uint32_t dn = col[r < 26 ? r + 1 : 26];  // row 27 = row 26
       const int s0 = dn & 255, s1 = (dn >> 8) & 255, s2 = (dn >> 16) & 255, s3 = dn >> 24;
+      // lane - 1's dword and lane + 1's dword (wave_shr:1 / wave_shl:1; the wave's end lanes are halo lanes)
+      const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid, 0x138, 0xf, 0xf, true);
+      const uint32_t rw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid, 0x130, 0xf, 0xf, true);
+      const int wl = (int)(lw >> 24), er = (int)(rw & 255);
       sum0 += max5(n0, wl, c0, c1, s0) - min5(n0, wl, c0, c1, s0);
       sum1 += max5(n1, c0, c1, c2, s1) - min5(n1, c0, c1, c2, s1);
       sum2 += max5(n2, c1, c2, c3, s2) - min5(n2, c1, c2, c3, s2);
       sum3 += max5(n3, c2, c3, er, s3) - min5(n3, c2, c3, er, s3);
       // row by row: left alone the compiler first moves the neighbour dwords of all 27 rows (199 registers)
       asm volatile("" : "+v"(sum0), "+v"(sum1), "+v"(sum2), "+v"(sum3), "+v"(dn));
-      up = mid;
+      n0 = c0; n1 = c1; n2 = c2; n3 = c3;
+      c0 = s0; c1 = s1; c2 = s2; c3 = s3;
       mid = dn;
     }
     if (on) {
