@@ -234,6 +234,13 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #ifndef DMZ_XSEG_FOLD  /* developer switch: 0 = the slash MLP always on Scharr samples */
 #define DMZ_XSEG_FOLD 1
 #endif
+// developer probe (-DDMZ_XSEG_TL; tools/dev/xseg_tl.py): cycles per phase summed over all waves
+#ifdef DMZ_XSEG_TL
+__device__ unsigned long long g_xs_tl[16];
+#define XS_TL(i) { const long long tl_now = (long long)__builtin_readcyclecounter(); tl_acc[i] += tl_now - tl_last; tl_last = tl_now; }
+#else
+#define XS_TL(i)
+#endif
 #define XSEG_STOP(k, expr)                     \
   if (DMZ_XSEG_STOP == (k)) {                  \
     if (lane == 0) sg->n = (int)(expr) & 0;    \
@@ -373,6 +380,10 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 #ifdef DMZ_XSEG_DBG
   const long long dbg_start = __builtin_readcyclecounter();
 #endif
+#ifdef DMZ_XSEG_TL
+  long long tl_last = (long long)__builtin_readcyclecounter();
+  long long tl_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   // window rows k = 0..20 <-> image rows base-3+k; the Scharr image is zero outside [y0, 269]
   unsigned vmask = 0u;
   for (int k = 0; k < 21; k++) {
@@ -411,6 +422,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
   }
   __syncthreads();
+  XS_TL(0)
   XSEG_STOP(1, L.inter[lane])
 
   // ---- column sums (456-486).  colA[c] = sum over window rows k = 3 .. 19 of the Scharr sample v_k (0 outside the ROI),
@@ -455,6 +467,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
   }
   __syncthreads();
+  XS_TL(1)
   XSEG_STOP(2, L.u.colA[lane])
   // thresholds (expiry_seg.cpp:447-449, 488-494).  While the running total stays below 2^24 every
   // float addition of these integers is exact, so the float total equals the integer total whenever
@@ -500,6 +513,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   const float avg = total / (float)cnt;
   const float thr2 = (float)(0.8 * (double)avg);
 
+  XS_TL(2)
   XSEG_STOP(3, thr2)
   // ---- greedy non-overlapping pick in descending sum order (expiry_seg.cpp:496-529), in parallel rounds: a
   // candidate that beats every live candidate within 8 columns is what the sequential scan would pick next in its
@@ -679,6 +693,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     if (lane == 0) atomicAdd(&g_xs_dbg[3], (unsigned long long)(__builtin_readcyclecounter() - dbg_t1));
 #endif
   }
+  XS_TL(3)
   XSEG_STOP(4, picked)
   // sorted by left = column order = lane-major, slot-minor: a lane's first item follows the picks of the lanes below
   int n_items = 0;
@@ -733,10 +748,12 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   }
   __syncthreads();  // u.a is dead from here on; u.b takes its place
 
+  XS_TL(4)
   XSEG_STOP(5, G)
   const int g_top = base - 1;  // expanded stripe top; group height 17
   int rbase = 0, ncand = 0;  // rects / slash candidates of the groups so far
   for (int g = 0; g < G; g++) {
+    XS_TL(7)
     // ---- regrid_group (169-229) ----
     const int left = L.gL[g], width = L.gW[g];
     const int bl = imax(left - 2 * SCW, 0), br = imin(left + width + 2 * SCW, CW);
@@ -799,6 +816,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     const int cw = sp - 1;
     int rs = 0, re = nR;
     strip_white_space_lanes(my_sum, rs, re);
+    XS_TL(5)
     if (DMZ_XSEG_STOP == 6) continue;
 
     // ---- optimize_character_rects (231-339): three rects per pass, 21 lanes each.  Lane c of a
@@ -903,7 +921,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
     rbase += n2;
     __syncthreads();
+    XS_TL(6)
   }
+  XS_TL(7)
   {
     // ---- slash search (643-674): character first+2 of every window of five, sixteen candidates
     // per pass -- over the candidates of ALL the stripe's groups (round 3: a pass per group fetched the 90 KB of weight
@@ -1086,6 +1106,13 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       }
     }
   }
+  XS_TL(8)
+#ifdef DMZ_XSEG_TL
+  if (lane == 0 && (blockIdx.x & 1023) == 7) {  // (a sample of the waves: every wave adding to nine counters slows the kernel down)
+    for (int i = 0; i < 9; i++) atomicAdd(&g_xs_tl[i], (unsigned long long)tl_acc[i]);
+    atomicAdd(&g_xs_tl[15], 1ull);
+  }
+#endif
   if (lane == 0) sg->n = n_emitted;
 #ifdef DMZ_XSEG_DBG
   if (lane == 0) atomicAdd(&g_xs_dbg[5], (unsigned long long)(__builtin_readcyclecounter() - dbg_start)), atomicAdd(&g_xs_dbg[6], 1ull);
@@ -1912,6 +1939,16 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
                        n, results, stage, out);
 }
 
+#ifdef DMZ_XSEG_TL
+extern "C" void dmz_dbg_xseg_tl(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xs_tl), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_xs_tl), z, sizeof(z));
+  }
+}
+#endif
 #ifdef DMZ_XSEG_DBG
 extern "C" void dmz_dbg_xseg(unsigned long long *out, int reset) {
   hipDeviceSynchronize();
