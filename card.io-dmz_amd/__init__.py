@@ -87,7 +87,7 @@ EXPORTS = (
     "dmz_hip_scores_batch", "dmz_hip_blur_cards_batch", "dmz_hip_set_expiry_conv", "dmz_hip_set_two_queues",
     "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
     "dmz_hip_gather_records", "dmz_hip_gather_wait", "dmz_hip_expiry_sort_positions",
-    "dmz_hip_categorize_expiry_groups_batch", "dmz_hip_scharr3_dx_abs",
+    "dmz_hip_categorize_expiry_groups_batch", "dmz_hip_scharr3_dx_abs", "dmz_hip_best_n_hseg_batch",
 )
 
 
@@ -144,6 +144,7 @@ def load_library():
     lib.dmz_hip_detect_batch.argtypes = [vp, vp, sz, i, i, i, vp, vp, sz, i, i, i, vp]
     lib.dmz_hip_transform_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, vp, sz]
     lib.dmz_hip_scan_cards_batch.argtypes = [vp, vp, sz, i, i, vp]
+    lib.dmz_hip_best_n_hseg_batch.argtypes = [vp, vp, sz, i, vp]
     lib.dmz_hip_pipeline_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp]
     lib.dmz_hip_scan_expiry_batch.argtypes = [vp, vp, sz, i, vp, vp]
     lib.dmz_hip_pipeline_expiry_batch.argtypes = [vp, vp, sz, i, i, i, i, i, i, vp, sz, vp, vp]
@@ -309,6 +310,10 @@ class Context:
     def scan_cards(self, cards, n, results, only_warped=False, skip_number=False):
         mode = (SCAN_ONLY_WARPED if only_warped else 0) | (SCAN_SKIP_NUMBER if skip_number else 0)
         self._check(self.lib.dmz_hip_scan_cards_batch(self.h, _ptr(cards), CARD_BYTES, n, mode, _ptr(results)))
+
+    def best_n_hseg(self, cards, n, results):
+        """best_n_hseg (n_hseg.cpp:88) at each record's vseg_y_offset / pattern_type (records with FLAG_VSEG_OK)"""
+        self._check(self.lib.dmz_hip_best_n_hseg_batch(self.h, _ptr(cards), CARD_BYTES, n, _ptr(results)))
 
     def pipeline(self, y, n, results, cards=None, width=FRAME_W, height=FRAME_H,
                  orientation=ORIENTATION_LANDSCAPE_RIGHT, options=0):

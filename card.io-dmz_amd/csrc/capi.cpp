@@ -823,7 +823,7 @@ struct RcclApi {
 struct RcclId {
   char internal[128];  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES), passed by value like the C API does
 };
-RcclApi load_rccl() {
+static RcclApi load_rccl() {
   RcclApi api;
   for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -1114,6 +1114,48 @@ int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t 
   if (!res_dev) {
     HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n,
                                 hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return DMZ_HIP_OK;
+}
+
+int dmz_hip_best_n_hseg_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                              dmz_hip_frame_result *results) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (!cards || !results || n <= 0 || card_stride < (size_t)DMZ_CARD_WIDTH * DMZ_CARD_HEIGHT || (card_stride & 3))
+    return fail(ctx, DMZ_HIP_EINVAL, "bad card buffer (stride must be >= 115560 and a multiple of 4)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const void *dc = nullptr;
+  if ((rc = stage_in(ctx, ctx->stage_cards, cards, card_stride * (size_t)n, &dc))) return rc;
+  if (((uintptr_t)dc) & 3) return fail(ctx, DMZ_HIP_EINVAL, "card buffer must be 4-byte aligned");
+  // the records come from the caller: their strip and pattern are checked on the host (a copy for device-resident ones)
+  std::vector<dmz_hip_frame_result> host((size_t)n);
+  const bool res_dev = is_device_ptr(results);
+  if (res_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), results, sizeof(dmz_hip_frame_result) * (size_t)n, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    memcpy(host.data(), results, sizeof(dmz_hip_frame_result) * (size_t)n);
+  }
+  for (int i = 0; i < n; i++) {
+    if (!(host[(size_t)i].flags & DMZ_HIP_FLAG_VSEG_OK)) continue;
+    if (host[(size_t)i].vseg_y_offset < 0 || host[(size_t)i].vseg_y_offset > DMZ_CARD_HEIGHT - 27)
+      return fail(ctx, DMZ_HIP_EINVAL, "vseg_y_offset outside the card");
+    if (host[(size_t)i].pattern_type != 1 && host[(size_t)i].pattern_type != 2)
+      return fail(ctx, DMZ_HIP_EINVAL, "pattern_type must be 1 or 2 where DMZ_HIP_FLAG_VSEG_OK is set");
+  }
+  dmz_hip_frame_result *dres = results;
+  if (!res_dev) {
+    if ((rc = ensure(ctx, ctx->stage_res, sizeof(dmz_hip_frame_result) * (size_t)n))) return rc;
+    dres = (dmz_hip_frame_result *)ctx->stage_res.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dres, results, sizeof(dmz_hip_frame_result) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  dmz_launch_hseg(ctx->stream, (const uint8_t *)dc, card_stride, n, dres);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!res_dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(results, dres, sizeof(dmz_hip_frame_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return DMZ_HIP_OK;

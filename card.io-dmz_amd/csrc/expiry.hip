@@ -828,6 +828,13 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     {
       const int sl = lane / 21, c = lane - sl * 21;
       unsigned char *tile = L.u.b.tile;  // [3][21][19]
+#ifdef DMZ_XSEG_TL
+      if (lane == 0 && (blockIdx.x & 1023) == 7) {
+        atomicAdd(&g_xs_tl[9], (unsigned long long)((re - rs + 2) / 3)), atomicAdd(&g_xs_tl[10], (unsigned long long)((re - rs + 3) / 4));
+        atomicAdd(&g_xs_tl[11], 1ull), atomicAdd(&g_xs_tl[12], ciw <= 16 ? 1ull : 0ull), atomicAdd(&g_xs_tl[13], (unsigned long long)(re - rs));
+        atomicAdd(&g_xs_tl[14], ciw <= 16 ? (unsigned long long)((re - rs + 2) / 3 - (re - rs + 3) / 4) : 0ull);
+      }
+#endif
       for (int b0 = rs; b0 < re; b0 += 3) {
         const int k = b0 + sl;
         const bool have = sl < 3 && k < re;

@@ -155,6 +155,14 @@ int dmz_hip_transform_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t f
 int dmz_hip_scan_cards_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride,
                              int n, int mode, dmz_hip_frame_result *results);
 
+/* best_n_hseg (scan/n_hseg.h, n_hseg.cpp:88-151) alone: the digit x-offset search on the 27-row strip at
+ * results[i].vseg_y_offset of card i for results[i].pattern_type (1 = sixteen digits, 2 = fifteen), for every record
+ * that carries DMZ_HIP_FLAG_VSEG_OK and 0 <= vseg_y_offset <= 243; fills n_offsets, offsets, hseg_score, number_width and
+ * pattern_offset and leaves the rest of the record alone (the stage entry dmz_hip_scan_cards_batch runs between its
+ * vseg and digit stages). */
+int dmz_hip_best_n_hseg_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t card_stride, int n,
+                              dmz_hip_frame_result *results);
+
 /* detect -> transform(Y) -> scan for n frames (the cython_dmz/dmz.pyx:379-483
  * call sequence).  cards may be NULL (an internal buffer is used). */
 int dmz_hip_pipeline_batch(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride,

@@ -274,6 +274,14 @@ class Oracle:
                                              _p(offs, _u16p), C.byref(sc), C.byref(nwc), C.byref(poc))
         return offs, sc.value, nwc.value, poc.value
 
+    def best_n_hseg(self, strip, pattern):
+        """n_hseg.cpp:88-151 on a 27-row strip: (n_offsets, offsets, score, number_width, pattern_offset)"""
+        strip = np.ascontiguousarray(strip, np.uint8)
+        res = np.zeros(1, RESULT_DTYPE)
+        self.lib.orc_best_n_hseg(_p(strip, _u8p), strip.shape[1], int(pattern), res.ctypes.data_as(C.c_void_p))
+        r = res[0]
+        return int(r["n_offsets"]), r["offsets"].copy(), r["hseg_score"], r["number_width"], int(r["pattern_offset"])
+
     def number_scores(self, strip, offsets, n):
         strip = np.ascontiguousarray(strip, np.uint8)
         offs = np.ascontiguousarray(offsets, np.uint16)

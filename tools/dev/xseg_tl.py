@@ -25,4 +25,6 @@ ctx.synchronize()
 ctx.lib.dmz_dbg_xseg_tl(out, 0)
 n = max(1, out[15])
 names = ["rows", "column sums", "thresholds + rect sums", "pick", "groups", "regrid", "character rects", "between", "slash + emit"]
+print("per wave: groups %.2f (with a character image <= 16 wide: %.2f), rects %.2f, batches of three %.2f, of four %.2f, batches saved by four where the image fits %.2f"
+      % (out[11] / n, out[12] / n, out[13] / n, out[9] / n, out[10] / n, out[14] / n))
 print("waves %d; cycles per wave: " % n + ", ".join("%s %.0f" % (names[i], out[i] / n) for i in range(9)) + "; total %.0f" % (sum(out[:9]) / n))
