@@ -230,7 +230,11 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
 #pragma unroll
     for (int m = 0; m < 3; m++)
 #pragma unroll
+#ifdef DMZ_DG_NOFC1LOAD  /* developer probe (timing only, wrong results): one cache line instead of the column's fragments */
+      for (int nt = 0; nt < 2; nt++) fb[m][nt] = fcw[0];
+#else
       for (int nt = 0; nt < 2; nt++) fb[m][nt] = fcw[((size_t)(m * 5 + pc) * 4 * 2 + nt) * 64];
+#endif
   };
   auto fc1_chunk = [&]() {
     f32x4 a[3];
@@ -485,20 +489,37 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DIGITS_WGS) void k_digits(const flo
   if (f >= n) return;
   dmz_hip_frame_result *res = results + f;
   DG_T(0)
+#ifndef DMZ_DG_PRIO  /* developer switch: issue priority of a workgroup while it requests its inputs */
+#define DMZ_DG_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(DMZ_DG_PRIO);
   // the card's patches (4320 dwords, fixed address: requested before the record says whether they are needed)
   constexpr int kStage = (XPLANE / 4 + DG_THREADS - 1) / DG_THREADS;  // 17
   const int tid = threadIdx.x;
   uint32_t st[kStage];
   {
+#ifdef DMZ_DG_SAMEPATCH  /* developer probe (timing only, wrong results): every card reads one of 64 cache-resident patch sets */
+    const uint32_t *src = patches + (size_t)(f & 63) * (XPLANE / 4);
+#else
     const uint32_t *src = patches + (size_t)f * (XPLANE / 4);
+#endif
 #pragma unroll
     for (int k = 0; k < kStage; k++) st[k] = tid + k * DG_THREADS < XPLANE / 4 ? src[tid + k * DG_THREADS] : 0u;
   }
+#ifdef DMZ_DG_LOADWAIT  /* developer probe: cycles until the card's patches have arrived (a sample of the workgroups) */
+  {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    if (tid == 0 && (blockIdx.x & 255) == 3) printf("k_digits block %d: patches arrived after %lld cycles\n", blockIdx.x, t1 - t0);
+  }
+#endif
   ConvWeights cw;
   conv_weights_load(cw, hidw, tid & 63);
   // the tail's weights (hidden biases, logistic layer): LDS, so that the short serial steps at the end wait for no L2
   const f32x4 *twsrc = (const f32x4 *)(hidw + dmzv::WFRAG + dmzv::DTAIL);
   const f32x4 tw0 = twsrc[tid], tw1 = tid + DG_THREADS < DG_TAILW / 16 ? twsrc[tid + DG_THREADS] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_setprio(0);
   if (!(res->flags & DMZ_HIP_FLAG_VSEG_OK)) return;
   const int nd = res->n_offsets;
 #pragma unroll
