@@ -762,23 +762,40 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     int gs = 0;
     for (int c = bl + lane; c < br; c += 64) gs += L.colB[c];
     const float group_sum = (float)wave_sum_i32(gs);
+    // The 65 hypotheses (spacing 11 .. 15, starting column < spacing): lane q scores hypothesis q, lane 0 also the 65th.  The
+    // reference adds the grid lines' column sums in float, but they are integers (<= 17 x 4 080) and at most 39 of them:
+    // every partial sum stays below 2^24, so the float sum IS the integer sum in any order -- four lines per trip with their
+    // LDS reads in flight together instead of a read, a wait and a conversion per line (the loop was ~5 k cycles of LDS
+    // round trips per group, -DDMZ_XSEG_TL).
     unsigned long long best = ~0ull;
+    {
+      int sp, so;
+      if (lane < 11) sp = 11, so = lane;
+      else if (lane < 23) sp = 12, so = lane - 11;
+      else if (lane < 36) sp = 13, so = lane - 23;
+      else if (lane < 50) sp = 14, so = lane - 36;
+      else sp = 15, so = lane - 50;
+      int acc = 0, acc64 = 0;
+      const int trips = ((bw + 10) / 11 + 3) >> 2;  // the most lines any hypothesis has: spacing 11 from column 0
+      int off = so, off64 = 14;
+      for (int t = 0; t < trips; t++) {
+        int v[4], w[4];
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const int q = lane + 64 * pass;
-      if (q <= 64) {
-        int sp, so;
-        if (q < 11) sp = 11, so = q;
-        else if (q < 23) sp = 12, so = q - 11;
-        else if (q < 36) sp = 13, so = q - 23;
-        else if (q < 50) sp = 14, so = q - 36;
-        else sp = 15, so = q - 50;
-        float gls = 0.0f;
-        int nl = 0;
-        for (int off = so; off < bw; off += sp) {
-          nl++;
-          gls += (float)L.colB[bl + off];
+        for (int u = 0; u < 4; u++) {
+          v[u] = L.colB[bl + imin(off + u * sp, bw - 1)];
+          w[u] = L.colB[bl + imin(off64 + u * 15, bw - 1)];
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          acc += off + u * sp < bw ? v[u] : 0;
+          acc64 += off64 + u * 15 < bw ? w[u] : 0;
+        }
+        off += 4 * sp;
+        off64 += 60;
+      }
+      auto consider = [&](int q, int lines_from, int spacing, int sum) {
+        const int nl = lines_from < bw ? (bw - 1 - lines_from) / spacing + 1 : 0;
+        float gls = (float)sum;
         const float average = gls / (float)nl;
         gls = average * (float)min_lines;
         const float ratio = gls / (group_sum - gls);
@@ -788,7 +805,9 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           const unsigned long long k = ((unsigned long long)u << 32) | (unsigned)q;
           best = k < best ? k : best;
         }
-      }
+      };
+      consider(lane, so, sp, acc);
+      if (lane == 0) consider(64, 14, 15, acc64);
     }
     best = wave_min_u64(best);
     int sp = 11, so = 0;
@@ -807,7 +826,12 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
       const bool ok = off + 1 < bw;
       if (ok) {
         const int cend = imin(off + sp, bw);
-        for (int c = off + 1; c < cend; c++) my_sum += L.colB[bl + c];
+        // (at most fourteen columns; all reads in flight together instead of one LDS round trip per column)
+        int cv[14];
+#pragma unroll
+        for (int u = 0; u < 14; u++) cv[u] = L.colB[bl + imin(off + 1 + u, bw - 1)];
+#pragma unroll
+        for (int u = 0; u < 14; u++) my_sum += off + 1 + u < cend ? cv[u] : 0;
         L.u.b.rL[lane] = bl + off + 1;
       }
       nR = __popcll(__ballot(ok));
