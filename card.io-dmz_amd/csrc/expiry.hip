@@ -871,10 +871,18 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           int iv[IROWS];
 #pragma unroll
           for (int t = 0; t < IROWS; t++) iv[t] = col ? (int)L.inter[t * ISTRIDE + rect_left + c] : 0;
+          if (vmask == 0x1FFFFFu) {  // (wave-uniform) the usual case: all 21 window rows inside the ROI, no per-row select
 #pragma unroll
-          for (int r = 0; r < 21; r++) {
-            v[r] = ((vmask >> r) & 1u) ? 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1] : 0;
-            mx = imax(mx, v[r]);
+            for (int r = 0; r < 21; r++) {
+              v[r] = 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1];
+              mx = imax(mx, v[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 21; r++) {
+              v[r] = ((vmask >> r) & 1u) ? 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1] : 0;
+              mx = imax(mx, v[r]);
+            }
           }
         }
         const int sidx = sl * 24 + c;  // this lane's entry of the per-slot arrays
