@@ -486,7 +486,10 @@ __device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, 
   }
 }
 
-__global__ __launch_bounds__(64, 5) void k_hseg(const uint8_t *__restrict__ cards, size_t card_stride,
+#ifndef DMZ_HSEG_WAVES  /* waves per SIMD the register allocation aims at (3 .. 6: 0.470 .. 0.481 ms, 4 = no scratch; LDS allows 18 workgroups per CU) */
+#define DMZ_HSEG_WAVES 4
+#endif
+__global__ __launch_bounds__(64, DMZ_HSEG_WAVES) void k_hseg(const uint8_t *__restrict__ cards, size_t card_stride,
                                               int n, dmz_hip_frame_result *__restrict__ results) {
   __shared__ float g[428 + 64];
   // the filter's table W[c][L - 16]; its first 428 words hold the integer column sums until g is built
