@@ -11,20 +11,19 @@
 // number_width and the offsets are bit-exact.
 //
 // CDNA4 mapping: one wave per card, one lane per candidate.
-//   * column sums straight from HBM/L2: a lane owns 4 adjacent columns (one dword per
-//     row, plus its two neighbour dwords), walks the 27 rows with three rows in
-//     registers; no strip in LDS (LDS holds only the 428 normalised floats), so up to 32
-//     cards are resident per CU and their serial sums hide each other's latency.
-//   * the sequential sum is organised by digit: for digit k every lane adds the columns
-//     [c_k, c_{k+1}) in order (the same column order as 0..427), so the template tap index
-//     j is wave-uniform (template values are instruction literals) and only the LDS
-//     address differs per lane; lanes whose segment is shorter add +0.0f.
+//   * column sums straight from HBM/L2: a lane owns 4 adjacent columns (one dword per row), all 27 row dwords of a 64-lane
+//     pass are requested together, the neighbour columns come from the neighbour lanes (DPP wave shifts); no strip in LDS
+//     (LDS holds the 428 normalised floats and the filter's table: 8.8 KB, 18 cards per CU).
+//   * the ordered form of a pass (lane = candidate): the sequential sum is organised by digit -- for digit k every lane adds
+//     the columns [c_k, c_{k+1}) in order (the same column order as 0..427), so the template tap index j is wave-uniform
+//     (template values are instruction literals) and only the LDS address differs per lane; lanes whose segment is shorter
+//     add +0.0f.  Since round 4 only the passes the filter cannot decide run in this form.
 //   * round 4: the search is FILTERED.  A candidate's score is sum_c |g_c| + sum_digits W_L[c_k] with
 //     W_L[c] = sum_{j<L} (|g_{c+j} - T_j| - |g_{c+j}|) (L = the digit's segment length, 16..19): one table of 428 x 4 floats
 //     per card turns a candidate into sixteen LDS reads and additions instead of 428 ordered terms.  That value is within a
-//     proven distance of the reference's ordered float sum (hseg_filter_eps below), so whenever the best candidate leads every
+//     proven distance of the reference's ordered float sum ("the filtered search" below), so whenever the best candidate leads every
 //     candidate with OTHER digit positions by more than that distance the pass is decided without any ordered sum; otherwise
-//     (measured: < 1 % of the passes) the pass runs in its ordered form.  The winner's ordered sum is evaluated once at the end:
+//     (measured: 1.1 % of the passes) the pass runs in its ordered form.  The winner's ordered sum is evaluated once at the end:
 //     hseg.score keeps the reference's bits.
 #include <float.h>
 
