@@ -94,3 +94,28 @@ def test_best_n_hseg_skips_records_without_a_segmentation_and_rejects_bad_ones(c
     bad["pattern_type"][1] = 0
     with pytest.raises(Exception):
         ctx.best_n_hseg(cards, 2, bad)
+
+
+def test_best_n_hseg_on_device_resident_buffers(ctx, pkg, oracle):
+    n = 24
+    dcards = ctx.alloc(n * pkg.CARD_BYTES)
+    ctx.synth_cards(SEED, 0, n, dcards.ptr)
+    cards = dcards.download(np.uint8).reshape(n, 270, 428)
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    ys = []
+    for i in range(n):
+        _, y, p, _, _ = oracle.best_n_vseg(cards[i])
+        ys.append((int(np.clip(y, 0, 243)), p if p else 1))
+    res["flags"] = pkg.FLAG_VSEG_OK
+    res["vseg_y_offset"] = [a for a, _ in ys]
+    res["pattern_type"] = [b for _, b in ys]
+    dres = ctx.alloc(n * res.dtype.itemsize)
+    dres.upload(res.view(np.uint8))
+    ctx.best_n_hseg(dcards.ptr, n, dres.ptr)
+    ctx.synchronize()
+    got = dres.download(pkg.RESULT_DTYPE, n)
+    for i in range(n):
+        n_off, offsets, score, width, po = oracle.best_n_hseg(cards[i][ys[i][0]:ys[i][0] + 27], ys[i][1])
+        assert got[i]["n_offsets"] == n_off and np.array_equal(got[i]["offsets"], offsets), i
+        assert got[i]["hseg_score"].view(np.uint32) == np.float32(score).view(np.uint32), i
+        assert got[i]["number_width"].view(np.uint32) == np.float32(width).view(np.uint32) and got[i]["pattern_offset"] == po, i
