@@ -332,11 +332,33 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       }
 #ifndef DMZ_DETECT_NOLOAD
     } else if (!VERT) {
-      for (int r = wave; r < h; r += NT / 64) {
-        const int soff = r * row_stride;
-        unsigned char *trow = tile + r * sp + 4;  // off = 4 + (x & 3) keeps the word alignment
-        for (int j = lane; j < wpr; j += 64)
-          *(uint32_t *)(trow + 4 * j) = __builtin_amdgcn_raw_buffer_load_b32(rs, ((bp.x >> 2) + j) * 4, soff, 0);
+      // A wave owns the rows wave, wave + NT / 64, ...; a row is ceil(wpr / 64) word columns per lane.  Eight (row, word
+      // column) items are requested before the first is stored: the row-by-row loop (load, wait, store) was one memory round
+      // trip per item, ten in a row for the standard box -- 13 - 15 k of a workgroup's 57 k cycles (-DDMZ_DT_TIMING).
+#ifndef DMZ_DT_INFLIGHT  /* (4 / 6 / 8 / 10 / 12 measured: see DESIGN) */
+#define DMZ_DT_INFLIGHT 8
+#endif
+      constexpr int kInFlight = DMZ_DT_INFLIGHT;
+      const int jt = (wpr + 63) >> 6;
+      int r = wave, jj = 0;  // the next item (wave-uniform)
+      while (r < h) {
+        uint32_t v[kInFlight];
+        int vr[kInFlight], vj[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; u++) {
+          vr[u] = r, vj[u] = lane + 64 * jj;
+          v[u] = 0u;
+          if (r < h) {
+            if (vj[u] < wpr) v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, ((bp.x >> 2) + vj[u]) * 4, r * row_stride, 0);
+            if (++jj == jt) jj = 0, r += NT / 64;
+          } else {
+            vr[u] = -1;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; u++)
+          if (vr[u] >= 0 && vj[u] < wpr)
+            *(uint32_t *)(tile + vr[u] * sp + 4 + 4 * vj[u]) = v[u];  // off = 4 + (x & 3) keeps the word alignment
       }
     } else {
       constexpr int kChunk = 12;  // words per pass: one pass for boxes up to 44 px wide
