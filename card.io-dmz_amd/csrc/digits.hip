@@ -367,7 +367,17 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
   unsigned short *xb = patches + (size_t)f * (XPLANE / 2);
 
   // ---- number strip -> LDS (2889 aligned dwords) ----
-  for (int i = tid; i < 27 * 107; i += DG_THREADS) ((uint32_t *)strip_l)[i] = strip[i];
+  // (all twelve dwords of a thread requested before the first is stored: the rolled loop was load, wait, store twelve times
+  // over -- twelve memory round trips at the head of every workgroup)
+  {
+    constexpr int kIt = (27 * 107 + DG_THREADS - 1) / DG_THREADS;  // 12
+    uint32_t sv[kIt];
+#pragma unroll
+    for (int k = 0; k < kIt; k++) sv[k] = strip[imin(tid + k * DG_THREADS, 27 * 107 - 1)];
+#pragma unroll
+    for (int k = 0; k < kIt; k++)
+      if (tid + k * DG_THREADS < 27 * 107) ((uint32_t *)strip_l)[tid + k * DG_THREADS] = sv[k];
+  }
   __syncthreads();
   if (DMZ_DP_STOP == 1) return;
   // ---- per digit, a wave each (wave w owns digits 4 w .. 4 w + 3): cross gradient clamped at the 19x27 ROI edge,
