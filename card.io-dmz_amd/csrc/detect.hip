@@ -268,7 +268,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
                             const DmzBoxParams &bp, int frame, int box_id,
                             DmzBoxHit *__restrict__ hits, unsigned char *lds) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: what depends on it stays on the scalar unit)
   DT_T(0)
   const int w = bp.w, h = bp.h;
   const int L = bp.lanes, S = bp.steps, N = L * S;
@@ -340,7 +340,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 #endif
       constexpr int kInFlight = DMZ_DT_INFLIGHT;
       const int jt = (wpr + 63) >> 6;
-      int r = wave, jj = 0;  // the next item (wave-uniform)
+      int r = wave, jj = 0;  // the next item (wave-uniform, in scalar registers: the row offset is a scalar operand of the load)
       while (r < h) {
         uint32_t v[kInFlight];
         int vr[kInFlight], vj[kInFlight];
