@@ -1310,7 +1310,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
     // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid): the fp32 convolution to rounding, at half the time of the
     // packed-FMA form (below, F32 variant).  A tile's sixteen rows are four pool windows x their four positions, so the
     // four accumulator elements of a lane ARE a pool window: max, bias, ReLU, hi/lo split for conv2, one store pair.
-    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m16 = lane & 15, kk = lane >> 4;
     // F16X3: both operands in two f16 parts (22 bits) and the three products that carry 2^-22 (lo*hi, hi*lo, hi*hi)
     constexpr int NP = MODE == DMZ_HIP_EXPIRY_CONV_F16X3 ? 2 : 3;
     u32x4 wb[NP][4];
@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   // tap-major zero-padded weight copy, prefetched one k-step ahead); the four partial sums meet in
   // LDS (over l1, dead by then) where the 2 x 3 max-pool, bias and ReLU finish the layer.
   {
-    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m16 = lane & 15, kk = lane >> 4;
     f32x4 acc[XMT][3];
 #pragma unroll
     for (int mt = 0; mt < XMT; mt++)
@@ -1638,7 +1638,7 @@ __device__ __forceinline__ void expiry_cnn_block(const float *__restrict__ wts, 
   // for the output layer (the timeline showed 21 - 69 k cycles here under load, of ~170 k per group).
   f32x4 b2v[11];
   {
-    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m16 = lane & 15, kk = lane >> 4;
     const f32x4 *fc1f = (const f32x4 *)(xw + dmzx::FC1_F) + lane;
     if (wave == 0) {
       const f32x4 *fc2f = (const f32x4 *)(xw + dmzx::FC2_F) + lane;
@@ -1773,7 +1773,7 @@ __global__ __launch_bounds__(XC_THREADS, XND == 1 ? 4 : 3) void k_expiry_cat(con
     // is some eighty registers of loop invariants -- more than three waves per SIMD leave)
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- prepare_image_for_cat (expiry_categorize.cpp:35-70): wave d = character d, on its own until the CNN (a wave's
     // LDS operations execute in order: no workgroup barrier between the steps).  The 16 x 11 pixels arrive as one aligned
     // dword per lane (the taps are clamped to the character, so nothing else is read) instead of fifteen byte loads. ----

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   const int f = blockIdx.x;
   if (f >= n) return;
   dmz_hip_frame_result *res = results + f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int in_flags = res->flags;
   if ((mode & DMZ_HIP_SCAN_ONLY_WARPED) && !(in_flags & DMZ_HIP_FLAG_WARPED)) {
     // not rectified: no gate can have passed, whatever the caller's record held
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
                                                             float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float feat[16 * 208];
   __shared__ float part[4 * 80 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int base = blockIdx.x * 16;
   const int rows = imin(16, n - base);
   if (rows <= 0) return;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   if (frame >= n) return;
   const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int x = tx * TW;   // OpenCV block origin in x
   const int y0 = ty * TH;  // 270 == 3 * TH: every strip is full height
   uint8_t *dbase = cards + (size_t)frame * card_stride;
