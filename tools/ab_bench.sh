@@ -7,10 +7,12 @@ cd "$(dirname "$0")/.."
 FILE=$1; REPS=${2:-3}
 P=card.io-dmz_amd
 mkdir -p gpurun_out/ab
+# the Makefile's per-file flags
+EXTRA_FILE_FLAGS=""; case $FILE in vseg.hip|expiry.hip) EXTRA_FILE_FLAGS="-fno-slp-vectorize";; esac
 for V in head work; do
   SRC=$P/csrc/$FILE
   if [ $V == head ]; then cp $P/csrc/$FILE.head gpurun_out/ab/$FILE; SRC=gpurun_out/ab/$FILE; fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$P/csrc \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$P/csrc $EXTRA_FILE_FLAGS \
      -c $SRC -o gpurun_out/ab/$V.o 2>/dev/null
   OBJS=""
   for f in detect geometry warp vseg hseg digits expiry session plumbing synth capi weights_blob; do

@@ -5,7 +5,9 @@ cd "$(dirname "$0")/../.."
 P=card.io-dmz_amd
 FILE=$1; FLAGS=$2; SCRIPT=$3
 mkdir -p gpurun_out/variant
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude $FLAGS -c $P/csrc/$FILE -o gpurun_out/variant/x.o 2>/dev/null
+# the Makefile's per-file flags
+EXTRA_FILE_FLAGS=""; case $FILE in vseg.hip|expiry.hip) EXTRA_FILE_FLAGS="-fno-slp-vectorize";; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude $EXTRA_FILE_FLAGS $FLAGS -c $P/csrc/$FILE -o gpurun_out/variant/x.o 2>/dev/null
 OBJS=""
 for f in detect geometry warp vseg hseg digits expiry session plumbing synth capi weights_blob; do
   if [ "$f.hip" == "$FILE" ]; then OBJS="$OBJS gpurun_out/variant/x.o"; else OBJS="$OBJS $P/csrc/$f.o"; fi
