@@ -87,12 +87,12 @@ struct RowRaw {
 };
 
 // lane t (< 51) owns down-sampled outputs 4t..4t+3 = card columns 9+8t .. 20+8t of the row
+// (lanes 51 .. 63 repeat lane 50: their gradients then never change the row's minimum or maximum, and the feature pass needs no
+// "lane < 51" selects -- eight v_cndmask per row of a kernel that lives on its instruction count)
 __device__ __forceinline__ RowRaw vseg_row_load(const uint8_t *__restrict__ row, int lane) {
-  RowRaw r = {0u, 0u, 0u};
-  if (lane < 51) {
-    const uint32_t *p = (const uint32_t *)(row + 8 + 8 * lane);
-    r.w0 = p[0]; r.w1 = p[1]; r.w2 = p[2];
-  }
+  RowRaw r;
+  const uint32_t *p = (const uint32_t *)(row + 8 + 8 * (lane < 50 ? lane : 50));
+  r.w0 = p[0]; r.w1 = p[1]; r.w2 = p[2];
   return r;
 }
 
@@ -115,7 +115,7 @@ __device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned cha
   }
   // replicate at the ROI ends: column 9 -> column 10 (lane 0), column 418 -> 417 (lane 50)
   if (lane == 0) b[1] = b[2];
-  if (lane == 50) b[10] = b[9];
+  if (lane >= 50) b[10] = b[9];
   int d[4];
   int vmin = 255, vmax = 0;
 #pragma unroll
@@ -124,12 +124,10 @@ __device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned cha
     const int g0 = max3i(a, bb, c) - min3i(a, bb, c);  // grad[2o]
     const int g1 = max3i(bb, c, e) - min3i(bb, c, e);  // grad[2o+1]
     d[m] = (g0 + g1 + 1) >> 1;
-    if (lane < 51) {
-      vmin = imin(vmin, d[m]);
-      vmax = imax(vmax, d[m]);
-    }
+    vmin = imin(vmin, d[m]);
+    vmax = imax(vmax, d[m]);
   }
-  // (lanes >= 51 hold the identities 255 / 0)
+  // (lanes >= 51 hold lane 50's values)
   vmin = 255 - (int)dmzwave::max_u32((unsigned)(255 - vmin));
   vmax = (int)dmzwave::max_u32((unsigned)vmax);
   if (lane < 56)  // lanes 51..55 write the zero k-tail 204..223
