@@ -88,6 +88,7 @@ EXPORTS = (
     "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
     "dmz_hip_gather_records", "dmz_hip_gather_wait", "dmz_hip_expiry_sort_positions",
     "dmz_hip_categorize_expiry_groups_batch", "dmz_hip_scharr3_dx_abs", "dmz_hip_best_n_hseg_batch",
+    "dmz_hip_debug_fill_lds",
 )
 
 
@@ -165,6 +166,7 @@ def load_library():
     lib.dmz_hip_apply_digit_model.argtypes = [vp, i, vp, i, vp]
     lib.dmz_hip_synth_frames.argtypes = [vp, u64, u64, i, vp]
     lib.dmz_hip_synth_cards.argtypes = [vp, u64, u64, i, vp]
+    lib.dmz_hip_debug_fill_lds.argtypes = [vp, C.c_uint32]
     lib.dmz_hip_set_profiling.argtypes = [vp, i]
     lib.dmz_hip_get_stage_times.argtypes = [vp, vp, vp, i]
     lib.dmz_hip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -423,6 +425,9 @@ class Context:
 
     def synth_frames(self, seed, first, n, y_dev):
         self._check(self.lib.dmz_hip_synth_frames(self.h, seed, first, n, _ptr(y_dev)))
+
+    def debug_fill_lds(self, word=0xFFFFFFFF):
+        self._check(self.lib.dmz_hip_debug_fill_lds(self.h, word))
 
     def synth_cards(self, seed, first, n, cards_dev):
         self._check(self.lib.dmz_hip_synth_cards(self.h, seed, first, n, _ptr(cards_dev)))

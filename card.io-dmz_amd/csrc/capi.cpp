@@ -1740,6 +1740,14 @@ int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_inde
   return run_synth(ctx, 1, seed, first_index, n, cards);
 }
 
+int dmz_hip_debug_fill_lds(dmz_hip_context *ctx, uint32_t word) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dmz_launch_fill_lds(ctx->stream, word);
+  HIP_TRY(ctx, hipGetLastError());
+  return DMZ_HIP_OK;
+}
+
 int dmz_hip_set_profiling(dmz_hip_context *ctx, int enabled) {
   if (!ctx) return DMZ_HIP_EINVAL;
   ctx->profiling = enabled != 0;

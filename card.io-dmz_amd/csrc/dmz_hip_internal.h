@@ -88,6 +88,7 @@ struct DmzWarpMat {
   int valid;
   int pad_;
   DmzWarpWin win[DMZ_WARP_STRIPS];
+  double alpha_x, alpha_y;  // 32 M1 / M7, 32 M4 / M7 (k_warp_windows; read by strips with the affine flag, warp.hip)
 };
 
 // Expiry path.  Per (frame, stripe) staging written by k_expiry_seg and merged, in stripe order,
@@ -201,6 +202,7 @@ size_t dmz_synth_params_bytes(int n);
 int dmz_synth_upload_params(hipStream_t s, uint64_t seed, uint64_t first, int n, void *scratch);
 void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *y);
 void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards);
+void dmz_launch_fill_lds(hipStream_t s, uint32_t word);
 void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* dmzx layout */,
                        const DmzExpiryTables *tables, const uint8_t *cards, size_t card_stride, int n,
                        const dmz_hip_frame_result *results, DmzExpiryStage *stage /* n x 3 */,

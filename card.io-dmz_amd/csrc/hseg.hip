@@ -32,6 +32,8 @@
 
 namespace {
 
+constexpr int kHsegG = 428 + 164;  // the normalised gradient sums + the zero padding the masked tail reads reach (k_hseg)
+
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int max5(int a, int b, int c, int d, int e) { return imax(imax(a, b), imax(imax(c, d), e)); }
@@ -490,7 +492,12 @@ __device__ __forceinline__ void hseg_pass_filtered(const float *__restrict__ g, 
 #endif
 __global__ __launch_bounds__(64, DMZ_HSEG_WAVES) void k_hseg(const uint8_t *__restrict__ cards, size_t card_stride,
                                               int n, dmz_hip_frame_result *__restrict__ results) {
-  __shared__ float g[428 + 64];
+  // g[0 .. 427] + zero padding.  hseg_score_t's tail loops read up to g[c_k + wave_max(len) + 2]: the segment length is
+  // the WAVE's maximum, so a lane whose last digit starts at column <= 408 reads up to 408 + (428 - 256) + 2 = 582 when
+  // another lane's last digit starts at 256 (the leftmost a 15-digit pattern admits).  Those terms are multiplied by a zero
+  // mask INSIDE an fma -- exact only for finite operands -- so every word such a read can reach is allocated and zeroed here
+  // (reads past the allocation would see a previous workgroup's leftovers: NaN bit patterns poison the sum).
+  __shared__ float g[kHsegG];
   // the filter's table W[c][L - 16]; its first 428 words hold the integer column sums until g is built
   __shared__ __attribute__((aligned(16))) float W[428 * 4];
   int *colsum = (int *)W;
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(64, DMZ_HSEG_WAVES) void k_hseg(const uint8_t *__re
     const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.;
     const double shift = 0.0 - smin * scale;
     const float fs = (float)scale, fb = (float)shift;
-    for (int c = lane; c < 428 + 64; c += 64) g[c] = c < 428 ? (float)colsum[c] * fs + fb : 0.0f;
+    for (int c = lane; c < kHsegG; c += 64) g[c] = c < 428 ? (float)colsum[c] * fs + fb : 0.0f;
   }
   __syncthreads();
 

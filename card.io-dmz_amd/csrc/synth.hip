@@ -250,6 +250,17 @@ __global__ __launch_bounds__(256) void k_synth_cards(const SynthParams *__restri
   *(uint32_t *)(cards + (size_t)f * (428 * 270) + (size_t)v * 428 + u0) = packed;
 }
 
+// test utility: every CU's LDS is overwritten with `word` (a kernel that reads LDS it did not write sees it afterwards)
+__global__ __launch_bounds__(1024) void k_fill_lds(uint32_t word, uint32_t *__restrict__ sink) {
+  __shared__ uint32_t lds[16384];  // 64 KiB, the largest static allocation: two to three workgroups cover a CU's 160 KiB
+  for (int i = threadIdx.x; i < 16384; i += 1024) lds[i] = word;
+  __syncthreads();
+  // (the stores must not be eliminated; the spin keeps workgroups resident together so that all of a CU's LDS is claimed)
+  uint32_t acc = 0;
+  for (int r = 0; r < 64; r++) acc += lds[(threadIdx.x * 17 + r * 1031) & 16383];
+  if (acc == 0x12345u && sink) sink[0] = acc;
+}
+
 }  // namespace
 
 // Host side: derive the per-frame parameters, upload, launch.  `scratch` must hold
@@ -273,4 +284,8 @@ void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *
 void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards) {
   hipLaunchKernelGGL(k_synth_cards, dim3(113u * (unsigned)n), dim3(256), 0, s,
                      (const SynthParams *)params, n, cards);
+}
+
+void dmz_launch_fill_lds(hipStream_t s, uint32_t word) {
+  hipLaunchKernelGGL(k_fill_lds, dim3(256u * 16u), dim3(1024), 0, s, word, (uint32_t *)nullptr);
 }

@@ -32,6 +32,8 @@
 // Strips whose window exceeds the LDS buffer or whose W changes sign (extreme caller-supplied
 // matrices) take the direct global path.  Blocks are renumbered so that all strips of a
 // frame run on one XCD (block b is dispatched to XCD b % 8) and share its L2.
+#include <type_traits>
+
 #include "dmz_hip_internal.h"
 
 namespace {
@@ -64,6 +66,12 @@ constexpr int kWaves = DMZ_WARP_WAVES, kThreads = 64 * kWaves;
 constexpr int kStageRows = kThreads / 32;  // window rows staged per pass (a thread = one dword column)
 constexpr int kStagePasses = (LH + kStageRows - 1) / kStageRows;  // (a partial last pass is guarded)
 constexpr int kFastFlag = 1 << 16;  // DmzWarpWin.wrows: the strip admits the extrapolated reciprocal (k_warp)
+constexpr int kAffFlag = 1 << 17;   // ... and the coordinates as an affine function of that reciprocal (k_warp)
+constexpr int kLinFlag = 1 << 18;   // ... or (hardly any perspective down a column) the reciprocal itself is linear in the row
+// developer A/B (tools/ab.sh): 0 = the numerators advance by recurrence (rounds 2 - 4), 1 = affine in the reciprocal
+#ifndef DMZ_WARP_AFFINE
+#define DMZ_WARP_AFFINE 1
+#endif
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -144,6 +152,11 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
     const int x = tx * TW, y0 = ty * TH;
     const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                  M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
+    const double sW = M7 * 0.03125, ax = M1 / sW, ay = M4 / sW;  // (frame-uniform: strip 0 stores them)
+    if (tile == 0) {
+      mats[frame].alpha_x = ax;
+      mats[frame].alpha_y = ay;
+    }
     int bx0 = 1 << 20, bx1 = -(1 << 20), by0 = 1 << 20, by1 = -(1 << 20), npos = 0, nneg = 0;
     double wmin = 1e300;  // min |W| over the strip: W is linear, so it is at a corner
     for (int c = 0; c < 4; c++) {
@@ -169,8 +182,23 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
     if ((npos == 4 || nneg == 4) && wcols <= LWMAX && w.wrows <= LH) {
       const bool interior = aligned && w.wx0 >= 0 && w.wx0 + 4 * wdw <= sw && w.wy0 >= 0 && w.wy0 + w.wrows <= sh;
       w.wdw = interior ? wdw : -wdw;
-      // relative change of W per card row <= 2^-11: the reciprocal may be extrapolated along rows
-      if (fabs(M7) * 2048.0 <= wmin) w.wrows |= kFastFlag;
+      // relative change of W per card row rho <= 2^-11: the reciprocal may be extrapolated along rows (k_warp's fast forms)
+      if (fabs(M7) * 2048.0 <= wmin) {
+#if DMZ_WARP_AFFINE
+        // Down a column X = X_a + M1 dj and Wd = Wd_a + sW dj (sW = M7 / 32), so X / Wd = alpha + (X_a - alpha Wd_a) / Wd
+        // with alpha = M1 / sW: the numerators need no recurrence.  The price: an error eps of the reciprocal enters as
+        // |alpha| eps instead of |X / Wd| eps, so |alpha| is bounded (k_warp's error budget).  Where there is hardly any
+        // perspective down a column (rho <= 2^-24; M7 == 0 included) the reciprocal itself is linear in the row to
+        // (29 rho)^2 <= 2^-38 instead.  The two cover every fast strip: |alpha| = 32 |M / W| / rho with 32 |M / W| <= 64
+        // (the window bounds the slope) is <= 2^30 wherever rho > 2^-24; a strip that fails both takes the exact loop.
+        if (fabs(M7) * 16777216.0 <= wmin)
+          w.wrows |= kFastFlag | kLinFlag;
+        else if (fabs(ax) <= 1073741824.0 && fabs(ay) <= 1073741824.0)  // 2^30 (NaN fails)
+          w.wrows |= kFastFlag | kAffFlag;
+#else
+        w.wrows |= kFastFlag;
+#endif
+      }
     }
   }
   mats[frame].win[tile] = w;
@@ -461,59 +489,126 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     double Xn, Yn, Wd, y1, y2;
   };
   const double dX2 = uniform(2.0 * M1), dY2 = uniform(2.0 * M4), dW2 = uniform(2.0 * sW);
-  auto fast_xy = [&](Chain &c, uint32_t &Xl, uint32_t &Yl) {
-    const double yn = newton(c.Wd, __builtin_fma(2.0, c.y1, -c.y2));
-    c.y2 = c.y1;
-    c.y1 = yn;
-    // (v_fma_f64 spelled out: the compiler picks the two-address v_fmac_f64 here and pays a 64-bit
-    // register copy of the addend per pixel)
-    double fx, fy;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fx) : "v"(c.Xn), "v"(yn), "s"(magicXf));
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fy) : "v"(c.Yn), "v"(yn), "s"(magicYf));
-    Xl = (uint32_t)__double2loint(fx);
-    Yl = (uint32_t)__double2loint(fy);
-    c.Xn += dX2;
-    c.Yn += dY2;
-    c.Wd += dW2;
-  };
-  Chain cA, cB;
-  {
-    const RowXYW ra = s_row[a], rb = s_row[a + 1];
-    cA.Xn = ra.X0 + A, cA.Yn = ra.Y0 + B, cA.Wd = Wa, cA.y1 = yA1, cA.y2 = yA2;
-    cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C, cB.y1 = yB1, cB.y2 = yB2;
-  }
-#pragma unroll
-  for (int m = 0; m < kRows / 2; m++) {
-    const int j0 = a + 2 * m, j1 = j0 + 1;
-    uint32_t Xa, Ya, Xb, Yb, va, vb;
-    fast_xy(cA, Xa, Ya);
-    fast_xy(cB, Xb, Yb);
-    uint32_t lo16;
-    unsigned long long amb;
-    // (three two-operand v_min_u16: the 16-bit VOP2 forms issue at full rate on gfx950, the three-operand v_min3_u16 at a
-    // quarter of it -- profiles/r4_valu_table_gfx950.txt: 2.4 against 8.5 cycles)
-    asm("v_min_u16 %0, %2, %3\n\t"
-        "v_min_u16 %0, %0, %4\n\t"
-        "v_min_u16 %0, %0, %5\n\t"
-        "v_cmp_eq_u16 %1, 0, %0"
-        : "=&v"(lo16), "=s"(amb)
-        : "v"(Xa), "v"(Ya), "v"(Xb), "v"(Yb));
-    if (__builtin_expect(amb != 0, 0)) {
-      exact_xy(s_row[j0], Xa, Ya);
-      exact_xy(s_row[j1], Xb, Yb);
+  // The loop in two forms (AFF: the strip carries kAffFlag).
+  //   recurrences: fX = fma(Xn, y, magic'), Xn += 2 M1 -- 8 fp64 operations per pixel;
+  //   affine:      Xn = X_a + M1 dj and Wd = Wd_a + sW dj are both linear in the row, so Xn / Wd = alpha + beta / Wd with
+  //     alpha = M1 / sW (uniform over the frame, k_warp_windows) and beta = X_a - alpha Wd_a (per lane):
+  //     fX = fma(beta, y, magic' + alpha) -- no numerator recurrences, 6 fp64 operations per pixel.  magic' + alpha is rounded
+  //     to the adder's 2^-16 grid; beta is built from THAT alpha (aq = (magic' + alpha) - magic', exact), which leaves
+  //     |alpha - aq| dj sW y <= 2^-17 * 30 * 2^-11 of error instead of 2^-17.
+  //     Error budget of the cheap fX (units of 1/32 px; the filter needs < 2^-17, half a unit of the last kept bit):
+  //     an error eps of y now enters as |beta y| eps <= (|fX| + |alpha|) eps.  |alpha| = 32 |M1 / W| / rho and
+  //     32 |M1 / W| <= |dfX/dj| + |fX| rho <= 64 (the window bounds the slope), eps <= 225 rho^4 from the extrapolation:
+  //     14400 rho^3 <= 2^-19.2 at rho = 2^-11 (where |alpha| <= 2^17); at the other end, |alpha| <= 2^30 (rho ~ 2^-24), the
+  //     drift of the Wd recurrence (15 additions: 2^-49) and the rounding of the Newton step (2^-51) give 2^-19 + 2^-21;
+  //     the |fX| eps term as before: <= 2^-20.  Either way the sum is < 2^-18.
+  //   linear:      (kLinFlag: rho <= 2^-24, the nearly affine maps whose |alpha| is beyond the bound above)  1 / Wd down the
+  //     wave's rows is y_a (1 - u + u^2 - ...), u = rho' dj <= 29 * 2^-24: the linear part alone is within (29 rho)^2 <= 2^-38
+  //     -- y advances by a constant, no extrapolation, no Newton step: 5 fp64 operations per pixel.
+  auto run_fast = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool AFF = MODE == 1, LIN = MODE == 2;
+    double Kx = magicXf, Ky = magicYf, bx = 0., by = 0.;
+    Chain cA, cB;
+    {
+      const RowXYW ra = s_row[a], rb = s_row[a + 1];
+      cA.Xn = ra.X0 + A, cA.Yn = ra.Y0 + B, cA.Wd = Wa, cA.y1 = yA1, cA.y2 = yA2;
+      cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C, cB.y1 = yB1, cB.y2 = yB2;
     }
-    blend2(Xa, Ya, Xb, Yb, va, vb);
-    store_row(j0, va);
-    store_row(j1, vb);
-  }
-  if constexpr (kRows & 1) {
-    const int j = a + kRows - 1;
-    uint32_t Xa, Ya, va, vb;
-    fast_xy(cA, Xa, Ya);
-    if (__builtin_amdgcn_ballot_w64((Xa & 0xffffu) == 0u || (Ya & 0xffffu) == 0u)) exact_xy(s_row[j], Xa, Ya);
-    blend2(Xa, Ya, Xa, Ya, va, vb);
-    store_row(j, va);
-  }
+    if constexpr (AFF) {
+      Kx = uniform(magicXf + wm.alpha_x);
+      Ky = uniform(magicYf + wm.alpha_y);
+      const double aqx = uniform(Kx - magicXf), aqy = uniform(Ky - magicYf);
+      bx = __builtin_fma(-aqx, cA.Wd, cA.Xn);
+      by = __builtin_fma(-aqy, cA.Wd, cA.Yn);
+    }
+    if constexpr (LIN) {
+      // y at row a (two Newton steps from the neighbouring row's: (rho)^2, (rho)^4 -- exact to the last bits), its slope
+      // dy = -sW y_a^2; chain A starts at row a, chain B one row further (y2 holds the step of two rows)
+      double ya = newton(Wa, y1);
+      ya = newton(Wa, ya);
+      const double dy = -(sW * ya) * ya;
+      cA.y1 = ya, cB.y1 = ya + dy;
+      cA.y2 = cB.y2 = 2.0 * dy;
+    }
+    auto fast_xy = [&](Chain &c, uint32_t &Xl, uint32_t &Yl) {
+      double yn;
+      if constexpr (LIN) {
+        yn = c.y1;
+        c.y1 += c.y2;
+      } else {
+        yn = newton(c.Wd, __builtin_fma(2.0, c.y1, -c.y2));
+        c.y2 = c.y1;
+        c.y1 = yn;
+      }
+      // (v_fma_f64 spelled out: the compiler picks the two-address v_fmac_f64 here and pays a 64-bit
+      // register copy of the addend per pixel)
+      double fx, fy;
+      if constexpr (AFF) {
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fx) : "v"(bx), "v"(yn), "s"(Kx));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fy) : "v"(by), "v"(yn), "s"(Ky));
+      } else {
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fx) : "v"(c.Xn), "v"(yn), "s"(Kx));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(fy) : "v"(c.Yn), "v"(yn), "s"(Ky));
+        c.Xn += dX2;
+        c.Yn += dY2;
+      }
+      Xl = (uint32_t)__double2loint(fx);
+      Yl = (uint32_t)__double2loint(fy);
+      if constexpr (!LIN) c.Wd += dW2;
+    };
+#pragma unroll
+    for (int m = 0; m < kRows / 2; m++) {
+      const int j0 = a + 2 * m, j1 = j0 + 1;
+      uint32_t Xa, Ya, Xb, Yb, va, vb;
+      fast_xy(cA, Xa, Ya);
+      fast_xy(cB, Xb, Yb);
+      uint32_t lo16;
+      unsigned long long amb;
+      // (three two-operand v_min_u16: the 16-bit VOP2 forms issue at full rate on gfx950, the three-operand v_min3_u16 at a
+      // quarter of it -- profiles/r4_valu_table_gfx950.txt: 2.4 against 8.5 cycles)
+      asm("v_min_u16 %0, %2, %3\n\t"
+          "v_min_u16 %0, %0, %4\n\t"
+          "v_min_u16 %0, %0, %5\n\t"
+          "v_cmp_eq_u16 %1, 0, %0"
+          : "=&v"(lo16), "=s"(amb)
+          : "v"(Xa), "v"(Ya), "v"(Xb), "v"(Yb));
+      if (__builtin_expect(amb != 0, 0)) {
+        exact_xy(s_row[j0], Xa, Ya);
+        exact_xy(s_row[j1], Xb, Yb);
+      }
+#ifdef DMZ_WARP_VERIFY  // developer check (tools/dev/warp_verify.sh): every cheap coordinate against the exact sequence
+      {
+        uint32_t Xe, Ye, Xf, Yf;
+        exact_xy(s_row[j0], Xe, Ye);
+        exact_xy(s_row[j1], Xf, Yf);
+        if ((Xe ^ Xa) >> 16 || (Ye ^ Ya) >> 16 || (Xf ^ Xb) >> 16 || (Yf ^ Yb) >> 16)
+          printf("WARP MISMATCH frame %d tile %d lane %d rows %d: %08x %08x %08x %08x exact %08x %08x %08x %08x mode %d\n", frame,
+                 tile, lane, j0, Xa, Ya, Xb, Yb, Xe, Ye, Xf, Yf, MODE);
+        if (logical == 0 && tid == 0 && m == 0) printf("warp verify active, mode %d\n", MODE);
+      }
+#endif
+      blend2(Xa, Ya, Xb, Yb, va, vb);
+      store_row(j0, va);
+      store_row(j1, vb);
+    }
+    if constexpr (kRows & 1) {
+      const int j = a + kRows - 1;
+      uint32_t Xa, Ya, va, vb;
+      fast_xy(cA, Xa, Ya);
+      if (__builtin_amdgcn_ballot_w64((Xa & 0xffffu) == 0u || (Ya & 0xffffu) == 0u)) exact_xy(s_row[j], Xa, Ya);
+      blend2(Xa, Ya, Xa, Ya, va, vb);
+      store_row(j, va);
+    }
+  };
+#if DMZ_WARP_AFFINE
+  if (ww.wrows & kAffFlag)
+    run_fast(std::integral_constant<int, 1>{});
+  else
+    run_fast(std::integral_constant<int, 2>{});
+#else
+  run_fast(std::integral_constant<int, 0>{});
+#endif
 }
 
 }  // namespace

@@ -343,6 +343,10 @@ int dmz_hip_synth_frames(dmz_hip_context *ctx, uint64_t seed, uint64_t first_ind
 int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n,
                         uint8_t *cards);
 
+/* Test utility: overwrite the LDS of every CU with `word` (asynchronous, on the context's stream).  A kernel that reads
+ * LDS words it never wrote sees them afterwards -- tests/test_gpu_hseg.py runs the scan behind 0xFFFFFFFF (a NaN pattern). */
+int dmz_hip_debug_fill_lds(dmz_hip_context *ctx, uint32_t word);
+
 /* Per-stage device timing with hipEvents on the context's stream. */
 #define DMZ_HIP_STAGE_DETECT 0
 #define DMZ_HIP_STAGE_GEOMETRY 1

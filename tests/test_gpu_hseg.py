@@ -119,3 +119,36 @@ def test_best_n_hseg_on_device_resident_buffers(ctx, pkg, oracle):
         assert got[i]["n_offsets"] == n_off and np.array_equal(got[i]["offsets"], offsets), i
         assert got[i]["hseg_score"].view(np.uint32) == np.float32(score).view(np.uint32), i
         assert got[i]["number_width"].view(np.uint32) == np.float32(width).view(np.uint32) and got[i]["pattern_offset"] == po, i
+
+
+def test_best_n_hseg_does_not_depend_on_lds_leftovers(ctx, pkg, oracle):
+    """The masked tail terms of a candidate's score are fma(|g|, 0, s): exact only for finite g, and the tail reads run up to
+    the WAVE's longest segment -- past column 427 into g's zero padding.  Words behind that padding would be leftovers of
+    whatever workgroup used the CU's LDS before: here every CU's LDS is filled with 0xFFFFFFFF (a NaN) and then with 0 in
+    front of the search; the records must not move, for both patterns, and equal the oracle's on a sample."""
+    n = 8192
+    dcards = ctx.alloc(n * pkg.CARD_BYTES)
+    ctx.synth_cards(SEED + 5, 0, n, dcards.ptr)
+    rng = np.random.default_rng(SEED + 5)
+    res = np.zeros(n, pkg.RESULT_DTYPE)
+    res["flags"] = pkg.FLAG_VSEG_OK
+    res["vseg_y_offset"] = rng.integers(0, 244, n)
+    res["pattern_type"] = 1 + (np.arange(n) % 2)
+    dres = ctx.alloc(n * res.dtype.itemsize)
+    got = []
+    for word in (0xFFFFFFFF, 0x00000000, 0x7F800000):  # NaN, zero, +Inf
+        dres.upload(res.view(np.uint8))
+        ctx.debug_fill_lds(word)
+        ctx.best_n_hseg(dcards.ptr, n, dres.ptr)
+        ctx.synchronize()
+        got.append(dres.download(pkg.RESULT_DTYPE, n))
+    for other in got[1:]:
+        assert np.array_equal(got[0].view(np.uint8), other.view(np.uint8))
+    cards = dcards.download(np.uint8).reshape(n, 270, 428)
+    for i in range(0, n, 128):
+        y, p = int(res["vseg_y_offset"][i]), int(res["pattern_type"][i])
+        n_off, offsets, score, width, po = oracle.best_n_hseg(cards[i][y:y + 27], p)
+        g = got[0][i]
+        assert g["n_offsets"] == n_off and np.array_equal(g["offsets"], offsets), i
+        assert g["hseg_score"].view(np.uint32) == np.float32(score).view(np.uint32), i
+        assert g["number_width"].view(np.uint32) == np.float32(width).view(np.uint32) and g["pattern_offset"] == po, i

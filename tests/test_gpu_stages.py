@@ -98,6 +98,39 @@ def test_warp_generic_path_matrices_byte_exact(ctx, pkg, oracle):
         assert np.array_equal(cards[i], want), (i, int((cards[i] != want).sum()))
 
 
+def test_warp_perspective_strength_sweep_byte_exact(ctx, pkg, oracle):
+    """k_warp's cheap coordinate forms are chosen per strip from rho = |M7| / |W|, the relative change of the projective
+    denominator per card row (warp.hip, k_warp_windows): 1 / W linear in the row below 2^-24, the coordinates affine in the
+    extrapolated reciprocal up to 2^-11, the exact sequence beyond.  Trapezoids whose top edge is inset by 10^-5 .. 60 px
+    walk rho through all of it (and across both thresholds), with shear / rotation / sub-pixel offsets on top, over noise
+    frames (a coordinate that is off by 1/32 px changes the byte)."""
+    rng = np.random.default_rng(77)
+    dst = np.array([0, 0, 427, 0, 0, 269, 427, 269], np.float32)
+    insets = np.concatenate([[0.0], np.logspace(-5, np.log10(60.0), 47)])
+    quads = []
+    for k, e in enumerate(insets):
+        x0, y0 = 106 + rng.uniform(-20, 20), 105 + rng.uniform(-20, 20)
+        w, h = 427 * rng.uniform(0.8, 1.2), 269 * rng.uniform(0.8, 1.2)
+        q = np.array([x0 + e, y0, x0 + w - e, y0, x0, y0 + h, x0 + w, y0 + h])  # tl, tr, bl, br
+        if k % 3 == 1:   # shear
+            q[[0, 2]] += rng.uniform(-25, 25)
+        if k % 3 == 2:   # small rotation about the quad's centre
+            a = np.deg2rad(rng.uniform(-6, 6))
+            c = q.reshape(4, 2) - [x0 + w / 2, y0 + h / 2]
+            q = (c @ np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]]) + [x0 + w / 2, y0 + h / 2]).reshape(8)
+        if k % 4 == 3:   # the perspective across the card instead of down it
+            q = np.array([x0, y0 + e, x0 + w, y0, x0, y0 + h - e, x0 + w, y0 + h])
+        quads.append(q.astype(np.float32))
+    n = len(quads)
+    mats = np.stack([oracle.calc_persp_transform(q, dst) for q in quads])
+    frames = rng.integers(0, 256, (n, 480, 640), dtype=np.uint8)
+    cards = np.full((n, 270, 428), 0xA5, np.uint8)
+    ctx.warp_perspective(frames, n, mats, cards)
+    for i in range(n):
+        want = oracle.warp_perspective(frames[i], mats[i])
+        assert np.array_equal(cards[i], want), (i, float(insets[i]), int((cards[i] != want).sum()))
+
+
 def test_scan_prewarped_cards(ctx, pkg, oracle):
     """BASELINE configs[2]: vseg/hseg/categorise on pre-warped 428x270 crops."""
     n = 40
