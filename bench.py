@@ -356,6 +356,8 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="units (frames / crops) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the configs[1] / configs[2] lines that follow the headline steps at N = 1 (`side_configs`)")
     ap.add_argument("--corpus", choices=("cards", "mixed"), default="cards",
                     help="cards: every frame shows a card (the metric's corpus); mixed: 40 %% card-less, 10 %% upside-down, "
                          "50 %% cards (config 4 only; a second line for the gated throughput, not the headline metric)")
@@ -599,6 +601,35 @@ def main():
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
 
+    # BASELINE configs[1] and configs[2] under the same clock (N = 1, default workload only): after the headline steps, 20
+    # steps each of the detect-only entry on the first 4 096 frames and of the digit pass on 65 536 synthetic pre-warped crops
+    # (generated into the card buffer, which the headline steps no longer need), same context, same timing discipline.
+    side = None
+    if world == 1 and args.config == 4 and args.corpus == "cards" and B >= CONFIGS[2]["batch"] and not args.no_side_configs:
+        side = {}
+        side_res = torch.zeros((B, 1024), dtype=torch.uint8, device=dev)
+        ctx.synth_cards(SEED, lo, B, cards)
+        for cid, call, units in ((2, lambda: ctx.detect(frames, CONFIGS[2]["batch"], side_res), CONFIGS[2]["batch"]),
+                                 (3, lambda: ctx.scan_cards(cards, B, side_res, only_warped=False), B)):
+            for _ in range(2):
+                call()
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ts = time.perf_counter()
+            e0.record(stream)
+            for _ in range(20):
+                call()
+            e1.record(stream)
+            sync()
+            wall = time.perf_counter() - ts
+            c = CONFIGS[cid]
+            rate = units * 20 / wall
+            side[c["name"]] = {"metric": c["metric"], "value": round(rate, 1), "unit": c["unit"] + "/s", "units_per_step": units,
+                               "steps": 20, "ms_per_step": round(wall / 20 * 1e3, 4), "device_ms_per_step": round(e0.elapsed_time(e1) / 20, 4),
+                               "algorithmic_bytes_per_unit": c["bytes"],
+                               "frac_of_hbm": round(rate * c["bytes"] / 1e9 / HBM_PEAK_GBPS, 5)}
+        del side_res
+
     # per-kernel durations with hipEvents on the launch stream (untimed extra steps)
     ctx.set_profiling(True)
     ctx.stage_times(reset=True)
@@ -762,6 +793,15 @@ def main():
             "roofline": roof,
             "stages": per_stage,
         }
+        if side:
+            out["side_configs"] = side
+        if pmc_tag:
+            # (which fields are counters of a committed profile, not of this run)
+            out["counters_from"] = {"profile": pmc_tag,
+                                    "fields": "hbm_*_B_per_unit, traffic*, valu_*, mfma_busy_frac, roofline.traffic / valu_issue and "
+                                              "an mfma-bound roofline.frac come from profiles/%s_pmc_* (rocprofv3 --pmc passes of the "
+                                              "same kernels at the batch in the file names), not from this run; ms / GBps / TFLOPs / "
+                                              "achieved are measured live" % pmc_tag}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -21,6 +21,7 @@ struct SynthParams {
   uint8_t digits[16];
   int ex0, ey0, epitch;
   uint8_t exp_digits[4];
+  int kind;  // 0: 16 digits 4-4-4-4; 1: 15 digits 4-6-5, prefix 34 / 37
 };
 
 uint64_t splitmix64(uint64_t *s) {
@@ -99,6 +100,20 @@ void make_params(uint64_t seed, uint64_t frame, SynthParams *p) {
   p->exp_digits[1] = (uint8_t)(month % 10);
   p->exp_digits[2] = (uint8_t)(year / 10);
   p->exp_digits[3] = (uint8_t)(year % 10);
+  // the card kind: the last draw (orc_synth.c)
+  p->kind = (splitmix64(&s) % 10) == 0;
+  if (p->kind) {
+    p->digits[0] = 3;
+    p->digits[1] = (p->digits[1] & 1) ? 7 : 4;
+    sum = 0;
+    for (int i = 0; i < 14; i++) {
+      int d = p->digits[i];
+      if (i & 1) { d *= 2; d = d % 10 + d / 10; }
+      sum += d;
+    }
+    p->digits[14] = (uint8_t)((10 - sum % 10) % 10);
+    p->digits[15] = 0;
+  }
 }
 
 __constant__ short c_seg[7][4] = {
@@ -155,8 +170,8 @@ __device__ int card_delta(const SynthParams &p, int U, int V) {
     const int rx = U - p.x0;
     if (rx >= -32) {
       const int slot = (rx + 32) / p.pitch;
-      if (slot < 19 && (slot % 5) != 4) {
-        const int di = slot - slot / 5;
+      if (p.kind ? (slot < 17 && slot != 4 && slot != 11) : (slot < 19 && (slot % 5) != 4)) {
+        const int di = p.kind ? slot - (slot > 4) - (slot > 11) : slot - slot / 5;
         const int lx = rx - slot * p.pitch;
         const int segs = c_digit_segs[p.digits[di]];
         const int c0 = stroke_cov(segs, lx, ry);

@@ -478,111 +478,132 @@ void scanner_add_frame(ScannerState *state, IplImage *y, FrameScanResult *result
 static bool g_allow_past_expiry = false;
 void dmz_hip_host_allow_past_expiry(bool allow) { g_allow_past_expiry = allow; }
 
-// expiry_categorize.cpp:162-228
+// ---- cross-frame aggregation of the expiry groups: the BEHAVIOUR of expiry_categorize.cpp:256-445, in this file's own
+// structure (the device's batched form of the same policy is session.hip) ----
+namespace {
+
+// two groups are "the same place on the card" when their origins are within half a character box and they hold the
+// same number of characters
+inline bool same_place(int top, int left, size_t n_chars, const GroupedRects &g) {
+  return abs(g.top - top) <= GROUPED_RECTS_VERTICAL_ALLOWANCE && abs(g.left - left) <= GROUPED_RECTS_HORIZONTAL_ALLOWANCE &&
+         g.character_rects.size() == n_chars;
+}
+
+// dst = (dst * wa + src * wb) / div, element by element in float, in that association (div == 1: no division)
+inline void blend_scores(ExpiryGroupScores &dst, float wa, const ExpiryGroupScores &src, float wb, float div) {
+  float *d = &dst.v[0][0];
+  const float *q = &src.v[0][0];
+  for (int i = 0; i < kExpiryMaxValidLength * 10; i++) {
+    const float t = d[i] * wa + q[i] * wb;
+    d[i] = div == 1.0f ? t : t / div;
+  }
+}
+
+template <class T>
+void drop_marked(std::vector<T> &v, const std::vector<char> &gone) {
+  size_t w = 0;
+  for (size_t r = 0; r < v.size(); r++)
+    if (!gone[r]) {
+      if (w != r) v[w] = v[r];
+      w++;
+    }
+  v.resize(w);
+}
+
+}  // namespace
+
 void expiry_aggregate_grouped_rects(GroupedRectsList &aggregated_groups, GroupedRectsList &new_groups) {
-  // coalesce equivalent groups within new_groups
-  for (size_t i1 = 0; i1 < new_groups.size(); i1++) {
-    GroupedRects &group1 = new_groups[i1];
-    const int top1 = group1.top, left1 = group1.left;
-    const size_t n1 = group1.character_rects.size();
-    float coalesced = 1;
-    for (size_t i2 = new_groups.size() - 1; i2 > i1; i2--) {
-      GroupedRects &group2 = new_groups[i2];
-      if (abs(group2.top - top1) > GROUPED_RECTS_VERTICAL_ALLOWANCE ||
-          abs(group2.left - left1) > GROUPED_RECTS_HORIZONTAL_ALLOWANCE || group2.character_rects.size() != n1)
-        continue;
-      for (int r = 0; r < kExpiryMaxValidLength; r++)
-        for (int c = 0; c < 10; c++)
-          group1.scores.v[r][c] = ((group1.scores.v[r][c] * coalesced) + group2.scores.v[r][c]) / (coalesced + 1);
-      coalesced++;
-      new_groups.erase(new_groups.begin() + i2);
+  const size_t n_new = new_groups.size();
+  std::vector<char> merged(n_new, 0);  // a frame's group that went into another group
+  // 1. within the frame: the LATER groups at an earlier group's place fold into it, last one first, as a running mean
+  for (size_t keep = 0; keep < n_new; keep++) {
+    if (merged[keep]) continue;
+    GroupedRects &k = new_groups[keep];
+    const int top = k.top, left = k.left;
+    const size_t n_chars = k.character_rects.size();
+    float members = 1.0f;
+    for (size_t j = n_new; j-- > keep + 1;) {
+      if (merged[j] || !same_place(top, left, n_chars, new_groups[j])) continue;
+      blend_scores(k.scores, members, new_groups[j].scores, 1.0f, members + 1.0f);
+      members += 1.0f;
+      merged[j] = 1;
     }
   }
-  // coalesce new_groups with equivalent groups inside aggregated_groups
-  for (GroupedRectsList::iterator old_group = aggregated_groups.begin(); old_group != aggregated_groups.end(); ++old_group) {
-    const int old_top = old_group->top, old_left = old_group->left;
-    const size_t old_n = old_group->character_rects.size();
-    for (int ni = (int)new_groups.size() - 1; ni >= 0; ni--) {
-      GroupedRects &new_group = new_groups[ni];
-      if (abs(new_group.top - old_top) > GROUPED_RECTS_VERTICAL_ALLOWANCE ||
-          abs(new_group.left - old_left) > GROUPED_RECTS_HORIZONTAL_ALLOWANCE ||
-          new_group.character_rects.size() != old_n)
-        continue;
-      old_group->recently_seen_count++;
-      old_group->total_seen_count++;
-      for (int r = 0; r < kExpiryMaxValidLength; r++)
-        for (int c = 0; c < 10; c++)
-          old_group->scores.v[r][c] =
-              (old_group->scores.v[r][c] * kExpiryDecayFactor) + (new_group.scores.v[r][c] * (1 - kExpiryDecayFactor));
-      old_group->top = new_group.top;
-      old_group->left = new_group.left;
-      new_groups.erase(new_groups.begin() + ni);
+  // 2. into the session: every frame group at a session group's place (the place the session group had BEFORE this
+  // frame) refreshes it -- exponential decay of the scores, the origin follows the newest sighting
+  for (size_t o = 0; o < aggregated_groups.size(); o++) {
+    GroupedRects &old = aggregated_groups[o];
+    const int top = old.top, left = old.left;
+    const size_t n_chars = old.character_rects.size();
+    for (size_t j = n_new; j-- > 0;) {
+      if (merged[j] || !same_place(top, left, n_chars, new_groups[j])) continue;
+      old.recently_seen_count++;
+      old.total_seen_count++;
+      blend_scores(old.scores, kExpiryDecayFactor, new_groups[j].scores, 1 - kExpiryDecayFactor, 1.0f);
+      old.top = new_groups[j].top;
+      old.left = new_groups[j].left;
+      merged[j] = 1;
     }
   }
-  // forget aggregated groups that have not been seen for a while
-  for (int oi = (int)aggregated_groups.size() - 1; oi >= 0; oi--) {
-    aggregated_groups[oi].recently_seen_count--;
-    if (aggregated_groups[oi].recently_seen_count <= 0) aggregated_groups.erase(aggregated_groups.begin() + oi);
+  // 3. every session group ages by one frame; the ones not seen lately are forgotten
+  {
+    std::vector<char> stale(aggregated_groups.size(), 0);
+    for (size_t o = 0; o < aggregated_groups.size(); o++) stale[o] = --aggregated_groups[o].recently_seen_count <= 0;
+    drop_marked(aggregated_groups, stale);
   }
-  // add the new, non-equivalent groups
-  for (GroupedRectsList::iterator new_group = new_groups.begin(); new_group != new_groups.end(); ++new_group) {
-    GroupedRects fresh_group(*new_group);
-    fresh_group.recently_seen_count = 3;  // stick around for at least the next couple of frames
-    fresh_group.total_seen_count = 1;
-    aggregated_groups.push_back(fresh_group);
+  // 4. what is left of the frame's groups is new to the session: three frames of grace
+  drop_marked(new_groups, merged);
+  for (size_t j = 0; j < new_groups.size(); j++) {
+    aggregated_groups.push_back(new_groups[j]);
+    aggregated_groups.back().recently_seen_count = 3;
+    aggregated_groups.back().total_seen_count = 1;
   }
 }
 
-// expiry_categorize.cpp:230-286
-static void expiry_string_to_expiry_month_and_year(char *expiry_string, GroupedRects &group, int *expiry_month,
-                                                   int *expiry_year) {
-  int month = -1, year = -1;
-  if (group.pattern == ExpiryPatternMMsYY && expiry_string[0] != ' ' && expiry_string[1] != ' ' &&
-      expiry_string[3] != ' ' && expiry_string[4] != ' ') {
-    month = ((uint8_t)expiry_string[0] - (uint8_t)'0') * 10 + ((uint8_t)expiry_string[1] - (uint8_t)'0');
-    year = ((uint8_t)expiry_string[3] - (uint8_t)'0') * 10 + ((uint8_t)expiry_string[4] - (uint8_t)'0');
-  }
-  if (month > 12 && year > 0 && year <= 12) {  // YY/MM cards
-    const int temp = month;
-    month = year;
-    year = temp;
-  }
-  int full_year = year + 2000;
-  if (month > 0 && month <= 12 &&
-      (full_year > *expiry_year || ((full_year == *expiry_year) && month > *expiry_month))) {
-    time_t now = time(NULL);
-    struct tm *time_struct = localtime(&now);
-    const int current_year = time_struct->tm_year + 1900, current_month = time_struct->tm_mon + 1;
-    if (full_year < current_year + 5 &&
-        (full_year > current_year || (full_year == current_year && month >= current_month))) {
-      *expiry_month = month;
-      *expiry_year = full_year;
-    } else if (g_allow_past_expiry) {  // the DMZ_DEBUG || CYTHON_DMZ branch
-      if (year > 60) full_year = year + 1900;
-      if (full_year < current_year + 5) {
-        *expiry_month = month;
-        *expiry_year = full_year;
-      }
-    }
-  }
+namespace {
+
+// Is (month, two-digit year) a date to report, and better than the one already held?  Returns the four-digit year or 0.
+int acceptable_expiry_year(int month, int year2, int held_month, int held_year) {
+  if (month <= 0 || month > 12) return 0;
+  int year4 = year2 + 2000;
+  if (!(year4 > held_year || (year4 == held_year && month > held_month))) return 0;  // no later than the date held
+  const time_t now = time(NULL);
+  const struct tm *t = localtime(&now);
+  const int this_year = t->tm_year + 1900, this_month = t->tm_mon + 1;
+  const bool in_window = year4 < this_year + 5;
+  if (in_window && (year4 > this_year || (year4 == this_year && month >= this_month))) return year4;
+  if (!g_allow_past_expiry) return 0;
+  // test builds of the reference (DMZ_DEBUG || CYTHON_DMZ) also take dates in the past, two-digit years above 60 as 19YY
+  if (year2 > 60) year4 = year2 + 1900;
+  return year4 < this_year + 5 ? year4 : 0;
 }
 
-// expiry_categorize.cpp:288-330
+}  // namespace
+
 void get_stable_expiry_month_and_year(GroupedRects &group, int *expiry_month, int *expiry_year) {
-  char expiry_string[128];
-  memset(expiry_string, 0, sizeof(expiry_string));
-  for (uint8_t i = 0; i < group.character_rects.size(); i++) {
-    if (group.pattern == ExpiryPatternMMsYY && i == 2) continue;
+  // a character counts when its best class holds at least kExpiryMinStability of the row's score mass
+  int digit[kExpiryMaxValidLength];
+  for (int i = 0; i < kExpiryMaxValidLength; i++) digit[i] = -1;
+  const size_t n = group.character_rects.size() < (size_t)kExpiryMaxValidLength ? group.character_rects.size()
+                                                                                  : (size_t)kExpiryMaxValidLength;
+  for (size_t i = 0; i < n; i++) {
     const float *p = group.scores.v[i];
-    int best = 0;  // Eigen maxCoeff: first maximum
+    int best = 0;  // (first maximum, as Eigen's maxCoeff visits them)
     for (int k = 1; k < 10; k++)
       if (p[k] > p[best]) best = k;
-    // Eigen 10-element redux tree
-    const float sum = ((p[0] + p[1]) + (p[2] + (p[3] + p[4]))) + ((p[5] + p[6]) + (p[7] + (p[8] + p[9])));
-    const float stability = p[best] / sum;
-    expiry_string[i] = stability < kExpiryMinStability ? ' ' : (char)((uint8_t)'0' + (uint8_t)best);
+    // the row sum in the order of Eigen's ten-element reduction tree
+    const float mass = ((p[0] + p[1]) + (p[2] + (p[3] + p[4]))) + ((p[5] + p[6]) + (p[7] + (p[8] + p[9])));
+    if (!(p[best] / mass < kExpiryMinStability)) digit[i] = best;
   }
-  expiry_string_to_expiry_month_and_year(expiry_string, group, expiry_month, expiry_year);
+  if (group.pattern != ExpiryPatternMMsYY) return;  // the only pattern the reference reads (MM/YY; position 2 is the slash)
+  if (digit[0] < 0 || digit[1] < 0 || digit[3] < 0 || digit[4] < 0) return;
+  int month = digit[0] * 10 + digit[1], year2 = digit[3] * 10 + digit[4];
+  if (month > 12 && year2 > 0 && year2 <= 12) std::swap(month, year2);  // YY/MM cards
+  const int year4 = acceptable_expiry_year(month, year2, *expiry_month, *expiry_year);
+  if (year4 > 0) {
+    *expiry_month = month;
+    *expiry_year = year4;
+  }
 }
 
 // FrameScanResult.expiry_groups from the device record (expiry_seg.cpp:651-668 field values)

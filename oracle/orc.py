@@ -381,11 +381,12 @@ class Reference:
     """Partial build of the reference's own code (oracle/_ref/libdmzref.so); None if absent."""
 
     @staticmethod
-    def available():
-        return os.path.exists(os.path.join(HERE, "_ref", "libdmzref.so"))
+    def available(flavour=""):
+        return os.path.exists(os.path.join(HERE, "_ref", "libdmzref%s.so" % flavour))
 
-    def __init__(self):
-        self.lib = C.CDLL(os.path.join(HERE, "_ref", "libdmzref.so"))
+    def __init__(self, flavour=""):
+        """flavour "" = Eigen's scalar paths (what the oracle restates); "_vec" = a stock x86-64 build (SSE2 packet paths)"""
+        self.lib = C.CDLL(os.path.join(HERE, "_ref", "libdmzref%s.so" % flavour))
         L = self.lib
         L.ref_line_by_shifting_origin.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]
         L.ref_parametric_intersect.argtypes = [C.c_float] * 4 + [_f32p, _f32p]

@@ -6,8 +6,10 @@
  * Not derived from the reference (it ships no test images); the scene follows
  * noisy dark background, a bright card quad whose corners are
  * the guide-frame corners (dmz_constants.h:16-27 => (106,105)-(533,374)) plus a
- * per-corner jitter, 16 Luhn-valid digits in the 4-4-4-4 layout rendered as
- * soft-edged 7-segment strokes in the number band of the card.
+ * per-corner jitter, 16 Luhn-valid digits in the 4-4-4-4 layout -- or, for every
+ * tenth card or so, 15 digits in the 4-6-5 layout with prefix 34 / 37 (the second
+ * number pattern of n_vseg.cpp:26-31 / n_hseg.cpp) -- rendered as soft-edged
+ * 7-segment strokes in the number band of the card.
  *
  * Determinism contract: per-frame parameters come from splitmix64(seed, frame);
  * per-pixel noise from a 32-bit integer hash; the frame->card mapping is IEEE
@@ -30,6 +32,7 @@ typedef struct {
   int ex0, ey0;      /* card-space origin of the MM/YY line, 1/16 px */
   int epitch;        /* its character pitch, 1/16 px */
   uint8_t exp_digits[4]; /* M M Y Y */
+  int kind;          /* 0: 16 digits 4-4-4-4; 1: 15 digits 4-6-5 */
 } synth_params;
 
 static uint64_t splitmix64(uint64_t *s) {
@@ -116,6 +119,21 @@ static void make_params(uint64_t seed, uint64_t frame, synth_params *p) {
   p->exp_digits[1] = (uint8_t)(month % 10);
   p->exp_digits[2] = (uint8_t)(year / 10);
   p->exp_digits[3] = (uint8_t)(year % 10);
+  /* the card kind is the LAST draw, so that the 16-digit cards keep the bytes they had before the kind existed */
+  p->kind = (splitmix64(&s) % 10) == 0;
+  if (p->kind) {
+    /* 15 digits, prefix 34 / 37; Luhn: from the right every second digit doubled = the odd indices of a 15-digit PAN */
+    p->digits[0] = 3;
+    p->digits[1] = (p->digits[1] & 1) ? 7 : 4;
+    sum = 0;
+    for (int i = 0; i < 14; i++) {
+      int d = p->digits[i];
+      if (i & 1) { d *= 2; d = d % 10 + d / 10; }
+      sum += d;
+    }
+    p->digits[14] = (uint8_t)((10 - sum % 10) % 10);
+    p->digits[15] = 0;
+  }
 }
 
 /* 7 segments in a 17 x 25 px digit box, 1/16 px units: x0,y0,x1,y1 */
@@ -177,10 +195,10 @@ static int card_delta(const synth_params *p, int U, int V) {
   if (ry >= -32 && ry < 25 * 16 + 32) {
     int rx = U - p->x0;
     if (rx >= -32) {
-      /* 4-4-4-4 layout: slot index over 19 slots, slots 4, 9, 14 are gaps */
+      /* 4-4-4-4 layout: slot index over 19 slots, slots 4, 9, 14 are gaps; 4-6-5: 17 slots, gaps at 4 and 11 */
       int slot = (rx + 32) / p->pitch;
-      if (slot < 19 && (slot % 5) != 4) {
-        int di = slot - slot / 5;
+      if (p->kind ? (slot < 17 && slot != 4 && slot != 11) : (slot < 19 && (slot % 5) != 4)) {
+        int di = p->kind ? slot - (slot > 4) - (slot > 11) : slot - slot / 5;
         int lx = rx - slot * p->pitch;
         int segs = k_digit_segs[p->digits[di]];
         int c0 = stroke_cov(segs, lx, ry);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/pipeline_golden.npz: the ORACLE's outputs for eight seeded synthetic
+"""Writes tests/golden/pipeline_golden.npz: the ORACLE's outputs for twenty seeded synthetic
 frames (result records, expiry records, SHA-256 of each rectified card, one full card).  A regression
 guard for the oracle and a committed target for the GPU parity test; regenerate only when
 the oracle changes on purpose:  python tests/golden/make_pipeline_golden.py"""
@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 import orc  # noqa: E402
 
-SEED, N = 20261001, 8
+SEED, N = 20261001, 20  # (frame 18 is a 15-digit 4-6-5 card)
 
 
 def main():

@@ -6,6 +6,8 @@ import hashlib
 import numpy as np
 import pytest
 
+from test_gpu_parity_large import assert_parity, compare_sample_with_oracle
+
 pytestmark = pytest.mark.gpu
 SEED, N = 0xCA4D10, 65536
 
@@ -54,22 +56,12 @@ def test_full_batch_properties(ctx, pkg, oracle):
     ctx.scan_expiry(cards.ptr + lo * pkg.CARD_BYTES, m, part, exp_again)
     assert exp_again.tobytes() == x1[lo * xs:(lo + m) * xs].tobytes()
 
-    # 4. a random sample of the batch against the oracle
-    frames = None
-    for i in rng.choice(N, 48, replace=False):
-        i = int(i)
-        frame, _ = oracle.synth_frame(SEED, i)
-        want, wcard = oracle.scan_frame(frame)
-        g = rec[i]
-        assert np.array_equal(g["found"], want["found"]) and np.array_equal(g["corners"].view(np.uint32), want["corners"].view(np.uint32)), i
-        assert g["flags"] == want["flags"] and g["vseg_y_offset"] == want["vseg_y_offset"], i
-        assert np.array_equal(g["offsets"], want["offsets"]) and np.array_equal(g["digits"], want["digits"]), i
-        assert np.abs(g["scores"] - want["scores"]).max() <= 1e-4, i
-        we = oracle.scan_card_expiry(wcard, want)
-        ge = x1.view(pkg.EXPIRY_DTYPE)[i]
-        assert ge["n_found"] == we["n_found"] and ge["n_stripes"] == we["n_stripes"], i
-        k = int(we["n_groups"])
-        assert np.array_equal(ge["groups"]["char_left"][:k], we["groups"]["char_left"][:k]), i
+    # 4. a random sample of the batch against the oracle, through the sweeps' own frame comparison: detect bits (found, rho,
+    # theta, corners), every card byte, segmentation indices, hseg_score bits, scores, labels, flags, expiry records
+    sample = rng.choice(N, 48, replace=False)
+    stats = compare_sample_with_oracle(ctx, pkg, oracle, sample, lambda i: oracle.synth_frame(SEED, i)[0], rec,
+                                       x1.view(pkg.EXPIRY_DTYPE), cards)
+    assert_parity(stats, len(sample))
 
     # 5. gate statistics of the corpus stay where DESIGN.md reports them
     usable = float(((rec["flags"] & pkg.FLAG_USABLE) != 0).mean())
@@ -150,22 +142,14 @@ def test_config3_digit_pass_on_65536_prewarped_crops(ctx, pkg, oracle):
         assert small_exp[:m].tobytes() == x1[lo * xs:(lo + m) * xs].tobytes(), (lo, m)
     rec, xrec = r1.view(pkg.RESULT_DTYPE), x1.view(pkg.EXPIRY_DTYPE)
     rng = np.random.default_rng(9)
-    for i in rng.choice(n, 48, replace=False):
-        i = int(i)
-        card, _ = oracle.synth_card(SEED, i)
-        want = oracle.scan_card_image(card, warped=False)
-        g = rec[i]
-        assert g["flags"] == want["flags"] and g["vseg_y_offset"] == want["vseg_y_offset"], i
-        assert np.array_equal(g["offsets"], want["offsets"]) and np.array_equal(g["digits"], want["digits"]), i
-        assert g["hseg_score"].view(np.uint32) == want["hseg_score"].view(np.uint32), i
-        assert np.abs(g["scores"] - want["scores"]).max() <= 1e-4, i
-        we, ge = oracle.scan_card_expiry(card, want), xrec[i]
-        assert ge["n_found"] == we["n_found"] and ge["n_stripes"] == we["n_stripes"] and ge["categorised"] == we["categorised"], i
-        k = int(we["n_groups"])
-        assert np.array_equal(ge["groups"]["char_left"][:k], we["groups"]["char_left"][:k]), i
-        assert np.array_equal(ge["groups"]["char_top"][:k], we["groups"]["char_top"][:k]), i
-        if k:
-            assert np.abs(ge["groups"]["scores"][:k] - we["groups"]["scores"][:k]).max() <= 1e-4, i
+    sample = rng.choice(n, 48, replace=False)
+    # (the sweeps' frame comparison: segmentation indices, hseg_score bits, scores, labels, flags, expiry stripes / rects / scores)
+    stats = compare_sample_with_oracle(ctx, pkg, oracle, sample, lambda i: oracle.synth_card(SEED, i)[0], rec, xrec, None,
+                                       scan="cards")
+    assert_parity(stats, len(sample))
+    fifteen = int((((rec["flags"] & pkg.FLAG_VSEG_OK) != 0) & (rec["pattern_type"] == 2)).sum())
+    print("config 3: crops with the 15-digit pattern: %d" % fifteen)
+    assert fifteen > n // 40  # every tenth synthetic card is a 4-6-5 one (orc_synth.c), two thirds of them are read as such
     vseg_ok = float(((rec["flags"] & pkg.FLAG_VSEG_OK) != 0).mean())
     usable = float(((rec["flags"] & pkg.FLAG_USABLE) != 0).mean())
     print("config 3 gate rates: vseg_ok %.3f usable %.3f" % (vseg_ok, usable))
@@ -199,7 +183,8 @@ def test_mixed_corpus_of_the_bench_against_the_oracle(ctx, pkg, oracle):
     gexp = exp.download(pkg.EXPIRY_DTYPE, n)
     assert not got["found_all"][kind < 4].any()                                  # no card: detection stops the frame
     assert ((got["flags"][kind == 4] & pkg.FLAG_UPSIDE_DOWN) != 0).all()         # upside down: vseg stops it
-    assert ((got["flags"][kind > 4] & pkg.FLAG_VSEG_OK) != 0).all()
+    # (every tenth card is a 15-digit one, and a third of those are not read as such: the per-frame comparison below decides)
+    assert ((got["flags"][kind > 4] & pkg.FLAG_VSEG_OK) != 0).mean() > 0.9
     for i in range(n):
         w, wcard = oracle.scan_frame(host[i])
         g = got[i]

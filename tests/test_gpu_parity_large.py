@@ -54,6 +54,41 @@ def prove_vseg_near_tie(oracle, card, gy, gp, wy, wp):
     return False
 
 
+def new_stats():
+    """the counters _compare_frame fills"""
+    return dict(card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
+                label_diff=0, flag_diff=0, unexplained=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
+                expiry_slash_flips=0, max_expiry_err=0.0)
+
+
+def compare_sample_with_oracle(ctx, pkg, oracle, indices, frame_of, rec, expv, cards_buf, scan=None):
+    """the frames `indices` of a batch whose records (rec, expv) are on the host and whose cards are resident in cards_buf
+    (None: no card bytes), through the same frame-by-frame comparison as the sweeps: detect bits (rho / theta / corners),
+    card bytes, segmentation indices, hseg_score bits, scores, labels, expiry.  frame_of(i) -> the frame (or, with
+    scan = "cards", the pre-warped crop) the oracle scans.  Returns the counters."""
+    stats = new_stats()
+    for i in indices:
+        i = int(i)
+        if scan == "cards":
+            wcard = frame_of(i)
+            w = oracle.scan_card_image(wcard, warped=False)
+            g = rec[i].copy()
+            for f in ("found", "found_all", "rho", "theta", "corners"):  # a crop has no detection record
+                g[f] = w[f]
+        else:
+            w, wcard = oracle.scan_frame(frame_of(i))
+            g = rec[i]
+        we = oracle.scan_card_expiry(wcard, w)
+        if cards_buf is not None:
+            gcard = np.empty(pkg.CARD_BYTES, np.uint8)
+            ctx._check(ctx.lib.dmz_hip_memcpy_d2h(ctx.h, gcard.ctypes.data, cards_buf.ptr + i * pkg.CARD_BYTES, gcard.nbytes))
+            gcard = gcard.reshape(270, 428)
+        else:
+            gcard = wcard
+        _compare_frame(pkg, oracle, stats, g, expv[i], gcard, w, wcard, we)
+    return stats
+
+
 def compare_with_oracle(ctx, pkg, oracle, y, n):
     """Full pipeline on the n frames resident in `y` against the oracle, frame by frame; returns the counters."""
     res = ctx.alloc(n * 1024)
@@ -67,9 +102,7 @@ def compare_with_oracle(ctx, pkg, oracle, y, n):
                  vseg_ok=int(((got["flags"] & pkg.FLAG_VSEG_OK) != 0).sum()) if hasattr(pkg, "FLAG_VSEG_OK") else -1,
                  # frames the 15-digit pattern won (n_vseg.cpp:26-30): the second instantiation of the hseg score, a 15-digit categorise
                  amex_like=int((((got["flags"] & pkg.FLAG_VSEG_OK) != 0) & (got["pattern_type"] == 2)).sum()),
-                 card_bytes_diff=0, det_diff=0, ties=0, idx_diff=0, max_score_err=0.0, max_vseg_err=0.0,
-                 label_diff=0, flag_diff=0, unexplained=0, expiry_frames=0, expiry_groups=0, expiry_seg_diff=0,
-                 expiry_slash_flips=0, max_expiry_err=0.0)
+                 **new_stats())
     nthreads = max(1, min(64, (os.cpu_count() or 2) // 2))
 
     def slice_to_host(buf, first, count, item_bytes):  # frames / cards of one chunk (a sweep's whole batch is tens of GB)
@@ -161,7 +194,7 @@ def _compare_frame(pkg, oracle, stats, g, ge, gcard, w, wcard, we):
             stats["max_expiry_err"] = max(stats["max_expiry_err"], float(np.abs(a["scores"] - b["scores"]).max()))
 
 
-def assert_parity(stats, n, min_expiry_frames=0):
+def assert_parity(stats, n, min_expiry_frames=0, max_ties=2):
     """the bars of DESIGN.md section 4 on one run's counters"""
     assert stats["det_diff"] == 0 and stats["card_bytes_diff"] == 0 and stats["idx_diff"] == 0, stats
     assert stats["max_score_err"] <= 1e-4 and stats["max_vseg_err"] <= 1e-4, stats
@@ -170,6 +203,9 @@ def assert_parity(stats, n, min_expiry_frames=0):
     # ... and proven near-ties of two votes / of the usable gate are rare events (measured: <= 1 per 65 536 corpus frames);
     # a regression that produced many "provable" ones must not pass
     assert stats["label_diff"] <= max(2, n // 2048) and stats["flag_diff"] <= max(2, n // 2048), stats
+    # ... and so are proven near-ties of two segmentations: none in 3 x 131 072 corpus frames, one per ~450 fuzz frames
+    # (garbage cards have flat vseg scores; the fuzz test passes its own bound)
+    assert stats["ties"] <= max_ties, stats
     assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4, stats
     assert stats["expiry_frames"] >= min_expiry_frames, stats
 
@@ -239,5 +275,6 @@ def test_fuzz_frames_against_oracle(ctx, pkg, oracle):
     stats = compare_with_oracle(ctx, pkg, oracle, y, n)
     y.free()
     print("fuzz parity stats over %d frames: %s" % (n, stats))
-    # garbage cards have flat vseg scores: near-ties (each one proven within 1e-4) are more frequent here
-    assert_parity(stats, n)
+    # garbage cards have flat vseg scores: near-ties (each one proven within 1e-4) are more frequent here -- measured 74 - 75
+    # per 33 600 frames (profiles/r4_*sweep*.log); the bound is about twice that rate
+    assert_parity(stats, n, max_ties=max(2, n // 256))

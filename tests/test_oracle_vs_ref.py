@@ -289,3 +289,63 @@ def test_card_rect_for_screen_matches_reference(oracle, reference):
         got = np.zeros(4, np.int32)
         oracle.lib.orc_card_rect_for_screen(*a, got.ctypes.data_as(C.POINTER(C.c_int)))
         assert list(got) == list(want), a
+
+
+def test_eigen_flavour_gap_report(oracle, reference, orc):
+    """REPORT (nothing but sanity is asserted): how far is the reference as a stock x86-64 build compiles it (Eigen 3.2.4
+    with its SSE2 packet paths: eigen.h defines no EIGEN_DONT_VECTORIZE) from the -DEIGEN_DONT_VECTORIZE flavour that the
+    oracle restates and the device reproduces bit for bit?  Per corpus frame: the float[9] of llcv_calc_persp_transform
+    (cv/warp.cpp:34-125, float Householder QR of an ill-conditioned 8 x 8) from both builds on the oracle's corners, each
+    pushed through the oracle's warp and scan.  DESIGN.md section 3 quotes the printed figures."""
+    import os
+    if not orc.Reference.available("_vec"):
+        pytest.skip("oracle/_ref/libdmzref_vec.so not built (make -C oracle ref, build container only)")
+    vec = orc.Reference("_vec")
+    assert vec.pass_kats() == reference.pass_kats()
+    n = int(os.environ.get("DMZ_FLAVOUR_FRAMES", "300"))
+    dst = reference.card_dest_points()
+    seed = 0xCA4D10
+    rel_max, mats_differ, cards_differ, bytes_max, bytes_sum, level_max = 0.0, 0, 0, 0, 0, 0
+    idx_changes = label_changes = flag_changes = frames = 0
+    for i in range(n):
+        frame, _ = oracle.synth_frame(seed, i)
+        w, wcard = oracle.scan_frame(frame)
+        if not w["found_all"]:
+            continue
+        frames += 1
+        c = w["corners"].astype(np.float32)
+        src = np.array([c[0], c[1], c[4], c[5], c[2], c[3], c[6], c[7]], np.float32)  # tl, tr, bl, br (dmz.cpp:446-471)
+        ms, mv = reference.calc_persp_transform(src, dst), vec.calc_persp_transform(src, dst)
+        assert np.array_equal(ms.view(np.uint32), oracle.calc_persp_transform(src, dst).view(np.uint32)), i
+        card_s = oracle.warp_perspective(frame, ms)
+        assert np.array_equal(card_s, wcard), i  # the scalar flavour IS the oracle's card
+        if np.array_equal(ms.view(np.uint32), mv.view(np.uint32)):
+            continue
+        mats_differ += 1
+        # element-wise, over the elements that are not cancellation residue (a shear term of 1e-9 beside a scale of 1)
+        rows = np.abs(ms.reshape(3, 3)).max(axis=1, keepdims=True).repeat(3, axis=1).reshape(9)
+        nz = np.abs(ms) > 1e-3 * rows
+        rel_max = max(rel_max, float(np.abs((mv[nz] - ms[nz]) / ms[nz]).max()))
+        card_v = oracle.warp_perspective(frame, mv)
+        d = card_v != card_s
+        if d.any():
+            cards_differ += 1
+            bytes_max = max(bytes_max, int(d.sum()))
+            bytes_sum += int(d.sum())
+            level_max = max(level_max, int(np.abs(card_v.astype(int) - card_s.astype(int)).max()))
+            rv = oracle.scan_card_image(card_v)
+            if (rv["vseg_y_offset"] != w["vseg_y_offset"] or rv["pattern_type"] != w["pattern_type"]
+                    or not np.array_equal(rv["offsets"], w["offsets"])):
+                idx_changes += 1
+            elif not np.array_equal(rv["digits"], w["digits"]):
+                label_changes += 1
+            if (rv["flags"] & 7) != (w["flags"] & 7):
+                flag_changes += 1
+    print("\nEigen flavour gap over %d corpus frames (scalar = oracle = device; vec = stock x86-64 build of the reference):" % frames)
+    print("  homography float[9] differs on %d frames, max relative difference %.3g (%.0f ulp)" % (
+        mats_differ, rel_max, rel_max / 2.0 ** -23))
+    print("  rectified cards with differing bytes: %d (mean %.1f, max %d bytes of 115 560; up to %d grey levels)" % (
+        cards_differ, bytes_sum / max(1, cards_differ), bytes_max, level_max))
+    print("  downstream: %d frames change a segmentation index, %d a digit label, %d a flag" % (
+        idx_changes, label_changes, flag_changes))
+    assert frames > n // 2 and rel_max < 1e-3
