@@ -33,6 +33,7 @@ SCAN_ONLY_WARPED, SCAN_SKIP_NUMBER = 1, 2
 EXPIRY_CONV_F32, EXPIRY_CONV_BF16X3, EXPIRY_CONV_BF16, EXPIRY_CONV_F16X3 = 0, 1, 2, 3
 OPT_TRUNCATE_CORNERS = 1
 OPT_UPSAMPLE = 2
+OPT_EIGEN_SSE2 = 4
 STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
 
 # mirror of struct dmz_hip_frame_result (include/dmz_hip.h), 1024 bytes
@@ -88,7 +89,7 @@ EXPORTS = (
     "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
     "dmz_hip_gather_records", "dmz_hip_gather_wait", "dmz_hip_expiry_sort_positions",
     "dmz_hip_categorize_expiry_groups_batch", "dmz_hip_scharr3_dx_abs", "dmz_hip_best_n_hseg_batch",
-    "dmz_hip_debug_fill_lds",
+    "dmz_hip_debug_fill_lds", "dmz_hip_set_reference_flavour",
 )
 
 
@@ -167,6 +168,7 @@ def load_library():
     lib.dmz_hip_synth_frames.argtypes = [vp, u64, u64, i, vp]
     lib.dmz_hip_synth_cards.argtypes = [vp, u64, u64, i, vp]
     lib.dmz_hip_debug_fill_lds.argtypes = [vp, C.c_uint32]
+    lib.dmz_hip_set_reference_flavour.argtypes = [vp, i]
     lib.dmz_hip_set_profiling.argtypes = [vp, i]
     lib.dmz_hip_get_stage_times.argtypes = [vp, vp, vp, i]
     lib.dmz_hip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -425,6 +427,10 @@ class Context:
 
     def synth_frames(self, seed, first, n, y_dev):
         self._check(self.lib.dmz_hip_synth_frames(self.h, seed, first, n, _ptr(y_dev)))
+
+    def set_reference_flavour(self, flavour):
+        """0: Eigen's scalar order (default); 1: a stock x86-64 build's SSE2 order (DMZ_HIP_OPT_EIGEN_SSE2)"""
+        self._check(self.lib.dmz_hip_set_reference_flavour(self.h, flavour))
 
     def debug_fill_lds(self, word=0xFFFFFFFF):
         self._check(self.lib.dmz_hip_debug_fill_lds(self.h, word))

@@ -55,6 +55,7 @@ struct dmz_hip_context {
   Buf patches;  // equalised digit patches between k_digit_patches and k_digits (digits.hip)
 
   int expiry_conv = DMZ_HIP_EXPIRY_CONV_F16X3;
+  int default_options = 0;  // dmz_hip_set_reference_flavour: OR-ed into the options of the transform / pipeline calls
 
   // multi-GPU (dmz_hip_comm_* / dmz_hip_gather_*): the communicator, its own queue, and the events that order it
   void *comm = nullptr;  // ncclComm_t
@@ -415,7 +416,7 @@ int run_transform(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_strid
   if (rc) return rc;
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_GEOMETRY);
-    dmz_launch_homography(ctx->stream, n, orientation, options, results, (DmzWarpMat *)ctx->mats.p);
+    dmz_launch_homography(ctx->stream, n, orientation, options | ctx->default_options, results, (DmzWarpMat *)ctx->mats.p);
   }
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_WARP);
@@ -1009,6 +1010,13 @@ int dmz_hip_set_two_queues(dmz_hip_context *ctx, int enable) {
   return DMZ_HIP_OK;
 }
 
+int dmz_hip_set_reference_flavour(dmz_hip_context *ctx, int flavour) {
+  if (!ctx) return DMZ_HIP_EINVAL;
+  if (flavour != 0 && flavour != 1) return fail(ctx, DMZ_HIP_EINVAL, "unknown reference flavour");
+  ctx->default_options = flavour ? DMZ_HIP_OPT_EIGEN_SSE2 : 0;
+  return DMZ_HIP_OK;
+}
+
 int dmz_hip_set_expiry_conv(dmz_hip_context *ctx, int mode) {
   if (!ctx) return DMZ_HIP_EINVAL;
   if (mode != DMZ_HIP_EXPIRY_CONV_F32 && mode != DMZ_HIP_EXPIRY_CONV_BF16X3 && mode != DMZ_HIP_EXPIRY_CONV_BF16 &&
@@ -1578,7 +1586,7 @@ int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts, con
   float *d = (float *)ctx->misc.p;
   HIP_TRY(ctx, hipMemcpyAsync(d, src_pts, sizeof(float) * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d + 8, dst_pts, sizeof(float) * 8, hipMemcpyHostToDevice, ctx->stream));
-  dmz_launch_persp(ctx->stream, 1, d, d + 8, d + 16);
+  dmz_launch_persp(ctx->stream, 1, d, d + 8, d + 16, ctx->default_options);
   HIP_TRY(ctx, hipMemcpyAsync(m, d + 16, sizeof(float) * 9, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DMZ_HIP_OK;

@@ -158,7 +158,7 @@ void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params_by_
                          dmz_hip_frame_result *results);
 void dmz_launch_homography(hipStream_t s, int n, int orientation, int options,
                            dmz_hip_frame_result *results, DmzWarpMat *mats);
-void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9);
+void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9, int options);
 void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMat *mats);
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,

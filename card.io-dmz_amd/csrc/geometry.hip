@@ -28,16 +28,50 @@ namespace {
 // indexed a[] dynamically and kept it in scratch memory (272 B per lane) -- slow, and the one kernel of the library whose
 // result depended on private-segment memory: with other queues' kernels in flight beside it, one 64-byte scratch line (one
 // matrix element of 16 consecutive frames) came back wrong about once in ten 65 536-frame runs (round 5, tools/dev/determinism.py).
+// SSE = the summation order of a stock x86-64 build of the reference (Eigen's SSE2 packet paths; DMZ_HIP_OPT_EIGEN_SSE2): the
+// three reductions -- tail.squaredNorm(), every coefficient of essential^T * bottom, and the inner products of Q^T b -- are
+// linear vectorised sums whose packets start at element 0: the first four terms as (x0 + x2) + (x1 + x3), the rest one by
+// one; fewer than four terms sequentially (oracle/orc_cv.c gives the Eigen source lines; pinned on the reference's build).
+template <bool SSE, int N>
+__device__ __forceinline__ float eigen_redux(const float (&x)[7]) {
+  float r;
+  if (SSE && N >= 4) {
+    r = (x[0] + x[2]) + (x[1] + x[3]);
+#pragma unroll
+    for (int i = 4; i < N; i++) r = r + x[i];
+  } else {
+    r = x[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) r = r + x[i];
+  }
+  return r;
+}
+// (N is a compile-time constant once k is: dispatch on the unrolled loop's counter)
+template <bool SSE>
+__device__ __forceinline__ float eigen_redux_n(const float (&x)[7], int n) {
+  switch (n) {
+    case 1: return eigen_redux<SSE, 1>(x);
+    case 2: return eigen_redux<SSE, 2>(x);
+    case 3: return eigen_redux<SSE, 3>(x);
+    case 4: return eigen_redux<SSE, 4>(x);
+    case 5: return eigen_redux<SSE, 5>(x);
+    case 6: return eigen_redux<SSE, 6>(x);
+    default: return eigen_redux<SSE, 7>(x);
+  }
+}
+
+template <bool SSE>
 __device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
   float hcoef[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int rem = 8 - k;
     float tail_sq = 0.0f;
+    if (rem > 1) {
+      float sq[7];
 #pragma unroll
-    for (int i = 1; i < rem; i++) {
-      float v = QA(k + i, k);
-      tail_sq = tail_sq + v * v;
+      for (int i = 1; i < rem; i++) sq[i - 1] = QA(k + i, k) * QA(k + i, k);
+      tail_sq = eigen_redux_n<SSE>(sq, rem - 1);
     }
     const float c0 = QA(k, k);
     float tau, beta;
@@ -61,9 +95,10 @@ __device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
 #pragma unroll
       for (int c = 0; c < rcols; c++) {
         const int col = k + 1 + c;
-        float tmp = 0.0f;
+        float pr[7];
 #pragma unroll
-        for (int i = 1; i < rem; i++) tmp = tmp + QA(k + i, k) * QA(k + i, col);
+        for (int i = 1; i < rem; i++) pr[i - 1] = QA(k + i, k) * QA(k + i, col);
+        float tmp = eigen_redux_n<SSE>(pr, rem - 1);
         tmp = tmp + QA(k, col);
         QA(k, col) = QA(k, col) - tau * tmp;
 #pragma unroll
@@ -78,9 +113,10 @@ __device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
     if (rem == 1) {
       b[k] = b[k] * (1.0f - tau);
     } else {
-      float tmp = 0.0f;
+      float pr[7];
 #pragma unroll
-      for (int i = 1; i < rem; i++) tmp = tmp + QA(k + i, k) * b[k + i];
+      for (int i = 1; i < rem; i++) pr[i - 1] = QA(k + i, k) * b[k + i];
+      float tmp = eigen_redux_n<SSE>(pr, rem - 1);
       tmp = tmp + b[k];
       b[k] = b[k] - tau * tmp;
 #pragma unroll
@@ -95,6 +131,7 @@ __device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
   }
 }
 
+template <bool SSE>
 __device__ __forceinline__ void calc_persp_transform(const float *sp, const float *dp, float *m) {
   float a[64], b[8];
 #pragma unroll
@@ -108,7 +145,7 @@ __device__ __forceinline__ void calc_persp_transform(const float *sp, const floa
     b[i] = dx;
     b[i + 4] = dy;
   }
-  householder_qr_solve8(a, b);
+  householder_qr_solve8<SSE>(a, b);
   m[0] = b[0]; m[1] = b[1]; m[2] = b[2];
   m[3] = b[3]; m[4] = b[4]; m[5] = b[5];
   m[6] = b[6]; m[7] = b[7]; m[8] = 1.0f;
@@ -201,6 +238,7 @@ __global__ __launch_bounds__(64) void k_geometry(int n, const DmzDetectParams *_
 
 // dmz_transform_card's part before the warp: corners -> source points -> float
 // homography -> inverse double matrix (dmz.cpp:446-471, warp.cpp:153-165).
+template <bool SSE>
 __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int options,
                              dmz_hip_frame_result *__restrict__ results,
                              DmzWarpMat *__restrict__ mats) {
@@ -238,7 +276,7 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
     const float rw = (float)(DMZ_CARD_WIDTH - 1), rh = (float)(DMZ_CARD_HEIGHT - 1);
     dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f + rw; dp[3] = 0.0f;
     dp[4] = 0.0f; dp[5] = 0.0f + rh; dp[6] = 0.0f + rw; dp[7] = 0.0f + rh;
-    calc_persp_transform(sp, dp, m);
+    calc_persp_transform<SSE>(sp, dp, m);
     // Evaluated again until two consecutive results agree bit for bit.  Round 5 measured why: with another queue's kernels
     // (the expiry CNN of a previous frame chunk) in flight beside this kernel, about once per 65 536 frames one quarter-wave
     // (always lanes 48..63) came out of this register-to-register computation with a wrong matrix from the right corners; a
@@ -251,7 +289,7 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
         sp2[i] = sp[i];
         asm volatile("" : "+v"(sp2[i]));  // (not the same value to the compiler: the second evaluation is not folded into the first)
       }
-      calc_persp_transform(sp2, dp, m2);
+      calc_persp_transform<SSE>(sp2, dp, m2);
       bool same = true;
       for (int i = 0; i < 9; i++) same = same && (__float_as_uint(m2[i]) == __float_as_uint(m[i]));
       for (int i = 0; i < 9; i++) m[i] = m2[i];
@@ -265,6 +303,7 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
   mats[f] = wm;
 }
 
+template <bool SSE>
 __global__ __launch_bounds__(64) void k_persp(int n, const float *__restrict__ src_pts, const float *__restrict__ dst_pts,
                         float *__restrict__ m9) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,7 +313,7 @@ __global__ __launch_bounds__(64) void k_persp(int n, const float *__restrict__ s
     sp[i] = src_pts[f * 8 + i];
     dp[i] = dst_pts[f * 8 + i];
   }
-  calc_persp_transform(sp, dp, m);
+  calc_persp_transform<SSE>(sp, dp, m);
   for (int i = 0; i < 9; i++) m9[f * 9 + i] = m[i];
 }
 
@@ -300,12 +339,17 @@ void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params, co
 
 void dmz_launch_homography(hipStream_t s, int n, int orientation, int options,
                            dmz_hip_frame_result *results, DmzWarpMat *mats) {
-  hipLaunchKernelGGL(k_homography, dim3((n + 63) / 64), dim3(64), 0, s, n, orientation, options,
-                     results, mats);
+  if (options & DMZ_HIP_OPT_EIGEN_SSE2)
+    hipLaunchKernelGGL(k_homography<true>, dim3((n + 63) / 64), dim3(64), 0, s, n, orientation, options, results, mats);
+  else
+    hipLaunchKernelGGL(k_homography<false>, dim3((n + 63) / 64), dim3(64), 0, s, n, orientation, options, results, mats);
 }
 
-void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9) {
-  hipLaunchKernelGGL(k_persp, dim3((n + 63) / 64), dim3(64), 0, s, n, src_pts, dst_pts, m9);
+void dmz_launch_persp(hipStream_t s, int n, const float *src_pts, const float *dst_pts, float *m9, int options) {
+  if (options & DMZ_HIP_OPT_EIGEN_SSE2)
+    hipLaunchKernelGGL(k_persp<true>, dim3((n + 63) / 64), dim3(64), 0, s, n, src_pts, dst_pts, m9);
+  else
+    hipLaunchKernelGGL(k_persp<false>, dim3((n + 63) / 64), dim3(64), 0, s, n, src_pts, dst_pts, m9);
 }
 
 void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMat *mats) {

@@ -107,6 +107,12 @@ typedef struct dmz_hip_expiry_result {
 #define DMZ_HIP_OPT_TRUNCATE_CORNERS 1 /* cast corner points to int like cython_dmz/dmz.pyx:267-270 */
 #define DMZ_HIP_OPT_UPSAMPLE 2         /* dmz_transform_card(upsample = true), dmz.cpp:473-481: the plane is a
                                           half-size Cb/Cr plane, the corner points are halved */
+#define DMZ_HIP_OPT_EIGEN_SSE2 4       /* llcv_calc_persp_transform's float Householder QR (warp.cpp:34-125) in the summation
+                                          order of a STOCK x86-64 build of the reference (Eigen 3.2.4's SSE2 packet paths; eigen.h
+                                          defines no EIGEN_DONT_VECTORIZE).  Default (bit clear): Eigen's scalar order, what the
+                                          reference's non-NEON ARM builds and -DEIGEN_DONT_VECTORIZE compute.  The two differ in
+                                          the last bits of the homography on three frames of four, hence in ~15 bytes of such a
+                                          card.  Also a context default: dmz_hip_set_reference_flavour. */
 
 typedef struct dmz_hip_context dmz_hip_context;
 
@@ -297,6 +303,10 @@ int dmz_hip_blur_cards_batch(dmz_hip_context *ctx, uint8_t *rgb, size_t card_str
  * src_pts/dst_pts: 4 (x,y) pairs; m: 9 floats row-major (host pointers). */
 int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts,
                                  const float *dst_pts, float *m);
+/* Which build of the reference the context reproduces bit for bit where the two differ (today: the homography, see
+ * DMZ_HIP_OPT_EIGEN_SSE2): 0 = Eigen's scalar paths (default), 1 = a stock x86-64 build (SSE2 packets).  The choice is OR-ed
+ * into the options of every later transform / pipeline call of the context and applies to dmz_hip_calc_persp_transform. */
+int dmz_hip_set_reference_flavour(dmz_hip_context *ctx, int flavour);
 /* Batched cvWarpPerspective as used by llcv_unwarp (warp.cpp:153-166) with
  * caller-supplied 3x3 float matrices (n x 9, row-major). */
 int dmz_hip_warp_perspective_batch(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_stride,

@@ -117,6 +117,8 @@ int orc_detect_edges(const uint8_t *y, int y_stride, int w, int h,
                      int orientation, orc_frame_result *res);
 /* warp.cpp:34-125 (row-major 3x3) */
 void orc_calc_persp_transform(const float src_pts[8], const float dst_pts[8], float m[9]);
+/* ... in the summation order of a stock x86-64 (SSE2 packet) build of the reference's Eigen (orc_cv.c) */
+void orc_calc_persp_transform_sse(const float src_pts[8], const float dst_pts[8], float m[9]);
 /* cvWarpPerspective(INTER_LINEAR|FILL_OUTLIERS, 0), SURVEY Appendix A10 */
 void orc_warp_perspective(const uint8_t *src, int stride, int sw, int sh,
                           const float m[9], uint8_t *dst, int dstride, int dw, int dh);

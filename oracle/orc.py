@@ -147,11 +147,11 @@ class Oracle:
                                       res.ctypes.data_as(C.c_void_p))
         return res[0]
 
-    def calc_persp_transform(self, src_pts, dst_pts):
+    def calc_persp_transform(self, src_pts, dst_pts, sse=False):
         s = np.ascontiguousarray(src_pts, np.float32).reshape(8)
         d = np.ascontiguousarray(dst_pts, np.float32).reshape(8)
         m = np.empty(9, np.float32)
-        self.lib.orc_calc_persp_transform(_p(s, _f32p), _p(d, _f32p), _p(m, _f32p))
+        (self.lib.orc_calc_persp_transform_sse if sse else self.lib.orc_calc_persp_transform)(_p(s, _f32p), _p(d, _f32p), _p(m, _f32p))
         return m
 
     def warp_perspective(self, src, m, dw=428, dh=270):

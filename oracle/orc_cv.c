@@ -406,20 +406,50 @@ int orc_detect_edges(const uint8_t *y, int y_stride, int w, int h, const uint8_t
 /* warp.cpp:34-125: A x = b by Eigen 3.2.4 HouseholderQR<Matrix8f> (compute():
  * one 8-wide block => householder_qr_inplace_unblocked, HouseholderQR.h:219-250;
  * solve(): apply H_0..H_7 to b then back-substitute, HouseholderQR.h:306-334).
- * Scalar (EIGEN_DONT_VECTORIZE) evaluation order; storage is column-major. */
+ * Storage is column-major.  Two evaluation orders (`sse`):
+ *   0  scalar (EIGEN_DONT_VECTORIZE): every reduction is a sequential sum -- what the reference's ARM builds without NEON
+ *      compute and what the device reproduces by default;
+ *   1  the order of a stock x86-64 build (eigen.h defines no EIGEN_DONT_VECTORIZE: SSE2 packets).  Only the REDUCTIONS
+ *      differ, everything element-wise gives the same bits in packets.  There are three, all evaluated as
+ *      <expression>.sum() = a linear vectorised redux (Redux.h:202-245): tail.squaredNorm() in makeHouseholder
+ *      (Householder.h:74); every coefficient of essential^T * bottom in applyHouseholderOnTheLeft (Householder.h:125) --
+ *      in compute() a coefficient-based product (product_type_selector<1, Small, Small>: a block of an 8 x 8 matrix has
+ *      MaxSize 8) whose dynamic-size coefficient is (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum()
+ *      (CoeffBasedProduct.h), in solve() GeneralProduct<InnerProduct> on the right-hand side vector
+ *      (GeneralProduct.h:159-166).  None of the summed expressions has direct access, so first_aligned() is 0 and the
+ *      packets start at element 0 (unaligned loads): for n >= 4 terms (n <= 7 here) the first four are ONE Packet4f,
+ *      predux = (x0 + x2) + (x1 + x3) (SSE2, PacketMath.h: movehl + add, shuffle + add_ss), the terms 4 .. n-1 follow
+ *      one by one; n < 4 terms are summed sequentially.  The triangular solve is one 8-wide panel of element-wise updates.
+ *      Pinned on oracle/_ref/libdmzref_vec.so stage by stage (matrixQR, hCoeffs, Q^T b, x) and end to end,
+ *      tests/test_oracle_vs_ref.py. */
 #define QA(r, c) a[(c) * 8 + (r)]
 
-static void orc_householder_qr_solve8(float *a /* col-major 8x8, destroyed */, float *b) {
+/* sum of x[0 .. n-1] in the order of the flavour */
+static float orc_eigen_redux(const float *x, int n, int sse) {
+  float r;
+  int i;
+  if (sse && n >= 4) {
+    r = (x[0] + x[2]) + (x[1] + x[3]);
+    i = 4;
+  } else {
+    r = x[0];
+    i = 1;
+  }
+  for (; i < n; i++) r = r + x[i];
+  return r;
+}
+
+static void orc_householder_qr_solve8(float *a /* col-major 8x8, destroyed */, float *b, int sse) {
   float hcoef[8];
   for (int k = 0; k < 8; k++) {
     const int rem = 8 - k; /* remainingRows */
     /* makeHouseholderInPlace on a(k..7, k)  (Householder.h:65-93) */
-    float tail_sq = 0.0f;
+    float tail_sq = 0.0f, terms[8];
     for (int i = 1; i < rem; i++) {
       float v = QA(k + i, k);
-      float p = v * v;
-      tail_sq = (i == 1) ? p : tail_sq + p;
+      terms[i - 1] = v * v;
     }
+    if (rem > 1) tail_sq = orc_eigen_redux(terms, rem - 1, sse);
     float c0 = QA(k, k);
     float tau, beta;
     if (rem == 1 || tail_sq == 0.0f) {
@@ -443,11 +473,9 @@ static void orc_householder_qr_solve8(float *a /* col-major 8x8, destroyed */, f
       } else {
         for (int c = 0; c < rcols; c++) {
           const int col = k + 1 + c;
-          float tmp = 0.0f;
-          for (int i = 1; i < rem; i++) {
-            float p = QA(k + i, k) * QA(k + i, col);
-            tmp = (i == 1) ? p : tmp + p;
-          }
+          float prod[8];
+          for (int i = 1; i < rem; i++) prod[i - 1] = QA(k + i, k) * QA(k + i, col);
+          float tmp = orc_eigen_redux(prod, rem - 1, sse);
           tmp += QA(k, col);
           QA(k, col) -= tau * tmp;
           for (int i = 1; i < rem; i++) QA(k + i, col) -= (tau * QA(k + i, k)) * tmp;
@@ -462,11 +490,9 @@ static void orc_householder_qr_solve8(float *a /* col-major 8x8, destroyed */, f
     if (rem == 1) {
       b[k] *= (1.0f - tau);
     } else {
-      float tmp = 0.0f;
-      for (int i = 1; i < rem; i++) {
-        float p = QA(k + i, k) * b[k + i];
-        tmp = (i == 1) ? p : tmp + p;
-      }
+      float terms[8];
+      for (int i = 1; i < rem; i++) terms[i - 1] = QA(k + i, k) * b[k + i];
+      float tmp = orc_eigen_redux(terms, rem - 1, sse);
       tmp += b[k];
       b[k] -= tau * tmp;
       for (int i = 1; i < rem; i++) b[k + i] -= (tau * QA(k + i, k)) * tmp;
@@ -479,7 +505,12 @@ static void orc_householder_qr_solve8(float *a /* col-major 8x8, destroyed */, f
   }
 }
 
-void orc_calc_persp_transform(const float sp[8], const float dp[8], float m[9]) {
+static void orc_calc_persp_transform_order(const float sp[8], const float dp[8], float m[9], int sse);
+void orc_calc_persp_transform(const float sp[8], const float dp[8], float m[9]) { orc_calc_persp_transform_order(sp, dp, m, 0); }
+/* the same in the summation order of a stock x86-64 (SSE2) build of the reference */
+void orc_calc_persp_transform_sse(const float sp[8], const float dp[8], float m[9]) { orc_calc_persp_transform_order(sp, dp, m, 1); }
+
+static void orc_calc_persp_transform_order(const float sp[8], const float dp[8], float m[9], int sse) {
   float a[64], b[8];
   for (int i = 0; i < 4; i++) {
     const float sx = sp[2 * i], sy = sp[2 * i + 1], dx = dp[2 * i], dy = dp[2 * i + 1];
@@ -491,7 +522,7 @@ void orc_calc_persp_transform(const float sp[8], const float dp[8], float m[9]) 
     b[i] = dx;
     b[i + 4] = dy;
   }
-  orc_householder_qr_solve8(a, b);
+  orc_householder_qr_solve8(a, b, sse);
   m[0] = b[0]; m[1] = b[1]; m[2] = b[2];
   m[3] = b[3]; m[4] = b[4]; m[5] = b[5];
   m[6] = b[6]; m[7] = b[7]; m[8] = 1.0f;

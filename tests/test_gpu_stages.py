@@ -42,6 +42,47 @@ def test_homography_bit_exact(ctx, oracle):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_homography_in_the_sse2_order_of_a_stock_x86_build(ctx, pkg, oracle):
+    """DMZ_HIP_OPT_EIGEN_SSE2 / dmz_hip_set_reference_flavour(1): the device's Householder QR in the summation order of the
+    reference as a stock x86-64 build compiles it (the oracle's second order is pinned on that build,
+    tests/test_oracle_vs_ref.py) -- single homographies through dmz_hip_calc_persp_transform, and the whole chain: the
+    pipeline's cards equal the oracle's warp with the SSE2-order matrix, and differ from the default-order cards."""
+    rng = np.random.default_rng(41)
+    dst = np.array([0, 0, 427, 0, 0, 269, 427, 269], np.float32)
+    base = np.array([106, 105, 533, 105, 106, 374, 533, 374], np.float32)
+    try:
+        ctx.set_reference_flavour(1)
+        for k in range(300):
+            src = base + rng.uniform(-12, 12, 8).astype(np.float32)
+            got = ctx.calc_persp_transform(src, dst)
+            want = oracle.calc_persp_transform(src, dst, sse=True)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, got, want)
+        n = 48
+        y = ctx.alloc(n * pkg.FRAME_BYTES)
+        res, cards = ctx.alloc(n * 1024), ctx.alloc(n * pkg.CARD_BYTES)
+        ctx.synth_frames(SEED + 3, 0, n, y.ptr)
+        ctx.pipeline(y.ptr, n, res.ptr, cards.ptr)
+        ctx.synchronize()
+        sse_cards = cards.download(np.uint8).reshape(n, 270, 428)
+        got = res.download(pkg.RESULT_DTYPE, n)
+    finally:
+        ctx.set_reference_flavour(0)
+    ctx.pipeline(y.ptr, n, res.ptr, cards.ptr)
+    ctx.synchronize()
+    default_cards = cards.download(np.uint8).reshape(n, 270, 428)
+    frames = y.download(np.uint8).reshape(n, 480, 640)
+    moved = 0
+    for i in range(n):
+        c = got[i]["corners"].astype(np.float32)
+        src = np.array([c[0], c[1], c[4], c[5], c[2], c[3], c[6], c[7]], np.float32)  # tl, tr, bl, br (dmz.cpp:446-471)
+        assert np.array_equal(sse_cards[i], oracle.warp_perspective(frames[i], oracle.calc_persp_transform(src, dst, sse=True))), i
+        assert np.array_equal(default_cards[i], oracle.warp_perspective(frames[i], oracle.calc_persp_transform(src, dst))), i
+        moved += int((sse_cards[i] != default_cards[i]).any())
+    assert moved > n // 4
+    for b in (y, res, cards):
+        b.free()
+
+
 def test_warp_with_given_matrices_byte_exact(ctx, pkg, oracle):
     """SURVEY Appendix B layering (ii): feed the oracle's float[9] to the HIP warp."""
     rng = np.random.default_rng(2)

@@ -65,6 +65,29 @@ def test_calc_persp_transform_bit_exact(oracle, reference):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, a, b)
 
 
+def test_calc_persp_transform_sse2_order_bit_exact(oracle, reference, orc):
+    """The oracle's second summation order (orc_calc_persp_transform_sse: Eigen 3.2.4's SSE2 packet reductions, what a stock
+    x86-64 build of the reference computes) against that build itself, oracle/_ref/libdmzref_vec.so; the default order stays
+    pinned on the -DEIGEN_DONT_VECTORIZE build above."""
+    if not orc.Reference.available("_vec"):
+        pytest.skip("oracle/_ref/libdmzref_vec.so not built (make -C oracle ref, build container only)")
+    vec = orc.Reference("_vec")
+    rng = np.random.default_rng(33)
+    dst = reference.card_dest_points()
+    base = np.array([106, 105, 533, 105, 106, 374, 533, 374], np.float32)
+    differ = 0
+    for k in range(4000):
+        src = base + rng.uniform(-12, 12, 8).astype(np.float32)
+        if k % 5 == 0:
+            src = np.trunc(src)
+        if k % 7 == 0:
+            src = (src * rng.uniform(0.2, 3.0)).astype(np.float32)  # other scales: half-size chroma planes, zooms
+        a, b = oracle.calc_persp_transform(src, dst, sse=True), vec.calc_persp_transform(src, dst)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, a, b)
+        differ += not np.array_equal(a.view(np.uint32), oracle.calc_persp_transform(src, dst).view(np.uint32))
+    assert differ > 1000  # the two orders are different computations (three quads of four)
+
+
 def test_vseg_box_sum_bit_exact(oracle, reference):
     rng = np.random.default_rng(4)
     for _ in range(500):
@@ -307,15 +330,41 @@ def test_eigen_flavour_gap_report(oracle, reference, orc):
     seed = 0xCA4D10
     rel_max, mats_differ, cards_differ, bytes_max, bytes_sum, level_max = 0.0, 0, 0, 0, 0, 0
     idx_changes = label_changes = flag_changes = frames = 0
+    hseg_frames = hseg_score_bits = hseg_offsets = hseg_width = 0
+    f = np.float32
+
+    def four_pass(lib, g, pat):  # best_n_hseg's four slices (n_hseg.cpp:104-147) through one build's best_n_hseg_constrained
+        st = (np.zeros(16, np.uint16), 428.0, 0.0, 0)
+        for step in range(4):
+            if step == 0:
+                w, o = (f(17.1), f(19.7), f(0.5)), (0, 0xFFFF, 10)
+            else:
+                dw, sw, do = [(f(0.5), f(0.2), 10), (f(0.2), f(0.1), 3), (f(0.1), f(0.05), 3)][step - 1]
+                nw, po = f(st[2]), st[3]
+                w, o = (nw - dw, nw + dw, sw), (0 if po < do else po - do, po + do, 1)
+            st = lib.best_n_hseg_constrained(g, pat, w, o, *st)
+        return st
     for i in range(n):
         frame, _ = oracle.synth_frame(seed, i)
         w, wcard = oracle.scan_frame(frame)
         if not w["found_all"]:
             continue
         frames += 1
+        if (w["flags"] & 4) and w["pattern_type"] in (1, 2):
+            # the digit search on the SAME card: best_n_hseg_constrained sums |grad - pattern| over 428 columns with Eigen --
+            # sequentially in the scalar flavour, as two interleaved packet accumulators in the SSE2 one (not restated)
+            y0, pat = int(w["vseg_y_offset"]), int(w["pattern_type"])
+            g = oracle.hseg_grad_sums(wcard[y0:y0 + 27])
+            a, b = four_pass(reference, g, pat), four_pass(vec, g, pat)
+            nd = 16 if pat == 1 else 15
+            hseg_frames += 1
+            hseg_score_bits += int(f(a[1]).view(np.uint32) != f(b[1]).view(np.uint32))
+            hseg_offsets += int(not np.array_equal(a[0][:nd], b[0][:nd]))
+            hseg_width += int(a[2] != b[2])
         c = w["corners"].astype(np.float32)
         src = np.array([c[0], c[1], c[4], c[5], c[2], c[3], c[6], c[7]], np.float32)  # tl, tr, bl, br (dmz.cpp:446-471)
         ms, mv = reference.calc_persp_transform(src, dst), vec.calc_persp_transform(src, dst)
+        assert np.array_equal(mv.view(np.uint32), oracle.calc_persp_transform(src, dst, sse=True).view(np.uint32)), i
         assert np.array_equal(ms.view(np.uint32), oracle.calc_persp_transform(src, dst).view(np.uint32)), i
         card_s = oracle.warp_perspective(frame, ms)
         assert np.array_equal(card_s, wcard), i  # the scalar flavour IS the oracle's card
@@ -348,4 +397,7 @@ def test_eigen_flavour_gap_report(oracle, reference, orc):
         cards_differ, bytes_sum / max(1, cards_differ), bytes_max, level_max))
     print("  downstream: %d frames change a segmentation index, %d a digit label, %d a flag" % (
         idx_changes, label_changes, flag_changes))
+    print("  (DMZ_HIP_OPT_EIGEN_SSE2 reproduces the vec build's homography bit for bit: the cards above are then the vec build's)")
+    print("  best_n_hseg on the same card, %d frames: hseg_score bits differ on %d, digit offsets on %d, number_width on %d" % (
+        hseg_frames, hseg_score_bits, hseg_offsets, hseg_width))
     assert frames > n // 2 and rel_max < 1e-3
