@@ -17,7 +17,7 @@ python3 $ROOT/bench.py --config 2 > $OUT/${TAG}_bench_config2_batch4096.json 2>>
 python3 $ROOT/bench.py --config 3 > $OUT/${TAG}_bench_config3_batch65536.json 2>> $OUT/bench.log
 python3 $ROOT/bench.py --corpus mixed --no-cpu-baseline > $OUT/${TAG}_bench_mixed_batch$B.json 2>> $OUT/bench.log
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ROOT/bench.py --batch $B --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ROOT/bench.py --batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-side-configs > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 cp $OUT/trace/bench_kernel_stats.csv $OUT/${TAG}_kernel_stats_batch$B.csv 2>/dev/null || find $OUT/trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_batch$B.csv \;
 summarise() {  # dir, output file, batch, counters...
   python3 - "$@" <<'PY'
