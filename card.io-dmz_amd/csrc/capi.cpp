@@ -1625,7 +1625,7 @@ int dmz_hip_warp_perspective_batch(dmz_hip_context *ctx, const uint8_t *plane, s
 }
 
 static int run_model(dmz_hip_context *ctx, int which, int model, const float *x, int n, float *out,
-                     int in_len, int out_len) {
+                     int in_len, int out_len, int expiry_conv = -1 /* -1: the context's */) {
   if (!ctx || !x || !out || n <= 0) return DMZ_HIP_EINVAL;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
@@ -1642,7 +1642,8 @@ static int run_model(dmz_hip_context *ctx, int which, int model, const float *x,
   else if (which == 2)
     dmz_launch_slash_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout);
   else if (which == 3)
-    dmz_launch_expiry_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout, ctx->expiry_conv);
+    dmz_launch_expiry_model(ctx->stream, ctx->d_weights, ctx->d_xw, (const float *)dx, n, dout,
+                            expiry_conv < 0 ? ctx->expiry_conv : expiry_conv);
   else
     dmz_launch_digit_model(ctx->stream, ctx->d_weights, ctx->d_hidwt, model, (const float *)dx, n, dout);
   HIP_TRY(ctx, hipGetLastError());
@@ -1676,10 +1677,7 @@ int dmz_hip_apply_expiry_model(dmz_hip_context *ctx, const float *x, int n, floa
     bool safe = true;
     for (size_t i = 0; i < (size_t)n * 176 && safe; i++) safe = fabsf(x[i]) <= 2048.0f;  // (false for NaN / inf)
     if (!safe) {
-      ctx->expiry_conv = DMZ_HIP_EXPIRY_CONV_F32;
-      const int rc = run_model(ctx, 3, 0, x, n, out, 176, 10);
-      ctx->expiry_conv = DMZ_HIP_EXPIRY_CONV_F16X3;
-      return rc;
+      return run_model(ctx, 3, 0, x, n, out, 176, 10, DMZ_HIP_EXPIRY_CONV_F32);  // (an argument: the context is not touched)
     }
   }
   return run_model(ctx, 3, 0, x, n, out, 176, 10);

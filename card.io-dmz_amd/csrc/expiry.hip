@@ -868,9 +868,12 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
         int v[21];
         int mx = 0;
         {
+          // (idle lanes -- columns past the window, the slot-less lane 63 -- read column 0 and are zeroed once below: a
+          // predicated load per row was a v_mov, an exec save and an exec restore each)
           int iv[IROWS];
+          const int rl = col ? rect_left + c : 0;
 #pragma unroll
-          for (int t = 0; t < IROWS; t++) iv[t] = col ? (int)L.inter[t * ISTRIDE + rect_left + c] : 0;
+          for (int t = 0; t < IROWS; t++) iv[t] = (int)L.inter[t * ISTRIDE + rl];
           if (vmask == 0x1FFFFFu) {  // (wave-uniform) the usual case: all 21 window rows inside the ROI, no per-row select
 #pragma unroll
             for (int r = 0; r < 21; r++) {
@@ -886,6 +889,11 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
           }
         }
         const int sidx = sl * 24 + c;  // this lane's entry of the per-slot arrays
+        if (!col) {
+          mx = 0;
+#pragma unroll
+          for (int r = 0; r < 21; r++) v[r] = 0;
+        }
         L.u.b.cm[sidx] = mx;
         __syncthreads();
         if (sl < 3) {

@@ -325,8 +325,9 @@ typedef struct {
 void dmz_scharr3_dx_abs(IplImage *src, IplImage *dst);
 // dmz.h:110 -- *expiry_groups is malloc'ed (and each group's character_rects), as in the reference; the caller frees
 void dmz_best_expiry_seg(IplImage *card_y, uint16_t starting_y_offset, CythonGroupedRects **expiry_groups, uint16_t *number_of_groups);
-// dmz.h:111-114 -- categorises the digits of the new groups, aggregates them into the session's groups (both arrays are
-// re-allocated to their new sizes as in dmz.cpp:625-655) and picks the stable month / year
+// dmz.h:111-114 -- categorises the digits of the new groups, aggregates them into the session's groups and picks the stable
+// month / year.  As in dmz.cpp:625-655 only the SESSION's array is re-allocated and rewritten (the categorised scores come
+// back there); the new-groups array and its count are left untouched, and no character_rects array is freed
 void dmz_expiry_extract(IplImage *card_y, uint16_t *number_of_expiry_groups, CythonGroupedRects **cython_expiry_groups,
                         uint16_t *number_of_new_groups, CythonGroupedRects **cython_new_groups, int *expiry_month,
                         int *expiry_year);

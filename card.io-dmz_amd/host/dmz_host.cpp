@@ -823,6 +823,11 @@ static void image_extent(const IplImage *im, int *x, int *y, int *w, int *h) {
 void dmz_scharr3_dx_abs(IplImage *src, IplImage *dst) {  // llcv_scharr3_dx_abs (cv/sobel.cpp:706-804)
   dmz_hip_context *ctx = hip_of(NULL);
   if (!ctx || !src || !dst || src->nChannels != 1 || dst->nChannels != 1 || src->depth != IPL_DEPTH_8U) return;
+  // the reference asserts a 16-bit signed destination (sobel.cpp:712-716); an 8-bit one of the same size would be overrun
+  if (dst->depth != IPL_DEPTH_16S || dst->widthStep < 2 * dst->width) {
+    fprintf(stderr, "dmz (HIP): dmz_scharr3_dx_abs needs an IPL_DEPTH_16S destination\n");
+    return;
+  }
   int sx, sy, sw, sh, dx, dy, dw, dh;
   image_extent(src, &sx, &sy, &sw, &sh);
   image_extent(dst, &dx, &dy, &dw, &dh);
@@ -938,23 +943,24 @@ void dmz_expiry_extract(IplImage *card_y, uint16_t *number_of_expiry_groups, Cyt
   for (int i = 0; i < *number_of_expiry_groups; i++) expiry_groups.push_back(from_cython_group(*cython_expiry_groups + i));
   for (int i = 0; i < *number_of_new_groups; i++) new_groups.push_back(from_cython_group(*cython_new_groups + i));
   // expiry_extract (expiry_categorize.cpp:448-501)
-  if (!new_groups.empty() && categorize_groups(card_y, new_groups)) {
-    expiry_aggregate_grouped_rects(expiry_groups, new_groups);
-    for (GroupedRectsList::iterator group = expiry_groups.begin(); group != expiry_groups.end(); ++group) {
-      if (group->total_seen_count < 3) continue;
-      get_stable_expiry_month_and_year(*group, expiry_month, expiry_year);
+  if (!new_groups.empty()) {
+    if (categorize_groups(card_y, new_groups)) {
+      expiry_aggregate_grouped_rects(expiry_groups, new_groups);
+      for (GroupedRectsList::iterator group = expiry_groups.begin(); group != expiry_groups.end(); ++group) {
+        if (group->total_seen_count < 3) continue;
+        get_stable_expiry_month_and_year(*group, expiry_month, expiry_year);
+      }
+    } else {
+      fprintf(stderr, "dmz (HIP): dmz_expiry_extract: the new groups could not be categorised (not a 428 x 270 card image, a "
+                      "rect outside it, or a group without five rects): the session's groups are left as they were\n");
     }
   }
-  // back to the caller's arrays, re-allocated to the new sizes (dmz.cpp:643-655); unlike the reference the character
-  // rectangle arrays of the replaced entries are released
-  for (int i = 0; i < *number_of_expiry_groups; i++) free((*cython_expiry_groups)[i].character_rects);
-  for (int i = 0; i < *number_of_new_groups; i++) free((*cython_new_groups)[i].character_rects);
-  *cython_expiry_groups = (CythonGroupedRects *)realloc(*cython_expiry_groups, sizeof(CythonGroupedRects) * (expiry_groups.size() + 1));
-  *cython_new_groups = (CythonGroupedRects *)realloc(*cython_new_groups, sizeof(CythonGroupedRects) * (new_groups.size() + 1));
-  for (size_t i = 0; i < expiry_groups.size(); i++) (*cython_expiry_groups)[i] = to_cython_group(expiry_groups[i]);
-  for (size_t i = 0; i < new_groups.size(); i++) (*cython_new_groups)[i] = to_cython_group(new_groups[i]);
+  // As dmz.cpp:643-655: ONLY the session's array is re-allocated to the new size and rewritten; the new-groups array and
+  // its count stay the caller's, untouched, and the character-rect arrays of the replaced entries are not freed (the
+  // reference has that free commented out: a caller may still hold those pointers).
   *number_of_expiry_groups = (uint16_t)expiry_groups.size();
-  *number_of_new_groups = (uint16_t)new_groups.size();
+  *cython_expiry_groups = (CythonGroupedRects *)realloc(*cython_expiry_groups, sizeof(CythonGroupedRects) * (expiry_groups.size() + 1));
+  for (size_t i = 0; i < expiry_groups.size(); i++) (*cython_expiry_groups)[i] = to_cython_group(expiry_groups[i]);
 }
 
 void dmz_expiry_extract_group(IplImage *card_y, CythonGroupedRects &cython_group, CythonGroupScores cython_scores,

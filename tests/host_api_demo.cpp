@@ -109,13 +109,15 @@ int main(int argc, char **argv) {
         }
         dmz_expiry_extract(card, &n_session, &session, &n_new, &fresh, &month, &year);
         if (rep == 0) {
-          printf("cycat %d", n_new);
-          for (int g = 0; g < n_new; g++)
+          // (as in the reference, dmz.cpp:625-655, the categorised scores come back in the SESSION's groups: the new-groups
+          // array is left untouched; an empty session takes the frame's groups in their order)
+          printf("cycat %d", n_session);
+          for (int g = 0; g < n_session; g++)
             for (int ch = 0; ch < 5; ch++) {
               if (ch == 2) continue;
               int best = 0;
-              for (int d = 1; d < 10; d++) if (fresh[g].scores[ch][d] > fresh[g].scores[ch][best]) best = d;
-              printf(" %d:%.6f", best, fresh[g].scores[ch][best]);
+              for (int d = 1; d < 10; d++) if (session[g].scores[ch][d] > session[g].scores[ch][best]) best = d;
+              printf(" %d:%.6f", best, session[g].scores[ch][best]);
             }
           printf("\n");
         }
