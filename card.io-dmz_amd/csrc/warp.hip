@@ -13,8 +13,10 @@
 // one destination column and walks down the strip's rows, so everything that depends on the
 // column only (M0*x1, M3*x1, M6*x1) is computed once per lane, and everything that depends on
 // the row only (M0*x + M1*y + M2, ...) is computed once per workgroup and broadcast from LDS.
-// What is left per pixel is what exactness needs -- the kernel is VALU-issue bound (fp64 and
-// integer instructions issue at the same rate on gfx950):
+// What is left per pixel is what exactness needs -- the kernel is VALU-issue bound (fp64 and most
+// integer instructions issue at about the same rate on gfx950).  These are the EXACT sequences; since round 2 nearly every
+// pixel takes the filtered-exact coordinates further down (cheap coordinates wherever they provably round like the exact
+// ones: since round 5 as an affine function of an extrapolated reciprocal, 6 fp64 operations per pixel):
 //   * 32/W = 1/(W/32) (the 2^-5 rides, exactly, in the row and column terms): the IEEE-exact
 //     v_rcp_f64 + fma sequence the compiler itself emits for 1.0/x, without its v_div_scale /
 //     v_div_fixup wrapper (quarter-rate instructions that are the identity for the exponents
@@ -481,10 +483,9 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   }
   double yA1 = newton(Wa - 2.0 * sW, y1), yA2 = newton(Wa - 4.0 * sW, y1);  // chain A: rows a, a+2, ...
   double yB1 = y1, yB2 = newton(Wa - 3.0 * sW, y1);                          // chain B: rows a+1, a+3, ...
-  // the numerators and Wd of a chain advance by recurrence (two rows per step): the cheap path needs
-  // them to ~2^-40 only, so the rounding of a dozen additions is irrelevant, and the per-row LDS
-  // records (three broadcast reads per pixel pair: the LDS pipe was the next limit) are left to
-  // the exact path
+  // Wd of a chain advances by recurrence (two rows per step; in the round 2 - 4 form the numerators too): the cheap path needs
+  // its operands to ~2^-40 only, so the rounding of a dozen additions is irrelevant, and the per-row LDS records (three
+  // broadcast reads per pixel pair: the LDS pipe was the next limit) are left to the exact path
   struct Chain {
     double Xn, Yn, Wd, y1, y2;
   };
