@@ -119,6 +119,8 @@ int orc_detect_edges(const uint8_t *y, int y_stride, int w, int h,
 void orc_calc_persp_transform(const float src_pts[8], const float dst_pts[8], float m[9]);
 /* ... in the summation order of a stock x86-64 (SSE2 packet) build of the reference's Eigen (orc_cv.c) */
 void orc_calc_persp_transform_sse(const float src_pts[8], const float dst_pts[8], float m[9]);
+/* 0 (default): orc_transform_card / orc_scan_frame restate the scalar-Eigen build; 1: the stock x86-64 (SSE2) one */
+void orc_set_reference_flavour(int flavour);
 /* cvWarpPerspective(INTER_LINEAR|FILL_OUTLIERS, 0), SURVEY Appendix A10 */
 void orc_warp_perspective(const uint8_t *src, int stride, int sw, int sh,
                           const float m[9], uint8_t *dst, int dstride, int dw, int dh);
@@ -150,7 +152,8 @@ void orc_best_n_hseg_constrained(const float *grad_sums, int pattern_type,
                                  float wmin, float wmax, float wstep,
                                  int omin, int omax, int ostep,
                                  uint16_t offsets[16], float *score, float *number_width,
-                                 int *pattern_offset);                      /* n_hseg.cpp:39-84 */
+                                 int *pattern_offset);
+                      /* n_hseg.cpp:39-84 */
 void orc_best_n_hseg(const uint8_t *strip, int stride, int pattern_type, orc_frame_result *res); /* n_hseg.cpp:88-151 */
 void orc_number_scores(const uint8_t *strip, int stride, const uint16_t *offsets, int n,
                        float scores[160]);                                  /* n_categorize.cpp:75-107 */

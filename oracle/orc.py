@@ -147,6 +147,10 @@ class Oracle:
                                       res.ctypes.data_as(C.c_void_p))
         return res[0]
 
+    def set_reference_flavour(self, flavour):
+        """0: the scalar-Eigen build (default); 1: a stock x86-64 build (SSE2 order of the homography): process-wide"""
+        self.lib.orc_set_reference_flavour(int(flavour))
+
     def calc_persp_transform(self, src_pts, dst_pts, sse=False):
         s = np.ascontiguousarray(src_pts, np.float32).reshape(8)
         d = np.ascontiguousarray(dst_pts, np.float32).reshape(8)

@@ -506,6 +506,10 @@ static void orc_householder_qr_solve8(float *a /* col-major 8x8, destroyed */, f
 }
 
 static void orc_calc_persp_transform_order(const float sp[8], const float dp[8], float m[9], int sse);
+/* which build of the reference orc_transform_card (and with it orc_scan_frame) restates: 0 = Eigen's scalar order (default),
+ * 1 = a stock x86-64 build's SSE2 order.  Process-wide: set once, before the oracle's threads start (tests only). */
+static int orc_reference_flavour = 0;
+void orc_set_reference_flavour(int flavour) { orc_reference_flavour = flavour != 0; }
 void orc_calc_persp_transform(const float sp[8], const float dp[8], float m[9]) { orc_calc_persp_transform_order(sp, dp, m, 0); }
 /* the same in the summation order of a stock x86-64 (SSE2) build of the reference */
 void orc_calc_persp_transform_sse(const float sp[8], const float dp[8], float m[9]) { orc_calc_persp_transform_order(sp, dp, m, 1); }
@@ -634,7 +638,7 @@ void orc_transform_card(const uint8_t *plane, int stride, int w, int h, const fl
   dp[0] = rx; dp[1] = ry; dp[2] = rx + rw; dp[3] = ry;
   dp[4] = rx; dp[5] = ry + rh; dp[6] = rx + rw; dp[7] = ry + rh;
   float m[9];
-  orc_calc_persp_transform(sp, dp, m);
+  orc_calc_persp_transform_order(sp, dp, m, orc_reference_flavour);
   orc_warp_perspective(plane, stride, w, h, m, card, ORC_CARD_W, ORC_CARD_W, ORC_CARD_H);
 }
 

@@ -19,6 +19,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 SEED = int(os.environ.get("DMZ_PARITY_SEED", "31337"))
+# DMZ_PARITY_FLAVOUR=1: the sweep with the device AND the oracle in the stock x86-64 (SSE2) order of the homography
+FLAVOUR = int(os.environ.get("DMZ_PARITY_FLAVOUR", "0"))
 
 
 def prove_vseg_near_tie(oracle, card, gy, gp, wy, wp):
@@ -210,13 +212,25 @@ def assert_parity(stats, n, min_expiry_frames=0, max_ties=2):
     assert stats["expiry_frames"] >= min_expiry_frames, stats
 
 
+def _with_flavour(ctx, oracle, fn):
+    if not FLAVOUR:
+        return fn()
+    ctx.set_reference_flavour(FLAVOUR)
+    oracle.set_reference_flavour(FLAVOUR)
+    try:
+        return fn()
+    finally:
+        ctx.set_reference_flavour(0)
+        oracle.set_reference_flavour(0)
+
+
 def test_1024_frames_against_oracle(ctx, pkg, oracle):
     n = int(os.environ.get("DMZ_PARITY_FRAMES", "4096"))  # raise for a one-off sweep (the oracle does ~215 frames/s per core)
     y = ctx.alloc(n * pkg.FRAME_BYTES)
     ctx.synth_frames(SEED, 1000, n, y.ptr)
-    stats = compare_with_oracle(ctx, pkg, oracle, y, n)
+    stats = _with_flavour(ctx, oracle, lambda: compare_with_oracle(ctx, pkg, oracle, y, n))
     y.free()
-    print("parity stats over %d frames: %s" % (n, stats))
+    print("parity stats%s over %d frames: %s" % (" (SSE2 flavour)" if FLAVOUR else "", n, stats))
     assert_parity(stats, n, min_expiry_frames=n // 4)
 
 
@@ -272,9 +286,9 @@ def test_fuzz_frames_against_oracle(ctx, pkg, oracle):
     rng = np.random.default_rng(int(os.environ.get("DMZ_PARITY_SEED", "31337")) + 7)
     frames = np.stack([_fuzz_frame(rng, i % 9, oracle) for i in range(n)])
     y = ctx.alloc(frames.nbytes).upload(frames)
-    stats = compare_with_oracle(ctx, pkg, oracle, y, n)
+    stats = _with_flavour(ctx, oracle, lambda: compare_with_oracle(ctx, pkg, oracle, y, n))
     y.free()
-    print("fuzz parity stats over %d frames: %s" % (n, stats))
+    print("fuzz parity stats%s over %d frames: %s" % (" (SSE2 flavour)" if FLAVOUR else "", n, stats))
     # garbage cards have flat vseg scores: near-ties (each one proven within 1e-4) are more frequent here -- measured 74 - 75
     # per 33 600 frames (profiles/r4_*sweep*.log); the bound is about twice that rate
     assert_parity(stats, n, max_ties=max(2, n // 256))
