@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
     // repeated evaluation in the same wave gave the right one (tools/dev/rejected/pipe_chunks_r5.patch.txt,
     // profiles/r5_homography_quarter_wave.log; cause not established).  The library's own pipeline never runs this kernel
     // beside another one of the same context, a second context on the same GPU may: 40 us per 65 536 frames buy the check.
+#ifndef DMZ_HOMOGRAPHY_NOCHECK  /* developer switch (tools/dev/two_context_stress.py): the single evaluation of rounds 1 - 4 */
     for (int tries = 0; tries < 6; tries++) {
       float m2[9], sp2[8];
       for (int i = 0; i < 8; i++) {
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
       for (int i = 0; i < 9; i++) m[i] = m2[i];
       if (same) break;
     }
+#endif
     invert3x3(m, &wm);
     res->flags = (res->flags & ~DMZ_HIP_FLAG_WARPED) | DMZ_HIP_FLAG_WARPED;
   } else {
