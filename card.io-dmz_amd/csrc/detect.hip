@@ -878,6 +878,11 @@ __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DE
   detect_body<VERT, NT, SC, RG>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
 }
 
+#ifdef DMZ_DUP
+#define DMZ_DUP_DETECT DMZ_TAG_CAT(DMZ_DUP)
+#else
+#define DMZ_DUP_DETECT 0
+#endif
 template <bool VERT, int NT, int SC, int RG>
 int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
                 const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask, int lds_bytes) {
@@ -892,6 +897,7 @@ int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int r
     configured_lds = lds_bytes;
   }
   lk.unlock();
+  for (int dup__ = 0; dup__ < 1 + (int)(DMZ_DUP_DETECT == (VERT ? 2 : 1)); dup__++)
   hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC, RG>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
                      frame_stride, row_stride, p, hits, skip_mask);
   return 0;

@@ -625,8 +625,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_digit_model(const float *__restr
 
 void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw, const uint8_t *cards,
                        size_t card_stride, int n, dmz_hip_frame_result *results, void *patches) {
+  DMZ_REPEAT(patches)
   hipLaunchKernelGGL(k_digit_patches, dim3(n), dim3(DG_THREADS), 0, s, cards, card_stride, n, results,
                      (unsigned short *)patches);
+  DMZ_REPEAT(digits)
   hipLaunchKernelGGL(k_digits, dim3(n), dim3(DG_THREADS), DMZ_LDS_PAD, s, weights, hidw, (const uint32_t *)patches, n,
                      results);
 }

@@ -203,6 +203,26 @@ int dmz_synth_upload_params(hipStream_t s, uint64_t seed, uint64_t first, int n,
 void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *y);
 void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards);
 void dmz_launch_fill_lds(hipStream_t s, uint32_t word);
+// Developer probe (tools/dev/marginal_cost.sh): -DDMZ_DUP=<kernel tag> launches that kernel TWICE (every kernel of the pipeline
+// is idempotent: same inputs, same outputs): the difference in the step time is what the kernel costs INSIDE the pipeline,
+// beside whatever runs on the other queues -- as opposed to its run time alone.
+#define DMZ_TAG_detect_h 1
+#define DMZ_TAG_detect_v 2
+#define DMZ_TAG_warp 3
+#define DMZ_TAG_vseg 4
+#define DMZ_TAG_hseg 5
+#define DMZ_TAG_patches 6
+#define DMZ_TAG_digits 7
+#define DMZ_TAG_stripes 8
+#define DMZ_TAG_xseg 9
+#define DMZ_TAG_xcat 10
+#define DMZ_TAG_CAT_(x) DMZ_TAG_##x
+#define DMZ_TAG_CAT(x) DMZ_TAG_CAT_(x)
+#ifdef DMZ_DUP
+#define DMZ_REPEAT(tag) for (int dup__ = 0; dup__ < (DMZ_TAG_CAT(DMZ_DUP) == DMZ_TAG_##tag ? 2 : 1); dup__++)
+#else
+#define DMZ_REPEAT(tag)
+#endif
 void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw /* dmzx layout */,
                        const DmzExpiryTables *tables, const uint8_t *cards, size_t card_stride, int n,
                        const dmz_hip_frame_result *results, DmzExpiryStage *stage /* n x 3 */,

@@ -31,6 +31,9 @@
 #include <float.h>
 #include <math.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "dmz_hip_internal.h"
 #include "dmz_wave.h"
 #include "dmz_stdsort.h"
@@ -66,6 +69,18 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1u
 // 10 I[r] with I[r] = sum over columns 27..284 of |p[c+1] - p[c-1]| (one v_sad_u8 per dword) and
 // the row index clamped to the ROI [y0, 269] (sobel.cpp:765-766).
 // ---------------------------------------------------------------------------------------------
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an unrolled loop whose index is a constant expression
+template <class F, int... Is>
+__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// v with lane LANE replaced by the (uniform) value x: one v_writelane_b32
+template <int LANE>
+__device__ __forceinline__ int with_lane(int x, int v) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(LANE));
+  return v;
+}
+
 __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict__ cards, size_t card_stride,
                                                        int n, const dmz_hip_frame_result *__restrict__ results,
                                                        dmz_hip_expiry_result *__restrict__ out,
@@ -87,35 +102,39 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   if (nrows > 128 || nrows < 18) return;  // y_offset >= 121 for a card that is not upside down
   const uint8_t *card = cards + (size_t)f * card_stride;
 
-  // sixteen rows per trip: 32 dword loads in flight per lane, and two rows per wave reduction (a lane's sum is < 2^11, a
-  // 16-lane row's < 2^15).  The kernel re-reads ~26 KB of every card in 258-byte row pieces (1.8 TB/s of scattered HBM
-  // traffic at 65 536 frames): a four-wave form with every row load of a frame in flight at once (round 3) has the same
-  // run time -- one trip then takes 13 - 16 k cycles -- so it is the memory system, not the wave's latency chain.
-  constexpr int kTrip = 16;
+  // 32 rows per trip, all of a trip's loads in flight together.  A lane loads dword 6 + lane of every row (p[24 + 4 lane ..]);
+  // its right-hand neighbour dword comes from lane + 1 by DPP, for lane 63 and for the two columns past the last whole dword
+  // (p[284], p[285]) from ONE more load per trip: lane 2 u + k holds dword 70 + k of row u, and what depends on those is
+  // uniform (scalar unit).  Round 5: 33 loads and ~500 VALU instructions per 32 rows; the form before it loaded both dwords
+  // of a lane per row and evaluated the two extra columns on lane 0 under a branch (64 loads, ~640 instructions): stage
+  // 3.42 -> 3.33 ms, step -0.15 ms (profiles/r5_stripes_trip32_ab.log).  Two rows per wave reduction (a lane's sum is < 2^11,
+  // a 16-lane row's < 2^15).  The kernel re-reads the rows below the number in 258-byte pieces, ~92 per card: a four-wave form
+  // with every row load of a frame in flight at once (round 3) has the same run time -- it is the memory system, not the wave's
+  // latency chain; and run in the tail of k_vseg (round 5: the workgroup that has just found the number row, four waves, one
+  // round trip) it costs k_vseg 0.44 ms where this kernel costs the three-queue step 0.50
+  // (tools/dev/rejected/vseg_tail_stripes_r5.patch.txt, profiles/r5_vseg_tail_stripes_ab.log).
+  constexpr int kTrip = 32;
   for (int r0 = 0; r0 < nrows; r0 += kTrip) {
-    uint32_t a[kTrip], b[kTrip];
-    unsigned extra[kTrip];
+    uint32_t a[kTrip];
 #pragma unroll
-    for (int u = 0; u < kTrip; u++) {
-      const int r = imin(r0 + u, nrows - 1);
-      const uint32_t *row = (const uint32_t *)(card + (size_t)(y0 + r) * CW);
-      a[u] = row[6 + lane];
-      b[u] = row[7 + lane];
-      extra[u] = 0u;
-      if (lane == 0) {
-        const uint32_t w70 = row[70], w71 = row[71];  // p[280..287]
-        // |p[284] - p[282]| + |p[285] - p[283]|
-        extra[u] = (unsigned)iabs((int)(w71 & 255u) - (int)((w70 >> 16) & 255u)) +
-                   (unsigned)iabs((int)((w71 >> 8) & 255u) - (int)(w70 >> 24));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kTrip; u += 2) {
-      unsigned s[2];
+    for (int u = 0; u < kTrip; u++)
+      a[u] = ((const uint32_t *)(card + (size_t)(y0 + imin(r0 + u, nrows - 1)) * CW))[6 + lane];
+    const uint32_t e = ((const uint32_t *)(card + (size_t)(y0 + imin(r0 + (lane >> 1), nrows - 1)) * CW))[70 + (lane & 1)];
+    int sums = 0;  // lane u: I[r0 + u]
+    static_for([&](auto pair) {
+      constexpr int u = 2 * decltype(pair)::value;
+      unsigned s[2], ex[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const uint32_t left = __builtin_amdgcn_alignbyte(b[u + h], a[u + h], 2);  // p[26 + 4 lane ..]
-        s[h] = __builtin_amdgcn_sad_u8(b[u + h], left, extra[u + h]);              // p[28 + 4 lane ..] vs left
+        const uint32_t w70 = (uint32_t)__builtin_amdgcn_readlane((int)e, 2 * (u + h));      // p[280..283]
+        const uint32_t w71 = (uint32_t)__builtin_amdgcn_readlane((int)e, 2 * (u + h) + 1);  // p[284..287]
+        const uint32_t nb = (uint32_t)with_lane<63>(
+            (int)w70, __builtin_amdgcn_update_dpp(0, (int)a[u + h], 0x130, 0xf, 0xf, true));  // dword 7 + lane (wave_shl:1)
+        const uint32_t left = __builtin_amdgcn_alignbyte(nb, a[u + h], 2);                    // p[26 + 4 lane ..]
+        s[h] = __builtin_amdgcn_sad_u8(nb, left, 0u);                                          // p[28 + 4 lane ..] vs left
+        // |p[284] - p[282]| + |p[285] - p[283]|
+        ex[h] = (unsigned)iabs((int)(w71 & 255u) - (int)((w70 >> 16) & 255u)) +
+                (unsigned)iabs((int)((w71 >> 8) & 255u) - (int)(w70 >> 24));
       }
       int v = (int)(s[0] | (s[1] << 16));
       v += DMZ_DPP_SHR(v, 1);
@@ -124,11 +143,12 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
       v += DMZ_DPP_SHR(v, 8);
       const unsigned q0 = (unsigned)__builtin_amdgcn_readlane(v, 15), q1 = (unsigned)__builtin_amdgcn_readlane(v, 31);
       const unsigned q2 = (unsigned)__builtin_amdgcn_readlane(v, 47), q3 = (unsigned)__builtin_amdgcn_readlane(v, 63);
-      const unsigned lo = (q0 & 0xffffu) + (q1 & 0xffffu) + (q2 & 0xffffu) + (q3 & 0xffffu);
-      const unsigned hi = (q0 >> 16) + (q1 >> 16) + (q2 >> 16) + (q3 >> 16);
-      if (lane == 0 && r0 + u < nrows) I[r0 + u] = (int)lo;
-      if (lane == 0 && r0 + u + 1 < nrows) I[r0 + u + 1] = (int)hi;
-    }
+      const unsigned lo = (q0 & 0xffffu) + (q1 & 0xffffu) + (q2 & 0xffffu) + (q3 & 0xffffu) + ex[0];
+      const unsigned hi = (q0 >> 16) + (q1 >> 16) + (q2 >> 16) + (q3 >> 16) + ex[1];
+      sums = with_lane<u>((int)lo, sums);
+      sums = with_lane<u + 1>((int)hi, sums);
+    }, std::make_integer_sequence<int, kTrip / 2>{});
+    if (lane < kTrip && r0 + lane < nrows) I[r0 + lane] = sums;
   }
   __syncthreads();
   for (int r = lane; r < nrows; r += 64)
@@ -1964,7 +1984,9 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
                        const uint8_t *cards, size_t card_stride, int n, const dmz_hip_frame_result *results,
                        DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid, int conv_mode, int phases) {
   if (phases & 1) {
+    DMZ_REPEAT(stripes)
     hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
+    DMZ_REPEAT(xseg)
     hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
                        out, stage);
   }
@@ -1979,6 +2001,7 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
     hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_BF16>, grid, block, lds, s, weights, xw, tables, cards, card_stride, n,
                        results, stage, out);
   else if (conv_mode == DMZ_HIP_EXPIRY_CONV_F16X3)
+    DMZ_REPEAT(xcat)
     hipLaunchKernelGGL(k_expiry_cat<DMZ_HIP_EXPIRY_CONV_F16X3>, grid, block, lds, s, weights, xw, tables, cards, card_stride, n,
                        results, stage, out);
   else

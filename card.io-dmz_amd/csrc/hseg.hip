@@ -684,5 +684,6 @@ extern "C" void dmz_dbg_hseg(unsigned long long *out, int reset) {
 
 void dmz_launch_hseg(hipStream_t s, const uint8_t *cards, size_t card_stride, int n,
                      dmz_hip_frame_result *results) {
+  DMZ_REPEAT(hseg)
   hipLaunchKernelGGL(k_hseg, dim3(n), dim3(64), 0, s, cards, card_stride, n, results);
 }

@@ -533,6 +533,7 @@ __global__ __launch_bounds__(VS_THREADS) void k_vseg_model(const float *__restri
 
 void dmz_launch_vseg(hipStream_t s, const float *weights, const float *wfrag, const uint8_t *cards, size_t card_stride,
                      int n, int mode, dmz_hip_frame_result *results) {
+  DMZ_REPEAT(vseg)
   hipLaunchKernelGGL(k_vseg, dim3(n), dim3(VS_THREADS), DMZ_LDS_PAD, s, weights, wfrag, cards, card_stride, n,
                      mode, results);
 }

@@ -621,6 +621,7 @@ void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, 
   const int aligned = ((((uintptr_t)planes) | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
   hipLaunchKernelGGL(k_warp_windows, dim3((unsigned)((n * kTiles + 255) / 256)), dim3(256), 0, s, n, width,
                      height, aligned, mats);
+  DMZ_REPEAT(warp)
   hipLaunchKernelGGL(k_warp, dim3((unsigned)n_pad * kTiles), dim3(kThreads), 0, s, planes, frame_stride,
                      row_stride, width, height, n, n_pad, mats, cards, card_stride);
 }
