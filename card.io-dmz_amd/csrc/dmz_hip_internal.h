@@ -79,17 +79,28 @@ struct DmzBoxHit {
 // win[]: per destination strip of k_warp, the source window k_warp_windows derived from the
 // strip's four corner pixels (wdw: dword columns; > 0 staged with aligned dword loads, < 0 staged
 // with the border-checked loop, 0 = generic path)
+// ... and the strip's uniform fp64 constants, evaluated ONCE per strip by k_warp_windows and read by k_warp through scalar
+// loads (round 5: k_warp's waves derived them on the vector unit and moved them to scalar registers, ~20 v_readfirstlane and
+// ~10 fp64 operations per wave of 30 rows): the rounding constants with the window origin folded in, exact path (mx, my) and
+// filtered path (kx, ky: + alpha where the strip takes the affine form; aqx, aqy: that alpha as the adder rounded it).
 struct DmzWarpWin {
   int wx0, wy0, wdw, wrows;
+  double mx, my, kx, ky, aqx, aqy;
 };
 constexpr int DMZ_WARP_STRIPS = 21;
 struct DmzWarpMat {
   double m[9];
   int valid;
   int pad_;
+  double sw, dw2;  // M7 / 32 = Wd(row + 1) - Wd(row), and twice that (k_warp_windows)
   DmzWarpWin win[DMZ_WARP_STRIPS];
-  double alpha_x, alpha_y;  // 32 M1 / M7, 32 M4 / M7 (k_warp_windows; read by strips with the affine flag, warp.hip)
 };
+// what k_homography / k_mats_from_float write (the rest belongs to k_warp_windows)
+__device__ __forceinline__ void dmz_store_mat_head(DmzWarpMat *dst, const DmzWarpMat &wm) {
+  for (int i = 0; i < 9; i++) dst->m[i] = wm.m[i];
+  dst->valid = wm.valid;
+  dst->pad_ = 0;
+}
 
 // Expiry path.  Per (frame, stripe) staging written by k_expiry_seg and merged, in stripe order,
 // by k_expiry_cat; group headers only (the first 32 bytes of dmz_hip_expiry_group).

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
   } else {
     res->flags = res->flags & ~DMZ_HIP_FLAG_WARPED;
   }
-  mats[f] = wm;
+  dmz_store_mat_head(mats + f, wm);
 }
 
 template <bool SSE>
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) void k_mats_from_float(int n, const float *__re
   wm.valid = 1;
   wm.pad_ = 0;
   invert3x3(m, &wm);
-  mats[f] = wm;
+  dmz_store_mat_head(mats + f, wm);
 }
 
 }  // namespace

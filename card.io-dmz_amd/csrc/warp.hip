@@ -148,17 +148,18 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
   if (i >= n * kTiles) return;
   const int frame = i / kTiles, tile = i - frame * kTiles;
   const DmzWarpMat &wm = mats[frame];
-  DmzWarpWin w = {0, 0, 0, 0};
+  DmzWarpWin w = {0, 0, 0, 0, 0., 0., 0., 0., 0., 0.};
   if (wm.valid) {
     const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
     const int x = tx * TW, y0 = ty * TH;
     const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
                  M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
-    const double sW = M7 * 0.03125, ax = M1 / sW, ay = M4 / sW;  // (frame-uniform: strip 0 stores them)
-    if (tile == 0) {
-      mats[frame].alpha_x = ax;
-      mats[frame].alpha_y = ay;
+    const double sW = M7 * 0.03125, ax = M1 / sW, ay = M4 / sW;
+    if (tile == 0) {  // (frame-uniform)
+      mats[frame].sw = sW;
+      mats[frame].dw2 = 2.0 * sW;
     }
+    bool affine = false;
     int bx0 = 1 << 20, bx1 = -(1 << 20), by0 = 1 << 20, by1 = -(1 << 20), npos = 0, nneg = 0;
     double wmin = 1e300;  // min |W| over the strip: W is linear, so it is at a corner
     for (int c = 0; c < 4; c++) {
@@ -196,12 +197,22 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
         if (fabs(M7) * 16777216.0 <= wmin)
           w.wrows |= kFastFlag | kLinFlag;
         else if (fabs(ax) <= 1073741824.0 && fabs(ay) <= 1073741824.0)  // 2^30 (NaN fails)
-          w.wrows |= kFastFlag | kAffFlag;
+          w.wrows |= kFastFlag | kAffFlag, affine = true;
 #else
         w.wrows |= kFastFlag;
 #endif
       }
     }
+    // The rounding constants with the window origin folded in (k_warp's comments): 1.5 * 2^52 - 32 * origin for the exact
+    // sequence, 1.5 * 2^36 + 0.5 - 32 * origin for the filtered one -- there plus alpha where the strip takes the affine form,
+    // and that alpha as the adder rounded it ((magic' + alpha) - magic', exact).
+    w.mx = 6755399441055744.0 - (double)(32 * w.wx0);
+    w.my = 6755399441055744.0 - (double)(32 * w.wy0);
+    const double mxf = 103079215104.0 + 0.5 - (double)(32 * w.wx0), myf = 103079215104.0 + 0.5 - (double)(32 * w.wy0);
+    w.kx = affine ? mxf + ax : mxf;
+    w.ky = affine ? myf + ay : myf;
+    w.aqx = w.kx - mxf;
+    w.aqy = w.ky - myf;
   }
   mats[frame].win[tile] = w;
 }
@@ -327,8 +338,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   // loop free of predication.
   const int x1 = imin(lane, DMZ_CARD_WIDTH - 1 - x);
   const double A = M0 * x1, B = M3 * x1, C = (M6 * x1) * 0.03125;
-  const double magicX = 6755399441055744.0 - (double)(32 * wx0);
-  const double magicY = 6755399441055744.0 - (double)(32 * wy0);
+  const double magicX = ww.mx, magicY = ww.my;  // (uniform, from k_warp_windows: scalar loads)
   __syncthreads();
 
   // Coordinates travel as "l-format" dwords: window-relative fixed point with 16 + 5 fractional
@@ -458,14 +468,9 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   //     the only place where floor, the half-way case of round-to-even included, can differ).
   //   * lanes whose dword has zero low bits (2^-16 per coordinate) take the exact sequence; the test
   //     is one v_min3_u16 + v_min_u16 + compare per pixel pair, the branch is wave-uniform.
-  // (uniform: kept in scalar registers, so that the fma needs no copy of its addend)
-  auto uniform = [](double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
-  };
-  const double magicXf = uniform(103079215104.0 + 0.5 - (double)(32 * wx0));  // 1.5 * 2^36
-  const double magicYf = uniform(103079215104.0 + 0.5 - (double)(32 * wy0));
-  const double sW = M7 * 0.03125;  // Wd(row + 1) - Wd(row)
+  // (the uniform constants come from k_warp_windows through scalar loads: the fma needs no copy of its addend, and no wave
+  // spends vector instructions on them)
+  const double sW = wm.sw;  // Wd(row + 1) - Wd(row)
   auto newton = [](double Wd, double g) {
     const double t = __builtin_fma(-Wd, g, 1.0);
     return __builtin_fma(g, t, g);
@@ -489,7 +494,8 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   struct Chain {
     double Xn, Yn, Wd, y1, y2;
   };
-  const double dX2 = uniform(2.0 * M1), dY2 = uniform(2.0 * M4), dW2 = uniform(2.0 * sW);
+  const double dW2 = wm.dw2;
+  const double dX2 = 2.0 * M1, dY2 = 2.0 * M4;  // (the recurrence form only: DMZ_WARP_AFFINE == 0)
   // The loop in two forms (AFF: the strip carries kAffFlag).
   //   recurrences: fX = fma(Xn, y, magic'), Xn += 2 M1 -- 8 fp64 operations per pixel;
   //   affine:      Xn = X_a + M1 dj and Wd = Wd_a + sW dj are both linear in the row, so Xn / Wd = alpha + beta / Wd with
@@ -509,7 +515,8 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   auto run_fast = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr bool AFF = MODE == 1, LIN = MODE == 2;
-    double Kx = magicXf, Ky = magicYf, bx = 0., by = 0.;
+    const double Kx = ww.kx, Ky = ww.ky;  // magic' (+ alpha)
+    double bx = 0., by = 0.;
     Chain cA, cB;
     {
       const RowXYW ra = s_row[a], rb = s_row[a + 1];
@@ -517,11 +524,8 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
       cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C, cB.y1 = yB1, cB.y2 = yB2;
     }
     if constexpr (AFF) {
-      Kx = uniform(magicXf + wm.alpha_x);
-      Ky = uniform(magicYf + wm.alpha_y);
-      const double aqx = uniform(Kx - magicXf), aqy = uniform(Ky - magicYf);
-      bx = __builtin_fma(-aqx, cA.Wd, cA.Xn);
-      by = __builtin_fma(-aqy, cA.Wd, cA.Yn);
+      bx = __builtin_fma(-ww.aqx, cA.Wd, cA.Xn);
+      by = __builtin_fma(-ww.aqy, cA.Wd, cA.Yn);
     }
     if constexpr (LIN) {
       // y at row a (two Newton steps from the neighbouring row's: (rho)^2, (rho)^4 -- exact to the last bits), its slope
