@@ -475,19 +475,20 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     const double t = __builtin_fma(-Wd, g, 1.0);
     return __builtin_fma(g, t, g);
   };
-  // reciprocals at the virtual rows a-1 (full Newton sequence) and a-2, a-3, a-4 (one step from
-  // y[a-1]: relative error (k rho)^2); the first extrapolations then start with <= 15 rho^2 and
-  // the Newton step leaves <= 225 rho^4 <= 2^-36
+  // reciprocals at the virtual rows a-1 (full Newton sequence) and a-2, a-3, a-4 (one step from y[a-1]: relative error
+  // (k rho)^2); the first extrapolations then start with <= 15 rho^2 and the Newton step leaves <= 225 rho^4 <= 2^-36.
+  // The one step from y1 against Wd(a-1) - k sW is y1 (2 - (Wd(a-1) - k sW) y1) = y1 + k (sW y1) y1 wherever y1 Wd(a-1) = 1
+  // (it is, to 2^-52): ONE fma per row on q = (sW y1) y1 instead of the row's Wd and two (round 5; same (k rho)^2).
   const double Wa = s_row[a].W0s + C;
-  double y1;
-  {
+  auto start_chains = [&](double &yA1, double &yA2, double &yB1, double &yB2) {
     const double Wd = Wa - sW;
-    y1 = __builtin_amdgcn_rcp(Wd);
+    double y1 = __builtin_amdgcn_rcp(Wd);
     y1 = newton(Wd, y1);
     y1 = newton(Wd, y1);
-  }
-  double yA1 = newton(Wa - 2.0 * sW, y1), yA2 = newton(Wa - 4.0 * sW, y1);  // chain A: rows a, a+2, ...
-  double yB1 = y1, yB2 = newton(Wa - 3.0 * sW, y1);                          // chain B: rows a+1, a+3, ...
+    const double q = (sW * y1) * y1;
+    yA1 = y1 + q, yA2 = __builtin_fma(3.0, q, y1);  // chain A: rows a, a+2, ... (previous: a-2, a-4)
+    yB1 = y1, yB2 = __builtin_fma(2.0, q, y1);       // chain B: rows a+1, a+3, ... (previous: a-1, a-3)
+  };
   // Wd of a chain advances by recurrence (two rows per step; in the round 2 - 4 form the numerators too): the cheap path needs
   // its operands to ~2^-40 only, so the rounding of a dozen additions is irrelevant, and the per-row LDS records (three
   // broadcast reads per pixel pair: the LDS pipe was the next limit) are left to the exact path
@@ -520,17 +521,19 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     Chain cA, cB;
     {
       const RowXYW ra = s_row[a], rb = s_row[a + 1];
-      cA.Xn = ra.X0 + A, cA.Yn = ra.Y0 + B, cA.Wd = Wa, cA.y1 = yA1, cA.y2 = yA2;
-      cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C, cB.y1 = yB1, cB.y2 = yB2;
+      cA.Xn = ra.X0 + A, cA.Yn = ra.Y0 + B, cA.Wd = Wa;
+      cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C;
     }
+    if constexpr (!LIN) start_chains(cA.y1, cA.y2, cB.y1, cB.y2);
     if constexpr (AFF) {
       bx = __builtin_fma(-ww.aqx, cA.Wd, cA.Xn);
       by = __builtin_fma(-ww.aqy, cA.Wd, cA.Yn);
     }
     if constexpr (LIN) {
-      // y at row a (two Newton steps from the neighbouring row's: (rho)^2, (rho)^4 -- exact to the last bits), its slope
-      // dy = -sW y_a^2; chain A starts at row a, chain B one row further (y2 holds the step of two rows)
-      double ya = newton(Wa, y1);
+      // y at row a (v_rcp_f64 and two Newton steps: exact to the last bits), its slope dy = -sW y_a^2; chain A starts at
+      // row a, chain B one row further (y2 holds the step of two rows)
+      double ya = __builtin_amdgcn_rcp(Wa);
+      ya = newton(Wa, ya);
       ya = newton(Wa, ya);
       const double dy = -(sW * ya) * ya;
       cA.y1 = ya, cB.y1 = ya + dy;
