@@ -26,17 +26,17 @@
 // magnitude and the 3x3 non-maximum suppression never leave registers:
 // neighbours along the walk are the lane's own previous/next step, neighbours
 // across are the adjacent lanes (two wave shifts per step).  LDS holds only the
-// u8 source tile, the u8 edge map and the u16 vote counters (39 KB / 30 KB per
-// workgroup => 4 workgroups, 28 / 16 waves per CU), so one workgroup's barriers
+// u8 source tile, the u8 edge map and the u16 vote counters, so one workgroup's barriers
 // are covered by the others.  The adaptive thresholds need the box-wide mean of
 // |dx|+|dy| before NMS.  For the standard geometry (28- and 38-step boxes of a
-// 640 x 480 frame) the walk can run ONCE: the lane keeps the (dx, dy) of its 28 / 38
+// 640 x 480 frame) the walk runs ONCE: the lane keeps the (dx, dy) of its 28 / 38
 // steps packed as sign-flipped s16 pairs in registers (one v_sad_u16 against
-// 0x80008000 gives |dx| + |dy| back), and the NMS pass reads them from there: used
-// for the left/right boxes (38 steps, 256-thread workgroups: 128 registers still
-// leave four workgroups per CU).  The top/bottom boxes and other box sizes take the
-// two-walk form (sum pass, NMS pass), which recomputes the gradients instead of
-// parking 44 KB of them per workgroup in LDS (see DMZ_DETECT_SINGLE_H below).
+// 0x80008000 gives |dx| + |dy| back), and the NMS pass reads them from there; the
+// edge map then lies over the tile (27.7 KB / 20.6 KB per workgroup: 28 waves per CU
+// either way).  Other box sizes take the two-walk form (sum pass, NMS pass), which
+// recomputes the gradients.  (Rounds 2 - 4 kept 14 / 28 of the gradients in registers
+// and parked the rest in LDS: with round 5's NMS the kernels need 52 / 63 registers
+// with all of them resident.)
 #include <mutex>
 
 #include "dmz_hip_internal.h"
@@ -191,15 +191,20 @@ constexpr int kDenseList = 96;
 // NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
 // given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
 // The reference's branches are kept: a wave whose 62 pixels are all below the low threshold (most of
-// the background) skips the direction test, and the slope gate runs only where a pixel survived
+// the background) skips everything -- the map was zeroed beforehand (thresholds_from) and is written for
+// pixels above the threshold only --, and the slope gate runs only where a pixel survived
 // (straight-line selects measured 17 % slower on the whole kernel).
-template <bool VERT>
-__device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, int low,
+// owner: the lane produces output for its coordinate.  LC: the box's lane count when it is a compile-time constant
+// (the boxes of a 640 x 480 frame: the map offset of a step is then an immediate of the LDS store), else 0.
+template <bool VERT, int LC>
+__device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, bool owner, int low,
                                           int high, int dxc, int dyc, int mp, int mp_lo, int mp_hi,
                                           int mc, int mc_lo, int mc_hi, int mn, int mn_lo, int mn_hi,
                                           unsigned char *map, unsigned short *seg, int seg_cap, int &ncand, int *s_int) {
   const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
   const int m = mc;
+  const bool above = owner && m > low;
+  if (__ballot(above) == 0ull) return;  // (wave-uniform)
   // neighbours in image coordinates
   int mN, mS, mW, mE, mNW, mNE, mSW, mSE;
   if (!VERT) {  // row = step, col = lane
@@ -209,8 +214,9 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
     mN = mc_lo; mS = mc_hi; mW = mp; mE = mn;
     mNW = mp_lo; mSW = mp_hi; mNE = mn_lo; mSE = mn_hi;
   }
+  const int q = s * (LC ? LC : c.L) + c.l;  // walk-space index
   int flags = 0;
-  if (m > low) {
+  if (above) {
     // canny.cpp:224-236 in 32 bits: |dx|, |dy| <= 32768, so x*TG22 < 2^29, tg67x < 2^32, y<<15 <= 2^30
     const unsigned ax = (unsigned)iabs(dxc), ay = (unsigned)iabs(dyc);
     const unsigned tg22x = ax * (unsigned)TG22;
@@ -241,10 +247,9 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
         use = !VERT;
       }
       if (use) flags |= MAP_GATE;
+      map[q] = (unsigned char)flags;
     }
   }
-  const int q = s * c.L + c.l;  // walk-space index
-  map[q] = (unsigned char)flags;
   // candidates that are not seeds go on THIS WAVE's list (seeds need no propagation): the count is wave-uniform,
   // so an append is a ballot and a prefix count -- no LDS atomic, no wait
   const bool cand = (flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND;
@@ -260,10 +265,10 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   }
 }
 
-// SC > 0: the box has exactly SC steps (compile time) and the walk runs once; SC == 0: any size, two walks.
-// RG: how many of the SC packed gradients a lane keeps in registers; the rest is parked in LDS over the edge
-// map and the vote counters, which nobody needs before the NMS pass (see the single-walk branch).
-template <bool VERT, int NT, int SC, int RG>
+// SC > 0: the box has exactly SC steps (compile time) and the walk runs once, a lane keeping its SC packed
+// gradients in registers for the NMS pass; SC == 0: any size, two walks.
+// LC: the box's lane count when the launch guarantees it (the single-walk kernels), else 0.
+template <bool VERT, int NT, int SC, int LC>
 __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_stride, int row_stride,
                             const DmzBoxParams &bp, int frame, int box_id,
                             DmzBoxHit *__restrict__ hits, unsigned char *lds) {
@@ -275,19 +280,16 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   const uint32_t inv_L = bp.inv_w;
   const int off = bp.tile_off, sp = bp.tile_stride;
 
-  // LDS regions: source tile | edge map | vote counters | scratch.  In the parked single-walk form the edge map
-  // moves over the tile (dead once the walk is done; L * S <= tile bytes), the packed gradients of the steps
-  // that do not fit in registers take the old map + counter space, followed by the candidate list: waves
-  // run the NMS pass at their own pace, so what one wave writes there (map rows, list entries) must never
-  // overlap gradients another wave has yet to read.
-  constexpr bool kParked = SC > 0 && RG < SC;
+  // LDS regions: source tile | edge map | vote counters | scratch.  In the single-walk form (compact layout) the edge
+  // map lies over the tile -- dead once every wave has finished its walk; L * S <= tile bytes -- and what follows the
+  // tile is one region with two tenants: the candidate lists until the hysteresis is done, then the vote counters.
+  constexpr bool kCompact = SC > 0;
   unsigned char *tile = lds;
-  unsigned char *map = kParked ? lds : lds + bp.lds_map;
+  unsigned char *map = kCompact ? lds : lds + bp.lds_map;
   unsigned int *acc32 = (unsigned int *)(lds + bp.lds_acc);
-  // candidate list, before voting: over the vote counters (behind the parked gradients, if any)
-  const int park_bytes = kParked ? ((4 * bp.lanes * (SC - RG) + 15) & ~15) : 0;
-  unsigned short *list = kParked ? (unsigned short *)(lds + bp.lds_map + park_bytes) : (unsigned short *)(lds + bp.lds_acc);
-  const int list_cap = kParked ? (bp.lds_red - bp.lds_map - park_bytes) / 2 : bp.list_cap;
+  // candidate list, before voting: over the vote counters
+  unsigned short *list = kCompact ? (unsigned short *)(lds + bp.lds_map) : (unsigned short *)(lds + bp.lds_acc);
+  const int list_cap = kCompact ? (bp.lds_red - bp.lds_map) / 2 : bp.list_cap;
   // one list segment per wave
   const int seg_cap = list_cap / (NT / 64);
   unsigned short *seg = list + wave * seg_cap;
@@ -418,6 +420,12 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     for (int o = 32; o > 0; o >>= 1) local_sum += __shfl_down(local_sum, o, 64);
     if (lane == 0) s_red[wave] = local_sum;
     __syncthreads();
+    // the edge map starts out empty (the NMS pass writes its survivors only).  Here: every wave has finished its walk, so
+    // the tile the map lies over in the compact layout is dead; lds_map and the map's own room are multiples of 16 bytes.
+    {
+      typedef uint32_t u32x4z __attribute__((ext_vector_type(4)));
+      for (int i = tid * 16; i < N; i += NT * 16) *(u32x4z *)(map + i) = (u32x4z){0u, 0u, 0u, 0u};
+    }
     if (tid == 0) {
       long long tot = 0;
       for (int i = 0; i < NT / 64; i++) tot += s_red[i];
@@ -433,42 +441,24 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     // ---- B+C, single walk.  g[s] = (dy << 16 | dx & 0xffff) ^ 0x80008000: each half is the gradient
     // plus 32768 as an unsigned 16-bit number, so |dx| + |dy| = v_sad_u16(g, 0x80008000, 0) exactly
     // (|-32768| = 32768 included), and dx, dy come back with one xor, one v_bfe_i32, one shift.
-    // Parked gradients: step k >= RG of column l at gpark[(k - RG) * L + l].
-    uint32_t g[RG];
-    uint32_t *gpark = (uint32_t *)(lds + bp.lds_map);
-    static_assert(RG == SC || RG % 7 == 0, "the parked part walks in groups of seven (a partial last group is guarded)");
+    uint32_t g[SC];
     {
       Window wn;
       window_init(c, wn);
       int acc = 0;
-      auto pack = [&](int dx, int dy) {
-        const uint32_t packed = pack_gradient(dx, dy);
-        acc = add_abs_sat(packed, acc);
-        return packed;
-      };
 #pragma unroll
-      for (int s0 = 0; s0 < RG; s0++) {
+      for (int s0 = 0; s0 < SC; s0++) {
         int dx, dy;
         window_step_s<VERT, false>(c, wn, s0, dx, dy);
-        g[s0] = pack(dx, dy);
-      }
-      if constexpr (RG < SC) {
-        // the parked steps: a rolled loop over groups of seven (window slots stay compile-time constants)
-#define DMZ_PARK_STEP(K)                                                                       \
-  if ((SC - RG) % 7 == 0 || sb + K < SC) {                                                      \
-    int dx, dy;                                                                                 \
-    window_step<VERT, K, false>(c, wn, sb + K, dx, dy);                                         \
-    const uint32_t packed = pack(dx, dy);                                                       \
-    if (owner) gpark[(sb + K - RG) * L + c.l] = packed; /* one writer per column */             \
-  }
-#pragma unroll 1
-        for (int sb = RG; sb < SC; sb += 7) {
-          DMZ_PARK_STEP(0) DMZ_PARK_STEP(1) DMZ_PARK_STEP(2) DMZ_PARK_STEP(3)
-          DMZ_PARK_STEP(4) DMZ_PARK_STEP(5) DMZ_PARK_STEP(6)
-        }
-#undef DMZ_PARK_STEP
+        g[s0] = pack_gradient(dx, dy);
+        acc = add_abs_sat(g[s0], acc);
       }
       thresholds_from(owner ? (long long)acc : 0ll);  // steps * 65534 fits an int for any box that fits LDS
+      // outside the ROI the magnitude is 0: the halo lanes beyond the box forget their gradients (once, not per step)
+      if (!inbox) {
+#pragma unroll
+        for (int s0 = 0; s0 < SC; s0++) g[s0] = 0x80008000u;
+      }
     }
     low = s_int[0], high = s_int[1];
     DMZ_STOP_AFTER(2, low + high)
@@ -478,28 +468,21 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       int mc = 0, mc_lo = 0, mc_hi = 0;
       uint32_t gc = 0x80008000u;
       auto nms_step = [&](int sn, uint32_t gn) {
-        // outside the ROI the magnitude is 0
-        const int mn = (sn < SC && inbox) ? (int)__builtin_amdgcn_sad_u16(gn, 0x80008000u, 0u) : 0;
+        const int mn = (int)__builtin_amdgcn_sad_u16(gn, 0x80008000u, 0u);  // (0 from the zero gradient past the last step)
         const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);
-        if (sn >= 1 && owner) {
+        if (sn >= 1) {
           const uint32_t h = gc ^ 0x80008000u;
           const int dxc = (int)(short)(h & 0xffffu), dyc = (int)h >> 16;
-          nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo, mc_hi, mn, mn_lo, mn_hi,
-                          map, seg, seg_cap, ncand, s_int);
+          nms_pixel<VERT, LC>(bp, c, sn - 1, owner, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo, mc_hi, mn, mn_lo, mn_hi,
+                              map, seg, seg_cap, ncand, s_int);
         }
         mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;
         mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;
         gc = gn;
       };
 #pragma unroll
-      for (int sn = 0; sn < RG; sn++) nms_step(sn, g[sn]);
-      if constexpr (RG < SC) {
-#pragma unroll 1
-        for (int sn = RG; sn <= SC; sn++)
-          nms_step(sn, (sn < SC && inbox) ? gpark[(sn - RG) * L + c.l] : 0x80008000u);
-      } else {
-        nms_step(SC, 0x80008000u);
-      }
+      for (int sn = 0; sn < SC; sn++) nms_step(sn, g[sn]);
+      nms_step(SC, 0x80008000u);
       __syncthreads();
     }
   } else {
@@ -546,9 +529,9 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       mn = inbox ? iabs(dxn) + iabs(dyn) : 0; /* outside the ROI the magnitude is 0 */   \
     }                                                                                     \
     const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);                             \
-    if (sn >= 1 && owner)                                                                 \
-      nms_pixel<VERT>(bp, c, sn - 1, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo,    \
-                      mc_hi, mn, mn_lo, mn_hi, map, seg, seg_cap, ncand, s_int);          \
+    if (sn >= 1)                                                                          \
+      nms_pixel<VERT, 0>(bp, c, sn - 1, owner, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, \
+                         mc_lo, mc_hi, mn, mn_lo, mn_hi, map, seg, seg_cap, ncand, s_int);\
     mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;                                                \
     mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;                                                \
     dxc = dxn; dyc = dyn;                                                                 \
@@ -841,31 +824,21 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 
 // VERT = false: boxes 0 and 2 (top, bottom: horizontal lines, lanes = columns);
 // VERT = true:  boxes 1 and 3 (left, right: vertical lines, lanes = rows).
-// waves per SIMD the register allocation aims at: four workgroups per CU (what the LDS tiles allow)
-// Measured (ms per 16 384 frames, both boxes pairs): two walks everywhere 2.22; single walk for the
-// left/right boxes only 2.08; for the top/bottom boxes only 2.21 -- their 28 packed gradients push
-// the kernel from 62 to ~100 registers (two 448-thread workgroups per CU instead of four), and what
-// the walk saves in VALU issue (-33 % instructions) is lost to barrier and LDS latency at that
-// occupancy; with 72 registers forced the allocator spills 43 dwords and it is slower still.
+// Developer switches: 0 = the two-walk kernels also for the standard boxes.
 #ifndef DMZ_DETECT_SINGLE_H
 #define DMZ_DETECT_SINGLE_H 1
-#endif
-#ifndef DMZ_DETECT_REGS_H  /* top/bottom boxes: packed gradients kept in registers (the other 28 - n are parked in LDS) */
-#define DMZ_DETECT_REGS_H 14
 #endif
 #ifndef DMZ_DETECT_SINGLE_V
 #define DMZ_DETECT_SINGLE_V 1
 #endif
-#ifndef DMZ_DETECT_REGS_V  /* left/right boxes: packed gradients kept in registers */
-#define DMZ_DETECT_REGS_V 28
-#endif
+// waves per SIMD the register allocation aims at
 #ifndef DMZ_DETECT_WPS_H
 #define DMZ_DETECT_WPS_H 7
 #endif
 #ifndef DMZ_DETECT_WPS_V
 #define DMZ_DETECT_WPS_V 7  /* (round 5, same-box A/B over four alternations: 5.57 -> 5.49 ms for the stage; 6 before) */
 #endif
-template <bool VERT, int NT, int SC, int RG>
+template <bool VERT, int NT, int SC, int LC>
 __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H)) void k_detect_walk(const uint8_t *__restrict__ planes,
                                                      size_t frame_stride, int row_stride,
                                                      DmzDetectParams params,
@@ -875,7 +848,7 @@ __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DE
   const int frame = blockIdx.x >> 1;  // 1-D grid: gridDim.y is limited to 65535
   const int box_id = (blockIdx.x & 1) * 2 + (VERT ? 1 : 0);
   if (skip_mask && skip_mask[frame * 4 + box_id]) return;
-  detect_body<VERT, NT, SC, RG>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
+  detect_body<VERT, NT, SC, LC>(planes, frame_stride, row_stride, params.box[box_id], frame, box_id, hits, lds);
 }
 
 #ifdef DMZ_DUP
@@ -883,7 +856,7 @@ __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DE
 #else
 #define DMZ_DUP_DETECT 0
 #endif
-template <bool VERT, int NT, int SC, int RG>
+template <bool VERT, int NT, int SC, int LC>
 int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride, int n,
                 const DmzDetectParams &p, DmzBoxHit *hits, const int *skip_mask, int lds_bytes) {
   // (contexts may be driven from one host thread each: the once-per-geometry configuration below is serialised)
@@ -891,14 +864,14 @@ int launch_pair(hipStream_t s, const uint8_t *planes, size_t frame_stride, int r
   static int configured_lds = 0;  // per instantiation
   std::unique_lock<std::mutex> lk(mu);
   if (lds_bytes > configured_lds) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT, SC, RG>,
+    hipError_t e = hipFuncSetAttribute((const void *)k_detect_walk<VERT, NT, SC, LC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
     configured_lds = lds_bytes;
   }
   lk.unlock();
   for (int dup__ = 0; dup__ < 1 + (int)(DMZ_DUP_DETECT == (VERT ? 2 : 1)); dup__++)
-  hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC, RG>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
+  hipLaunchKernelGGL((k_detect_walk<VERT, NT, SC, LC>), dim3(2u * (unsigned)n), dim3(NT), lds_bytes, s, planes,
                      frame_stride, row_stride, p, hits, skip_mask);
   return 0;
 }
@@ -910,22 +883,21 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
   const int nt = a.nthreads > b.nthreads ? a.nthreads : b.nthreads;
   const int lds = a.lds_total > b.lds_total ? a.lds_total : b.lds_total;
   // the boxes of a 640 x 480 frame (28 steps x 389 lanes, 38 steps x 241 lanes): single-walk kernels
-  constexpr int kSteps = VERT ? 38 : 28, kNt = VERT ? 256 : 448, kRegs = VERT ? DMZ_DETECT_REGS_V : DMZ_DETECT_REGS_H;
-  auto parks = [](const DmzBoxParams &q) {  // the parked gradients and a list of >= 1024 entries fit, the map fits the tile
-    return q.lds_red - q.lds_map - ((4 * q.lanes * (kSteps - kRegs) + 15) & ~15) >= 2048 && q.lanes * q.steps <= q.lds_map;
+  constexpr int kSteps = VERT ? 38 : 28, kLanes = VERT ? 241 : 389, kNt = VERT ? 256 : 448;
+  auto compact = [](const DmzBoxParams &q) {  // a list of >= 1024 entries fits behind the tile, the map fits the tile
+    return q.lds_red - q.lds_map >= 2048 && q.lanes * q.steps <= q.lds_map;
   };
-  if (a.steps == kSteps && b.steps == kSteps && nt <= kNt && (VERT ? DMZ_DETECT_SINGLE_V : DMZ_DETECT_SINGLE_H) &&
-      (kRegs == kSteps || (parks(a) && parks(b)))) {
-    if (kRegs == kSteps) return launch_pair<VERT, kNt, kSteps, kRegs>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
-    // Parked form: the edge map lies over the tile, so what follows the tile is ONE region with two tenants -- the parked
-    // gradients + the candidate lists until the hysteresis is done, then the vote counters: tile | region | scratch
-    // (21.6 KB instead of 30 KB for the left/right boxes of a 640 x 480 frame).
+  if (a.steps == kSteps && b.steps == kSteps && a.lanes == kLanes && b.lanes == kLanes && nt <= kNt &&
+      (VERT ? DMZ_DETECT_SINGLE_V : DMZ_DETECT_SINGLE_H) && compact(a) && compact(b)) {
+    // Compact layout: the edge map lies over the tile, so what follows the tile is ONE region with two tenants -- the
+    // candidate lists until the hysteresis is done, then the vote counters: tile | region | scratch
+    // (20.6 KB instead of 30 KB for the left/right boxes of a 640 x 480 frame).
     // What the device holds, asked once: LDS per CU, and how many workgroups of this kernel the register file and the wave
     // slots admit (the occupancy query with no dynamic LDS).  No literals: a different part or compiler changes the answer.
     static std::mutex mu;  // the cached device answers and the per-geometry check: one thread at a time
     std::unique_lock<std::mutex> lk(mu);
     static int lds_cu = 0, wgs_regs = 0;
-    const void *kfn = (const void *)k_detect_walk<VERT, kNt, kSteps, kRegs>;
+    const void *kfn = (const void *)k_detect_walk<VERT, kNt, kSteps, kLanes>;
     if (lds_cu == 0) {
       int dev = 0, v = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
@@ -944,8 +916,8 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
       int wgs_min = 1 << 20;
       for (int e = VERT ? 1 : 0; e < 4; e += 2) {
         DmzBoxParams &bx = q.box[e];
-        const int park = (4 * bx.lanes * (kSteps - kRegs) + 15) & ~15, acc = bx.lds_red - bx.lds_acc;
-        int region = ((park + 2048 > acc ? park + 2048 : acc) + 15) & ~15;
+        const int acc = bx.lds_red - bx.lds_acc;
+        int region = ((2048 > acc ? 2048 : acc) + 15) & ~15;
         // the candidate lists take what the workgroups-per-CU count leaves over (busy frames then stay on the list path
         // instead of the whole-map fallback): the count is the smaller of what LDS and the registers / wave slots allow
         const int tile = bx.lds_map;
@@ -977,7 +949,7 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
     }
     if (!checked_ok) (void)layout(false);
     lk.unlock();
-    return launch_pair<VERT, kNt, kSteps, kRegs>(s, planes, frame_stride, row_stride, n, q, hits, skip_mask, total);
+    return launch_pair<VERT, kNt, kSteps, kLanes>(s, planes, frame_stride, row_stride, n, q, hits, skip_mask, total);
   }
   if (nt <= 256) return launch_pair<VERT, 256, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);
   if (nt <= 448) return launch_pair<VERT, 448, 0, 0>(s, planes, frame_stride, row_stride, n, p, hits, skip_mask, lds);

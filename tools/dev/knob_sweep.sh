@@ -14,10 +14,8 @@ run() {  # name file stage flags...
 }
 if [ $WHAT == detect ] || [ $WHAT == all ]; then
 run base detect.hip detect
-for r in 10 12 16 18 20; do run regsH$r detect.hip detect -DDMZ_DETECT_REGS_H=$r; done
 for w in 6 8; do run wpsH$w detect.hip detect -DDMZ_DETECT_WPS_H=$w; done
-for r in 24 32 38; do run regsV$r detect.hip detect -DDMZ_DETECT_REGS_V=$r; done
-for w in 5 7; do run wpsV$w detect.hip detect -DDMZ_DETECT_WPS_V=$w; done
+for w in 6 8; do run wpsV$w detect.hip detect -DDMZ_DETECT_WPS_V=$w; done
 for f in 6 10 12; do run infl$f detect.hip detect -DDMZ_DT_INFLIGHT=$f; done
 run base2 detect.hip detect
 fi
