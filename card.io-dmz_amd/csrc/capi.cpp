@@ -223,25 +223,46 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
   const int numangle = (int)lrint((double)((theta_max - theta_min) / theta));
   if (numangle != kNumAngle) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "unexpected Hough angle count");
   bp.numrho = (int)lrint((double)(((bp.w + bp.h) * 2 + 1) / rho));
+  float ang = theta_min;
+  for (int n = 0; n < kNumAngle; ang += theta, n++) {
+    bp.tab_sin[n] = (int)floorf(1024 * sinf(ang) * irho);
+    bp.tab_cos[n] = (int)floorf(1024 * cosf(ang) * irho);
+  }
+  // Which rho bins can a pixel of THIS box vote for?  t = col * cos_n + r * sin_n is linear in the pixel, so its extremes
+  // over the ROI are at the corners; the box is thin and its angles lie within 5 degrees of its own direction, so they span a
+  // few dozen of the numrho = 2 (w + h) + 1 bins (97 of 835 for the top / bottom boxes of a 640 x 480 frame, 81 of 559 for
+  // the left / right ones).  Only those have counters: every other bin stays at zero votes in the reference too, and a zero
+  // never wins the strict-greater scan (hough.cpp:163-176) -- so zeroing, voting and the arg-max run over rho_cnt bins
+  // per angle, in the same (r, n) order.
+  {
+    const int half = (bp.numrho - 1) / 2;
+    int lo = 1 << 30, hi = -(1 << 30);
+    for (int n = 0; n < kNumAngle; n++)
+      for (int cnr = 0; cnr < 4; cnr++) {
+        const int col = (cnr & 1) ? bp.w - 1 : 0, r = (cnr & 2) ? bp.h - 1 : 0;
+        const int rr = half + ((col * bp.tab_cos[n] + r * bp.tab_sin[n]) >> 10);  // hough.cpp:150-153
+        lo = rr < lo ? rr : lo;
+        hi = rr > hi ? rr : hi;
+      }
+    if (lo < 0 || hi >= bp.numrho) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "Hough rho range outside the accumulator");
+    bp.rho_lo = lo;
+    bp.rho_cnt = hi - lo + 1;
+  }
   {
     const int tile_bytes = (sp * bp.steps + 15) & ~15;
     const int map_bytes = (bp.w * bp.h + 15) & ~15;
-    const int acc_bytes = (bp.numrho * kNumAngle * 2 + 15) & ~15;  // u16 vote counters
+    int acc_bytes = (bp.rho_cnt * kNumAngle * 2 + 15) & ~15;  // u16 vote counters
+    if (acc_bytes < 2048) acc_bytes = 2048;  // (the two-walk kernels keep their candidate lists there: >= 1024 entries)
     bp.lds_map = tile_bytes;
     bp.lds_acc = tile_bytes + map_bytes;
     bp.lds_red = bp.lds_acc + acc_bytes;
     bp.lds_total = bp.lds_red + 512;
     bp.list_cap = acc_bytes / 2;
-    // (numrho * kNumAngle < 2^16: the arg-max packs votes and scan position into one 32-bit key; implied by the LDS bound)
+    // (numrho * kNumAngle < 2^16: the arg-max packs votes and scan position into one 32-bit key)
     if (bp.lds_total > kDetectMaxLds || bp.nthreads > kDetectMaxThreads || bp.w * bp.h > 65535 ||
         bp.numrho * kNumAngle > 65535)
       return fail(ctx, DMZ_HIP_EUNSUPPORTED,
                   "detection box does not fit the LDS-resident detect kernel");
-  }
-  float ang = theta_min;
-  for (int n = 0; n < kNumAngle; ang += theta, n++) {
-    bp.tab_sin[n] = (int)floorf(1024 * sinf(ang) * irho);
-    bp.tab_cos[n] = (int)floorf(1024 * cosf(ang) * irho);
   }
   const float gat = 10;  // kHoughGradientAngleThreshold
   if (vertical) {

@@ -189,7 +189,9 @@ __device__ __forceinline__ int lane_above(int v) { return __builtin_amdgcn_updat
 constexpr int kDenseList = 96;
 
 // NMS (canny.cpp:213-285) + Hough slope gate (hough.cpp:133-150) for pixel (lane, step s),
-// given its gradient and the magnitudes of (own, lane-1, lane+1) at steps s-1 / s / s+1.
+// given its gradient and its magnitude at steps s-1 / s / s+1 (mp, mc, mn; the neighbouring lanes' are fetched here, by
+// DPP, and only in wave-steps that get past the threshold test: every lane of the wave must call -- a DPP source lane has
+// to be active).
 // The reference's branches are kept: a wave whose 62 pixels are all below the low threshold (most of
 // the background) skips everything -- the map was zeroed beforehand (thresholds_from) and is written for
 // pixels above the threshold only --, and the slope gate runs only where a pixel survived
@@ -198,13 +200,14 @@ constexpr int kDenseList = 96;
 // (the boxes of a 640 x 480 frame: the map offset of a step is then an immediate of the LDS store), else 0.
 template <bool VERT, int LC>
 __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, bool owner, int low,
-                                          int high, int dxc, int dyc, int mp, int mp_lo, int mp_hi,
-                                          int mc, int mc_lo, int mc_hi, int mn, int mn_lo, int mn_hi,
-                                          unsigned char *map, unsigned short *seg, int seg_cap, int &ncand, int *s_int) {
+                                          int high, int dxc, int dyc, int mp, int mc, int mn, unsigned char *map, unsigned short *seg, int seg_cap, int &ncand, int *s_int) {
   const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
   const int m = mc;
   const bool above = owner && m > low;
-  if (__ballot(above) == 0ull) return;  // (wave-uniform)
+  if (__builtin_amdgcn_ballot_w64(above) == 0ull) return;  // (wave-uniform)
+  const int mp_lo = lane_below(mp), mp_hi = lane_above(mp);
+  const int mc_lo = lane_below(mc), mc_hi = lane_above(mc);
+  const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);
   // neighbours in image coordinates
   int mN, mS, mW, mE, mNW, mNE, mSW, mSE;
   if (!VERT) {  // row = step, col = lane
@@ -253,7 +256,7 @@ __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx 
   // candidates that are not seeds go on THIS WAVE's list (seeds need no propagation): the count is wave-uniform,
   // so an append is a ballot and a prefix count -- no LDS atomic, no wait
   const bool cand = (flags & (MAP_CAND | MAP_EDGE)) == MAP_CAND;
-  const unsigned long long bal = __ballot(cand);
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
   if (bal) {
     if (cand) {
       const int slot = ncand + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
@@ -463,21 +466,18 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     low = s_int[0], high = s_int[1];
     DMZ_STOP_AFTER(2, low + high)
     {
-      // magnitudes of (own, lane-1, lane+1) at steps s-1 (p), s (c), s+1 (n)
-      int mp = 0, mp_lo = 0, mp_hi = 0;
-      int mc = 0, mc_lo = 0, mc_hi = 0;
+      // the lane's magnitudes at steps s-1 (p), s (c), s+1 (n)
+      int mp = 0, mc = 0;
       uint32_t gc = 0x80008000u;
       auto nms_step = [&](int sn, uint32_t gn) {
         const int mn = (int)__builtin_amdgcn_sad_u16(gn, 0x80008000u, 0u);  // (0 from the zero gradient past the last step)
-        const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);
         if (sn >= 1) {
           const uint32_t h = gc ^ 0x80008000u;
           const int dxc = (int)(short)(h & 0xffffu), dyc = (int)h >> 16;
-          nms_pixel<VERT, LC>(bp, c, sn - 1, owner, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, mc_lo, mc_hi, mn, mn_lo, mn_hi,
-                              map, seg, seg_cap, ncand, s_int);
+          nms_pixel<VERT, LC>(bp, c, sn - 1, owner, low, high, dxc, dyc, mp, mc, mn, map, seg, seg_cap, ncand, s_int);
         }
-        mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;
-        mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;
+        mp = mc;
+        mc = mn;
         gc = gn;
       };
 #pragma unroll
@@ -516,9 +516,8 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   {
     Window wn;
     window_init(c, wn);
-    // magnitudes of (own, lane-1, lane+1) at steps s-1 (p), s (c), s+1 (n)
-    int mp = 0, mp_lo = 0, mp_hi = 0;
-    int mc = 0, mc_lo = 0, mc_hi = 0;
+    // the lane's magnitudes at steps s-1 (p), s (c), s+1 (n)
+    int mp = 0, mc = 0;
     int dxc = 0, dyc = 0;
 #define DMZ_P2_STEP(K)                                                                   \
   if (s0 + K <= S) {                                                                      \
@@ -528,12 +527,11 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       window_step<VERT, K>(c, wn, sn, dxn, dyn);                                          \
       mn = inbox ? iabs(dxn) + iabs(dyn) : 0; /* outside the ROI the magnitude is 0 */   \
     }                                                                                     \
-    const int mn_lo = lane_below(mn), mn_hi = lane_above(mn);                             \
     if (sn >= 1)                                                                          \
-      nms_pixel<VERT, 0>(bp, c, sn - 1, owner, low, high, dxc, dyc, mp, mp_lo, mp_hi, mc, \
-                         mc_lo, mc_hi, mn, mn_lo, mn_hi, map, seg, seg_cap, ncand, s_int);\
-    mp = mc; mp_lo = mc_lo; mp_hi = mc_hi;                                                \
-    mc = mn; mc_lo = mn_lo; mc_hi = mn_hi;                                                \
+      nms_pixel<VERT, 0>(bp, c, sn - 1, owner, low, high, dxc, dyc, mp, mc, mn, map, seg, \
+                         seg_cap, ncand, s_int);                                          \
+    mp = mc;                                                                              \
+    mc = mn;                                                                              \
     dxc = dxn; dyc = dyn;                                                                 \
   }
     for (int s0 = 0; s0 <= S; s0 += 7) {
@@ -570,8 +568,8 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       unsigned long long C = 0ull, E = 0ull;
       for (int a = 0; a < S; a++) {
         const int fl = inbox ? (int)map[a * L + c.l] : 0;
-        const unsigned long long bc = __ballot((fl & MAP_CAND) != 0) & 0x7ffffffffffffffeull,
-                                 be = __ballot((fl & MAP_EDGE) != 0) & 0x7ffffffffffffffeull;
+        const unsigned long long bc = __builtin_amdgcn_ballot_w64((fl & MAP_CAND) != 0) & 0x7ffffffffffffffeull,
+                                 be = __builtin_amdgcn_ballot_w64((fl & MAP_EDGE) != 0) & 0x7ffffffffffffffeull;
         if (lane == a) C = bc, E = be;
       }
       auto lane_dn = [](unsigned long long v) {  // the word of lane - 1 (0 at lane 0)
@@ -604,7 +602,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
           }
           const bool ch = g != E;
           E = g;
-          if (__ballot(ch) == 0ull) break;
+          if (__builtin_amdgcn_ballot_w64(ch) == 0ull) break;
           any = 1;
         }
         if (!__syncthreads_or(any)) break;
@@ -626,7 +624,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       for (int a = 0; a < S; a++) {  // this wave's column of words
         const int q = a * L + c.l;
         const int fl = inbox ? (int)map[q] : 0;
-        const unsigned long long bc = __ballot((fl & MAP_CAND) != 0), be = __ballot((fl & MAP_EDGE) != 0);
+        const unsigned long long bc = __builtin_amdgcn_ballot_w64((fl & MAP_CAND) != 0), be = __builtin_amdgcn_ballot_w64((fl & MAP_EDGE) != 0);
         if (lane == 0) {
           bcand[a * NW + wave] = bc & 0x7ffffffffffffffeull;
           bedge[a * NW + wave] = be & 0x7ffffffffffffffeull;
@@ -729,12 +727,13 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   DMZ_STOP_AFTER(4, map[0] + map[N - 1])
 
   // ---- E. Hough accumulator (hough.cpp:127-161), u16 counters packed in 32-bit words ----
-  const int numrho = bp.numrho;
+  // Counters exist for the rho bins a pixel of this box can reach only (bp.rho_lo, bp.rho_cnt: fill_box_params).
+  const int numrho = bp.rho_cnt;
   const int ncell = kNumAngle * numrho;
   for (int i = tid; i < (ncell + 1) / 2; i += NT) acc32[i] = 0;
   __syncthreads();
   {
-    const int half = (numrho - 1) / 2;
+    const int half = (bp.numrho - 1) / 2 - bp.rho_lo;
     const uint32_t *map32 = (const uint32_t *)map;  // lds_map is 16-byte aligned
     for (int q4 = tid; q4 < (N + 3) >> 2; q4 += NT) {
       const uint32_t w4 = map32[q4];
@@ -761,8 +760,8 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
             // atomic at 2 cycles per lane (tools/ubench/lds_atomic_rate.hip: 127 cycles for 64 lanes against 4 for 64
             // different counters).  One lane adds the count for all of them.
             const int c0 = __builtin_amdgcn_readfirstlane(cell);
-            const unsigned long long act = __ballot(true);
-            if (__ballot(cell != c0) == 0ull) {
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            if (__builtin_amdgcn_ballot_w64(cell != c0) == 0ull) {
               if ((int)(threadIdx.x & 63) == __builtin_ctzll(act))
                 atomicAdd(&acc32[c0], (unsigned)__popcll(act) << ((n & 1) * 16));
               continue;
@@ -778,12 +777,12 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
   static_assert(kNumAngle % 2 == 0, "vote counters are packed in angle pairs");
 
   // ---- F. arg-max with the reference's scan order (hough.cpp:163-176) ----
-  // One 32-bit key per cell: votes (< 2^16) above the complement of the scan position (the counters of a box fit 64 KB
-  // of LDS, so there are fewer than 2^16 cells): the maximum key is the first strict maximum of the reference's scan.
+  // One 32-bit key per cell: votes (< 2^16) above the complement of the scan position (numrho * 10 < 2^16): the
+  // maximum key is the first strict maximum of the reference's scan.  The bins without counters hold zero votes.
   unsigned int best = 0;
   {
     for (int p = 0; p < kNumAngle / 2; p++) {
-      const unsigned int obase = 0xffffu - (unsigned int)(2 * p);
+      const unsigned int obase = 0xffffu - (unsigned int)(2 * p + bp.rho_lo * kNumAngle);
       for (int rr = tid; rr < numrho; rr += NT) {
         const unsigned int w2 = acc32[p * numrho + rr];
         const unsigned int o0 = obase - (unsigned int)(rr * kNumAngle);  // 0xffff - scan position of the low half
@@ -836,7 +835,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 #define DMZ_DETECT_WPS_H 7
 #endif
 #ifndef DMZ_DETECT_WPS_V
-#define DMZ_DETECT_WPS_V 7  /* (round 5, same-box A/B over four alternations: 5.57 -> 5.49 ms for the stage; 6 before) */
+#define DMZ_DETECT_WPS_V 8  /* (63 registers; the compact layout with counters for the reachable rho bins only is 12 KB: eight workgroups per CU) */
 #endif
 template <bool VERT, int NT, int SC, int LC>
 __global__ __launch_bounds__(NT, SC == 0 ? 1 : (VERT ? DMZ_DETECT_WPS_V : DMZ_DETECT_WPS_H)) void k_detect_walk(const uint8_t *__restrict__ planes,

@@ -42,6 +42,7 @@ struct DmzBoxParams {
   int x, y, w, h;        // ROI in the plane (dmz.cpp:279-341)
   int vertical;          // LineOrientationVertical (left/right boxes)
   int numrho;            // hough.cpp:99
+  int rho_lo, rho_cnt;   // the rho bins a pixel of this box can vote for: [rho_lo, rho_lo + rho_cnt) (fill_box_params)
   int threshold;         // max(w,h)/6, dmz.cpp:246
   int tab_sin[kNumAngle];
   int tab_cos[kNumAngle];
