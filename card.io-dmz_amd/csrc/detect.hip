@@ -107,10 +107,8 @@ struct Window {
   int b1, b2;    // level 4 of the across-smooth cascade one and two pushes ago
 };
 
-// push along-position a (clamped by the caller's arithmetic); after the push of position t the filters centred on t - 3 are out
-__device__ __forceinline__ void window_push(const WalkCtx &c, Window &wn, int a, int &g_ds, int &g_sd) {
-  int ad, as;
-  across_taps(c, a, ad, as);
+// push the across-axis pair (ad, as) of one along-position; after the push of position t the filters centred on t - 3 are out
+__device__ __forceinline__ void window_push_taps(Window &wn, int ad, int as, int &g_ds, int &g_sd) {
   int v = ad;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -130,6 +128,12 @@ __device__ __forceinline__ void window_push(const WalkCtx &c, Window &wn, int a,
   wn.b2 = wn.b1;
   wn.b1 = u;
 }
+// push along-position a (clamped by the caller's arithmetic)
+__device__ __forceinline__ void window_push(const WalkCtx &c, Window &wn, int a, int &g_ds, int &g_sd) {
+  int ad, as;
+  across_taps(c, a, ad, as);
+  window_push_taps(wn, ad, as, g_ds, g_sd);
+}
 
 __device__ __forceinline__ void window_init(const WalkCtx &c, Window &wn) {
   // along positions -3..+2 (position +3 is pushed by the first window_step): whatever the zeroed state contributes has left
@@ -139,11 +143,13 @@ __device__ __forceinline__ void window_init(const WalkCtx &c, Window &wn) {
 #pragma unroll
   for (int k = 0; k < 4; k++) wn.ps[k] = 0;
   wn.b1 = wn.b2 = 0;
+  // (positions -3 .. 0 are all row 0 -- replicate border: its pair is evaluated once)
+  int g_ds, g_sd, ad0, as0;
+  across_taps(c, 0, ad0, as0);
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    int g_ds, g_sd;
-    window_push(c, wn, clampi(i - 3, 0, c.S - 1), g_ds, g_sd);
-  }
+  for (int i = 0; i < 4; i++) window_push_taps(wn, ad0, as0, g_ds, g_sd);
+  window_push(c, wn, clampi(1, 0, c.S - 1), g_ds, g_sd);
+  window_push(c, wn, clampi(2, 0, c.S - 1), g_ds, g_sd);
 }
 
 // step s: push position s+3, return the saturated (dx, dy)
@@ -171,11 +177,6 @@ __device__ __forceinline__ int add_abs_sat(uint32_t g, int acc) {
   const u16x2 one = {1, 1};
   const u16x2 lifted = __builtin_elementwise_max(__builtin_bit_cast(u16x2, g), one);
   return (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, lifted), 0x80008000u, (uint32_t)acc);
-}
-
-template <bool VERT, bool SAT = true>
-__device__ __forceinline__ void window_step_s(const WalkCtx &c, Window &wn, int s, int &dx, int &dy) {
-  window_step<VERT, 0, SAT>(c, wn, s, dx, dy);
 }
 
 // lane - 1 / lane + 1 of the wave by DPP (wave_shr:1 / wave_shl:1; the end lanes, which own no pixel, read 0):
@@ -449,11 +450,18 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       Window wn;
       window_init(c, wn);
       int acc = 0;
+      int ad_last = 0, as_last = 0;  // the across pair of the last row: pushed four times (replicate border)
 #pragma unroll
       for (int s0 = 0; s0 < SC; s0++) {
-        int dx, dy;
-        window_step_s<VERT, false>(c, wn, s0, dx, dy);
-        g[s0] = pack_gradient(dx, dy);
+        int g_ds, g_sd;  // along axis: the derivative smoothed, the smooth differentiated
+        if (s0 + 3 < SC - 1) {
+          window_push(c, wn, s0 + 3, g_ds, g_sd);
+        } else {
+          if (s0 + 3 == SC - 1) across_taps(c, SC - 1, ad_last, as_last);
+          window_push_taps(wn, ad_last, as_last, g_ds, g_sd);
+        }
+        // top/bottom boxes: across = x  => dx = g_ds, dy = g_sd ; left/right boxes: across = y
+        g[s0] = pack_gradient(VERT ? g_sd : g_ds, VERT ? g_ds : g_sd);
         acc = add_abs_sat(g[s0], acc);
       }
       thresholds_from(owner ? (long long)acc : 0ll);  // steps * 65534 fits an int for any box that fits LDS
@@ -752,7 +760,9 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
         for (int n = 0; n < kNumAngle; n++) {
           // counter of (n, rr): half n & 1 of word (n >> 1) * numrho + rr -- the half is a
           // compile-time constant per angle; counts < 65536, so no carry between the halves
-          const int t = col * bp.tab_cos[n] + r * bp.tab_sin[n];
+          // (24-bit multiplies: coordinates < 2^16, table entries within +-1024 -- the plain int form compiled to
+          // v_mul_lo_u32 + v_mad_u64_u32)
+          const int t = __mul24(col, bp.tab_cos[n]) + __mul24(r, bp.tab_sin[n]);
           const int cell = (n >> 1) * numrho + half + (t >> 10);
           if (n == kNumAngle / 2) {
             // The middle angle is the box's own direction (its table entry across the box is 0 or -1): the voters of one
@@ -785,7 +795,7 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
       const unsigned int obase = 0xffffu - (unsigned int)(2 * p + bp.rho_lo * kNumAngle);
       for (int rr = tid; rr < numrho; rr += NT) {
         const unsigned int w2 = acc32[p * numrho + rr];
-        const unsigned int o0 = obase - (unsigned int)(rr * kNumAngle);  // 0xffff - scan position of the low half
+        const unsigned int o0 = obase - (unsigned int)__mul24(rr, kNumAngle);  // 0xffff - scan position of the low half
         const unsigned int k0 = (w2 << 16) | o0, k1 = (w2 & 0xffff0000u) | (o0 - 1u);
         best = k0 > best ? k0 : best;
         best = k1 > best ? k1 : best;
