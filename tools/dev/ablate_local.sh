@@ -8,7 +8,7 @@ mkdir -p variants
 while [ $# -gt 1 ]; do
   TAG=$1; FLAGS=$2; shift 2
   (
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude $FLAGS -c $P/csrc/$FILE -o variants/$TAG.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$P/csrc $FLAGS -c $P/csrc/$FILE -o variants/$TAG.o 2>/dev/null
   OBJS=""
   for f in detect geometry warp vseg hseg digits expiry session plumbing synth capi weights_blob; do
     if [ "$f.hip" == "$FILE" ]; then OBJS="$OBJS variants/$TAG.o"; else OBJS="$OBJS $P/csrc/$f.o"; fi
