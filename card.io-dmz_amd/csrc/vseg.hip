@@ -104,35 +104,52 @@ __device__ __forceinline__ RowRaw vseg_row_load(const uint8_t *__restrict__ row,
 // active LDS cycles in round 2); with the flip rows 8..15 of a tile use the other half of each 32-byte group.
 __device__ __forceinline__ int vs_swz(int row) { return (row & 8) << 1; }
 
-__device__ __forceinline__ void vseg_row_features(const RowRaw &rw, unsigned char *__restrict__ grow, int swz,
+// Round 5: the eight 3-tap gradients of a lane on PACKED 16-bit pairs.  With b0..b11 the lane's twelve bytes, output m needs
+// a, b, c, e = b[1 + 2m .. 4 + 2m]: the four sequences over m = 0..3 are unpacked into two registers of two zero-extended
+// bytes each (one v_perm_b32 per register; the replicate fix-ups at the ROI ends -- column 9 -> 10 on lane 0, column 418 ->
+// 417 on lanes >= 50 -- are a different byte selector on those lanes, a per-lane constant: VsegSel), max(b, c) / min(b, c)
+// are shared between the two gradients of an output, and everything up to the packed bytes is v_pk_*_u16: 38 instructions
+// per row where the byte-at-a-time form took ~55.
+struct VsegSel {
+  uint32_t a01, e23;  // selectors of {b1, b3} (lane 0: {b2, b3}) and {b8, b10} (lanes >= 50: {b8, b9})
+};
+__device__ __forceinline__ VsegSel vseg_selectors(int lane) {
+  VsegSel q;
+  q.a01 = lane == 0 ? 0x0c030c02u : 0x0c030c01u;
+  q.e23 = lane >= 50 ? 0x0c010c00u : 0x0c020c00u;
+  return q;
+}
+typedef unsigned short vs_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vs_u16x2 vs_pk(uint32_t v) { return __builtin_bit_cast(vs_u16x2, v); }
+__device__ __forceinline__ uint32_t vs_u32(vs_u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+__device__ __forceinline__ void vseg_row_features(const RowRaw &rw, const VsegSel &sel, unsigned char *__restrict__ grow, int swz,
                                                   float *__restrict__ norm /* 2 */, int lane) {
-  int b[12];
+  // v_perm_b32(S0, S1, sel): selector byte 0..3 = byte of S1, 4..7 = byte of S0, 0x0c = zero
+  const vs_u16x2 A[2] = {vs_pk(__builtin_amdgcn_perm(rw.w0, rw.w0, sel.a01)),       // {b1, b3}
+                         vs_pk(__builtin_amdgcn_perm(rw.w1, rw.w1, 0x0c030c01u))};  // {b5, b7}
+  const vs_u16x2 B[2] = {vs_pk(__builtin_amdgcn_perm(rw.w1, rw.w0, 0x0c040c02u)),   // {b2, b4}
+                         vs_pk(__builtin_amdgcn_perm(rw.w2, rw.w1, 0x0c040c02u))};  // {b6, b8}
+  const vs_u16x2 C[2] = {vs_pk(__builtin_amdgcn_perm(rw.w1, rw.w0, 0x0c050c03u)),   // {b3, b5}
+                         vs_pk(__builtin_amdgcn_perm(rw.w2, rw.w1, 0x0c050c03u))};  // {b7, b9}
+  const vs_u16x2 E[2] = {vs_pk(__builtin_amdgcn_perm(rw.w1, rw.w1, 0x0c020c00u)),   // {b4, b6}
+                         vs_pk(__builtin_amdgcn_perm(rw.w2, rw.w2, sel.e23))};      // {b8, b10}
+  const vs_u16x2 one = {1, 1};
+  vs_u16x2 d[2];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    b[k] = (rw.w0 >> (8 * k)) & 255;
-    b[4 + k] = (rw.w1 >> (8 * k)) & 255;
-    b[8 + k] = (rw.w2 >> (8 * k)) & 255;
+  for (int h = 0; h < 2; h++) {
+    const vs_u16x2 mx = __builtin_elementwise_max(B[h], C[h]), mn = __builtin_elementwise_min(B[h], C[h]);
+    const vs_u16x2 g0 = __builtin_elementwise_max(A[h], mx) - __builtin_elementwise_min(A[h], mn);  // grad[2o]
+    const vs_u16x2 g1 = __builtin_elementwise_max(mx, E[h]) - __builtin_elementwise_min(mn, E[h]);  // grad[2o+1]
+    d[h] = (g0 + g1 + one) >> 1;
   }
-  // replicate at the ROI ends: column 9 -> column 10 (lane 0), column 418 -> 417 (lane 50)
-  if (lane == 0) b[1] = b[2];
-  if (lane >= 50) b[10] = b[9];
-  int d[4];
-  int vmin = 255, vmax = 0;
-#pragma unroll
-  for (int m = 0; m < 4; m++) {
-    const int a = b[1 + 2 * m], bb = b[2 + 2 * m], c = b[3 + 2 * m], e = b[4 + 2 * m];
-    const int g0 = max3i(a, bb, c) - min3i(a, bb, c);  // grad[2o]
-    const int g1 = max3i(bb, c, e) - min3i(bb, c, e);  // grad[2o+1]
-    d[m] = (g0 + g1 + 1) >> 1;
-    vmin = imin(vmin, d[m]);
-    vmax = imax(vmax, d[m]);
-  }
+  const vs_u16x2 lo2 = __builtin_elementwise_min(d[0], d[1]), hi2 = __builtin_elementwise_max(d[0], d[1]);
+  int vmin = (int)(lo2.x < lo2.y ? lo2.x : lo2.y), vmax = (int)(hi2.x > hi2.y ? hi2.x : hi2.y);
   // (lanes >= 51 hold lane 50's values)
   vmin = 255 - (int)dmzwave::max_u32((unsigned)(255 - vmin));
   vmax = (int)dmzwave::max_u32((unsigned)vmax);
   if (lane < 56)  // lanes 51..55 write the zero k-tail 204..223
-    *(uint32_t *)(grow + ((4 * lane) ^ swz)) =
-        lane < 51 ? (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24) : 0u;
+    *(uint32_t *)(grow + ((4 * lane) ^ swz)) = lane < 51 ? __builtin_amdgcn_perm(vs_u32(d[1]), vs_u32(d[0]), 0x06040200u) : 0u;
   // the row's (min, max) parked as two integers; vseg_row_norms turns them into (scale, shift) for many rows
   // at once (the fp64 division costs ~30 issue slots whether one lane or 64 need it)
   if (lane == 0) {
@@ -161,6 +178,7 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
                                                   const unsigned short *__restrict__ row_y, int nrows,
                                                   unsigned char *__restrict__ grad,
                                                   float *__restrict__ norm, int wave, int lane) {
+  const VsegSel sel = vseg_selectors(lane);
   for (int i0 = wave; i0 < nrows; i0 += VS_WAVES * VS_RIF) {
     RowRaw raw[VS_RIF];
 #pragma unroll
@@ -171,7 +189,7 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
 #pragma unroll
     for (int k = 0; k < VS_RIF; k++) {
       const int i = i0 + k * VS_WAVES;
-      if (i < nrows) vseg_row_features(raw[k], grad + i * VS_GSTRIDE, vs_swz(i), norm + 2 * i, lane);
+      if (i < nrows) vseg_row_features(raw[k], sel, grad + i * VS_GSTRIDE, vs_swz(i), norm + 2 * i, lane);
     }
   }
   vseg_row_norms(norm, nrows, wave, lane);
