@@ -22,18 +22,19 @@
 // left/right boxes, whose tile is transposed while it is loaded; 62 outputs + 2
 // halo lanes per wave) and every lane walks the short axis with a 7-deep
 // register window.  The across-axis 7-tap pair is three aligned LDS dwords, two
-// v_alignbyte and five v_dot4_u32_u8; the separable Sobel, the |dx|+|dy|
+// v_alignbyte and four v_dot4_u32_u8; the separable Sobel, the |dx|+|dy|
 // magnitude and the 3x3 non-maximum suppression never leave registers:
 // neighbours along the walk are the lane's own previous/next step, neighbours
-// across are the adjacent lanes (two wave shifts per step).  LDS holds only the
+// across are the adjacent lanes (DPP wave shifts, fetched only in wave-steps that have
+// a pixel above the low threshold).  LDS holds only the
 // u8 source tile, the u8 edge map and the u16 vote counters, so one workgroup's barriers
 // are covered by the others.  The adaptive thresholds need the box-wide mean of
 // |dx|+|dy| before NMS.  For the standard geometry (28- and 38-step boxes of a
 // 640 x 480 frame) the walk runs ONCE: the lane keeps the (dx, dy) of its 28 / 38
 // steps packed as sign-flipped s16 pairs in registers (one v_sad_u16 against
 // 0x80008000 gives |dx| + |dy| back), and the NMS pass reads them from there; the
-// edge map then lies over the tile (27.7 KB / 20.6 KB per workgroup: 28 waves per CU
-// either way).  Other box sizes take the two-walk form (sum pass, NMS pass), which
+// edge map then lies over the tile and the vote counters exist for the rho bins the box's
+// pixels can reach only (27.7 KB / 12 KB per workgroup: 28 / 32 waves per CU).  Other box sizes take the two-walk form (sum pass, NMS pass), which
 // recomputes the gradients.  (Rounds 2 - 4 kept 14 / 28 of the gradients in registers
 // and parked the rest in LDS: with round 5's NMS the kernels need 52 / 63 registers
 // with all of them resident.)

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   //     cvRound(exact fX) unless its low 16 bits are exactly 0 (a multiple of 2^16 within 3/4 unit:
   //     the only place where floor, the half-way case of round-to-even included, can differ).
   //   * lanes whose dword has zero low bits (2^-16 per coordinate) take the exact sequence; the test
-  //     is one v_min3_u16 + v_min_u16 + compare per pixel pair, the branch is wave-uniform.
+  //     is three v_min_u16 + one compare per pixel pair, the branch is wave-uniform.
   // (the uniform constants come from k_warp_windows through scalar loads: the fma needs no copy of its addend, and no wave
   // spends vector instructions on them)
   const double sW = wm.sw;  // Wd(row + 1) - Wd(row)
