@@ -251,7 +251,8 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
   {
     const int tile_bytes = (sp * bp.steps + 15) & ~15;
     const int map_bytes = (bp.w * bp.h + 15) & ~15;
-    int acc_bytes = (bp.rho_cnt * kNumAngle * 2 + 15) & ~15;  // u16 vote counters
+    bp.acc_copy_bytes = (bp.rho_cnt * kNumAngle * 2 + 15) & ~15;  // u16 vote counters, one copy
+    int acc_bytes = kDetectVoteCopies * bp.acc_copy_bytes;
     if (acc_bytes < 2048) acc_bytes = 2048;  // (the two-walk kernels keep their candidate lists there: >= 1024 entries)
     bp.lds_map = tile_bytes;
     bp.lds_acc = tile_bytes + map_bytes;

@@ -737,11 +737,20 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
 
   // ---- E. Hough accumulator (hough.cpp:127-161), u16 counters packed in 32-bit words ----
   // Counters exist for the rho bins a pixel of this box can reach only (bp.rho_lo, bp.rho_cnt: fill_box_params).
+  // They are kept in kDetectVoteCopies copies, a lane voting into copy lane & (copies - 1): the voters of one instruction are
+  // neighbours on an edge, for the angles near the edge's own they name the same few counters, and equal addresses serialise an
+  // LDS atomic at 2 cycles per lane.  Measured on one box (profiles/r5_detect_vote_copies_ab.log): one copy 4.20 ms, two 4.12,
+  // four 4.14, eight 4.25 for the stage -- the conflicts are ~2 % of the kernel (the passes' 60 instructions are the rest).
+  // The arg-max adds the copies (packed halves: totals < 2^16).
   const int numrho = bp.rho_cnt;
-  const int ncell = kNumAngle * numrho;
-  for (int i = tid; i < (ncell + 1) / 2; i += NT) acc32[i] = 0;
+  const int copy_words = bp.acc_copy_bytes >> 2;
+  {
+    typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < kDetectVoteCopies * copy_words / 4; i += NT) ((u32x4a *)acc32)[i] = (u32x4a){0u, 0u, 0u, 0u};
+  }
   __syncthreads();
   {
+    unsigned int *const acc_mine = acc32 + (lane & (kDetectVoteCopies - 1)) * copy_words;
     const int half = (bp.numrho - 1) / 2 - bp.rho_lo;
     const uint32_t *map32 = (const uint32_t *)map;  // lds_map is 16-byte aligned
     for (int q4 = tid; q4 < (N + 3) >> 2; q4 += NT) {
@@ -774,17 +783,17 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
             const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
             if (__builtin_amdgcn_ballot_w64(cell != c0) == 0ull) {
               if ((int)(threadIdx.x & 63) == __builtin_ctzll(act))
-                atomicAdd(&acc32[c0], (unsigned)__popcll(act) << ((n & 1) * 16));
+                atomicAdd(&acc_mine[c0], (unsigned)__popcll(act) << ((n & 1) * 16));
               continue;
             }
           }
-          atomicAdd(&acc32[cell], (n & 1) ? 0x10000u : 1u);
+          atomicAdd(&acc_mine[cell], (n & 1) ? 0x10000u : 1u);
         }
       }
     }
   }
   __syncthreads();
-  DMZ_STOP_AFTER(5, acc32[0] + acc32[numrho])
+  DMZ_STOP_AFTER(5, acc32[0] + acc32[numrho] + acc32[copy_words])
   static_assert(kNumAngle % 2 == 0, "vote counters are packed in angle pairs");
 
   // ---- F. arg-max with the reference's scan order (hough.cpp:163-176) ----
@@ -795,7 +804,9 @@ __device__ void detect_body(const uint8_t *__restrict__ planes, size_t frame_str
     for (int p = 0; p < kNumAngle / 2; p++) {
       const unsigned int obase = 0xffffu - (unsigned int)(2 * p + bp.rho_lo * kNumAngle);
       for (int rr = tid; rr < numrho; rr += NT) {
-        const unsigned int w2 = acc32[p * numrho + rr];
+        unsigned int w2 = acc32[p * numrho + rr];
+#pragma unroll
+        for (int cp = 1; cp < kDetectVoteCopies; cp++) w2 += acc32[cp * copy_words + p * numrho + rr];
         const unsigned int o0 = obase - (unsigned int)__mul24(rr, kNumAngle);  // 0xffff - scan position of the low half
         const unsigned int k0 = (w2 << 16) | o0, k1 = (w2 & 0xffff0000u) | (o0 - 1u);
         best = k0 > best ? k0 : best;

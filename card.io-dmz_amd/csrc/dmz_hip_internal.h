@@ -38,11 +38,15 @@ constexpr int TOTAL = EXPIRY + 1250 + 50 + 50000 + 40 + 21120 + 176 + 1760 + 10;
 // ---------------------------------------------------------------------------
 constexpr int kNumAngle = 10;  // cvRound(2 * 5deg / 1deg), hough.cpp:98
 
+// Vote counters are kept in this many copies, a lane voting into copy (lane & (copies - 1)): the voters of one instruction are
+// neighbours on an edge and name the same few counters, and equal addresses serialise an LDS atomic (detect.hip, phase E).
+constexpr int kDetectVoteCopies = 2;
 struct DmzBoxParams {
   int x, y, w, h;        // ROI in the plane (dmz.cpp:279-341)
   int vertical;          // LineOrientationVertical (left/right boxes)
   int numrho;            // hough.cpp:99
   int rho_lo, rho_cnt;   // the rho bins a pixel of this box can vote for: [rho_lo, rho_lo + rho_cnt) (fill_box_params)
+  int acc_copy_bytes;    // one copy of the vote counters (16-byte multiple); the kernel keeps kDetectVoteCopies of them
   int threshold;         // max(w,h)/6, dmz.cpp:246
   int tab_sin[kNumAngle];
   int tab_cos[kNumAngle];
