@@ -216,10 +216,40 @@ __device__ __forceinline__ void vseg_prepare_rows(const uint8_t *__restrict__ ca
 // 1-KB coalesced loads, prefetched one k-step ahead) once per pass.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vs_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vs_h2 __attribute__((ext_vector_type(2)));
+
+// What a lane needs of the layers behind the hidden product.  The hidden product is evaluated TRANSPOSED (weights as the A
+// operand, gradient rows as B: the same register contents, the operands swapped), so a lane's four accumulators are four
+// hidden units u = 16 wave + 4 (lane >> 4) + v of ONE card row (lane & 15) -- which is exactly the B operand of a
+// v_mfma_f32_16x16x16_f16 whose contraction runs over the hidden units.  The logistic layer 50 -> 3 is then a matrix product
+// too (round 5): out^T[c][row] = sum_u w2[c][u] h[u][row], with both operands split into an f16 rounding and the f16
+// rounding of the remainder and the three products that carry 2^-22 (as the expiry CNN's convolutions).  Rounds 2 - 4 summed
+// w2[c][u] h over the sixteen lanes of a DPP row: twelve v_add_f32_dpp and three multiplies per accumulator.
+struct VsegTail {
+  float rowsum[4], b1[4];  // of the lane's four hidden units (zero beyond unit 49)
+  vs_h4 w2hi, w2lo;        // A operand of the logistic layer: row lane & 15 = class (three used), k = the lane's four units
+};
+__device__ __forceinline__ VsegTail vseg_tail_load(const float *__restrict__ wts, const float *__restrict__ wfrag, int wave, int lane) {
+  VsegTail q;
+  const int c = lane & 15, u0 = 16 * wave + 4 * (lane >> 4);
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const int u = u0 + v;
+    const bool unit = u < 50;
+    q.rowsum[v] = wfrag[dmzv::ROWSUM + u];
+    q.b1[v] = unit ? wts[dmzw::VSEG_B1 + u] : 0.0f;
+    const float w = (unit && c < 3) ? wts[dmzw::VSEG_W2 + c * 50 + u] : 0.0f;
+    const _Float16 hi = (_Float16)w;
+    q.w2hi[v] = hi;
+    q.w2lo[v] = (_Float16)(w - (float)hi);
+  }
+  return q;
+}
+
 template <int NT>
 __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb /* this wave + lane: [ks 7][part 3] x 64 */,
-                                                  float rowsum, float b1, float w20, float w21, float w22,
-                                                  const unsigned char *__restrict__ grad,
+                                                  const VsegTail &tl, const unsigned char *__restrict__ grad,
                                                   const float *__restrict__ norm, int nrows,
                                                   float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
                                                   int lane) {
@@ -253,26 +283,38 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
       a.z = __builtin_amdgcn_perm(0u, by.y, 0x0c010c00u);
       a.w = __builtin_amdgcn_perm(0u, by.y, 0x0c030c02u);
       const bf16x8 av = __builtin_bit_cast(bf16x8, a);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[2], acc[t], 0, 0, 0);  // small terms first
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[1], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[0], acc[t], 0, 0, 0);
+      // (weights as A, rows as B: the transposed product)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], av, acc[t], 0, 0, 0);  // small terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], av, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], av, acc[t], 0, 0, 0);
     }
   }
-  // D layout: column (hidden unit) = lane & 15, row = 4 * (lane >> 4) + v
+  // D layout: row (hidden unit of this wave) = 4 * (lane >> 4) + v, column (card row of the tile) = lane & 15
 #pragma unroll
-  for (int t = 0; t < NT; t++)
+  for (int t = 0; t < NT; t++) {
+    const int row = t * 16 + ii, rc = imin(row, nrows - 1);
+    const float sc = norm[2 * rc] * 0x1p33f, sh = norm[2 * rc + 1];  // (A carries 2^100, B 2^-133)
+    float hv[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) hv[v] = fast_tanh(fmaf(sc, acc[t][v], fmaf(sh, tl.rowsum[v], tl.b1[v])));  // units >= 50: tanh(0) = 0
+    // h = hi + lo to 2^-22, both rounded to nearest (the packed conversion truncates: its errors all have one sign and add
+    // up over the fifty units -- measured: 1.5 x the score error and a few more flipped near-ties on the fuzz frames)
+    vs_h4 bhi, blo;
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-      const int row = t * 16 + 4 * kk + v, rc = imin(row, nrows - 1);
-      const float pre = fmaf(norm[2 * rc] * 0x1p33f, acc[t][v], fmaf(norm[2 * rc + 1], rowsum, b1));  // (A carries 2^-133, B 2^100)
-      const float hv = fast_tanh(pre);  // units >= 50 have zero logistic weights
-      // sum over the 16 hidden units of this wave (one DPP row)
-      const float o0 = row16_sum(w20 * hv), o1 = row16_sum(w21 * hv), o2 = row16_sum(w22 * hv);
-      if (ii == 15 && row < nrows) {
-        float *p = part + (wave * VS_PROWS + row) * 3;
-        p[0] = o0; p[1] = o1; p[2] = o2;
-      }
+      bhi[v] = (_Float16)hv[v];
+      blo[v] = (_Float16)(hv[v] - (float)bhi[v]);
     }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    o = __builtin_amdgcn_mfma_f32_16x16x16f16(tl.w2lo, bhi, o, 0, 0, 0);  // small terms first
+    o = __builtin_amdgcn_mfma_f32_16x16x16f16(tl.w2hi, blo, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_16x16x16f16(tl.w2hi, bhi, o, 0, 0, 0);
+    // D layout again: row (class) = 4 * (lane >> 4) + v, column = card row: lanes 0..15 hold the three sums of their row
+    if (kk == 0 && row < nrows) {
+      float *p = part + (wave * VS_PROWS + row) * 3;
+      p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+    }
+  }
 }
 
 // n_vseg.cpp:49-92, called by one wave.  The reference's ring buffer entry read at step y is the
@@ -421,19 +463,10 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   vseg_prepare_rows(card, row_y, VS_MAXROWS, grad, norm, wave, lane);
   // this wave's hidden units 16 wave .. + 15: weight fragments, row sum, bias and the logistic weights
   const bf16x8 *wb = (const bf16x8 *)(wfrag + dmzv::WB3) + wave * VS_KS32 * 3 * 64 + lane;
-  struct { float b1, w20, w21, w22, rowsum; } w;
-  {
-    const int j = 16 * wave + (lane & 15);
-    const bool unit = j < 50;
-    w.rowsum = wfrag[dmzv::ROWSUM + j];
-    w.b1 = unit ? wts[dmzw::VSEG_B1 + j] : 0.0f;
-    w.w20 = unit ? wts[dmzw::VSEG_W2 + 0 * 50 + j] : 0.0f;
-    w.w21 = unit ? wts[dmzw::VSEG_W2 + 1 * 50 + j] : 0.0f;
-    w.w22 = unit ? wts[dmzw::VSEG_W2 + 2 * 50 + j] : 0.0f;
-  }
+  const VsegTail tl = vseg_tail_load(wts, wfrag, wave, lane);
   __syncthreads();
   VS_STOP(1, grad[0] + norm[5])
-  vseg_mlp_rows_bf16<5>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, VS_MAXROWS, part, wave, lane);
+  vseg_mlp_rows_bf16<5>(wb, tl, grad, norm, VS_MAXROWS, part, wave, lane);
   __syncthreads();
   VS_STOP(2, part[0] + part[100])
   vseg_finish_rows(wts, part, row_y, VS_MAXROWS, vis, amx, tid);
@@ -459,8 +492,8 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
     vseg_prepare_rows(card, row_y, nfine, grad, norm, wave, lane);
     __syncthreads();
     // (43 rows around the coarse winner minus the 10 or 11 the coarse pass scored: 32 fresh rows in three cards of four -- two tiles)
-    if (nfine <= 32) vseg_mlp_rows_bf16<2>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
-    else vseg_mlp_rows_bf16<3>(wb, w.rowsum, w.b1, w.w20, w.w21, w.w22, grad, norm, nfine, part, wave, lane);
+    if (nfine <= 32) vseg_mlp_rows_bf16<2>(wb, tl, grad, norm, nfine, part, wave, lane);
+    else vseg_mlp_rows_bf16<3>(wb, tl, grad, norm, nfine, part, wave, lane);
     __syncthreads();
     vseg_finish_rows(wts, part, row_y, nfine, vis, amx, tid);
     __syncthreads();
