@@ -227,18 +227,18 @@ typedef _Float16 vs_h2 __attribute__((ext_vector_type(2)));
 // rounding of the remainder and the three products that carry 2^-22 (as the expiry CNN's convolutions).  Rounds 2 - 4 summed
 // w2[c][u] h over the sixteen lanes of a DPP row: twelve v_add_f32_dpp and three multiplies per accumulator.
 struct VsegTail {
-  float rowsum[4], b1[4];  // of the lane's four hidden units (zero beyond unit 49)
-  vs_h4 w2hi, w2lo;        // A operand of the logistic layer: row lane & 15 = class (three used), k = the lane's four units
+  const float *unit_tab;  // LDS: rowsum[64] then b1[64] of the hidden units (zero beyond unit 49); the lane reads its four per tile
+                          // (eight more resident registers spilled seven dwords at the kernel's 72)
+  vs_h4 w2hi, w2lo;       // A operand of the logistic layer: row lane & 15 = class (three used), k = the lane's four units
 };
-__device__ __forceinline__ VsegTail vseg_tail_load(const float *__restrict__ wts, const float *__restrict__ wfrag, int wave, int lane) {
+__device__ __forceinline__ VsegTail vseg_tail_load(const float *__restrict__ wts, const float *unit_tab, int wave, int lane) {
   VsegTail q;
+  q.unit_tab = unit_tab + 16 * wave + 4 * (lane >> 4);
   const int c = lane & 15, u0 = 16 * wave + 4 * (lane >> 4);
 #pragma unroll
   for (int v = 0; v < 4; v++) {
     const int u = u0 + v;
     const bool unit = u < 50;
-    q.rowsum[v] = wfrag[dmzv::ROWSUM + u];
-    q.b1[v] = unit ? wts[dmzw::VSEG_B1 + u] : 0.0f;
     const float w = (unit && c < 3) ? wts[dmzw::VSEG_W2 + c * 50 + u] : 0.0f;
     const _Float16 hi = (_Float16)w;
     q.w2hi[v] = hi;
@@ -294,9 +294,10 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
   for (int t = 0; t < NT; t++) {
     const int row = t * 16 + ii, rc = imin(row, nrows - 1);
     const float sc = norm[2 * rc] * 0x1p33f, sh = norm[2 * rc + 1];  // (A carries 2^100, B 2^-133)
+    const f32x4 rs4 = *(const f32x4 *)tl.unit_tab, b14 = *(const f32x4 *)(tl.unit_tab + 64);
     float hv[4];
 #pragma unroll
-    for (int v = 0; v < 4; v++) hv[v] = fast_tanh(fmaf(sc, acc[t][v], fmaf(sh, tl.rowsum[v], tl.b1[v])));  // units >= 50: tanh(0) = 0
+    for (int v = 0; v < 4; v++) hv[v] = fast_tanh(fmaf(sc, acc[t][v], fmaf(sh, rs4[v], b14[v])));  // units >= 50: tanh(0) = 0
     // h = hi + lo to 2^-22, both rounded to nearest (the packed conversion truncates: its errors all have one sign and add
     // up over the fifty units -- measured: 1.5 x the score error and a few more flipped near-ties on the fuzz frames)
     vs_h4 bhi, blo;
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   __shared__ float vis[288], amx[288];
   __shared__ unsigned short row_y[VS_MAXROWS];
   __shared__ int s_int[4];
+  __shared__ __attribute__((aligned(16))) float unit_tab[128];
 
   const int f = blockIdx.x;
   if (f >= n) return;
@@ -463,7 +465,11 @@ __global__ __launch_bounds__(VS_THREADS, DMZ_VSEG_BLOCKS) void k_vseg(const floa
   vseg_prepare_rows(card, row_y, VS_MAXROWS, grad, norm, wave, lane);
   // this wave's hidden units 16 wave .. + 15: weight fragments, row sum, bias and the logistic weights
   const bf16x8 *wb = (const bf16x8 *)(wfrag + dmzv::WB3) + wave * VS_KS32 * 3 * 64 + lane;
-  const VsegTail tl = vseg_tail_load(wts, wfrag, wave, lane);
+  if (tid < 128) {  // rowsum[64] | b1[64] of the hidden units
+    const int u = tid & 63;
+    unit_tab[tid] = tid < 64 ? wfrag[dmzv::ROWSUM + u] : (u < 50 ? wts[dmzw::VSEG_B1 + u] : 0.0f);
+  }
+  const VsegTail tl = vseg_tail_load(wts, unit_tab, wave, lane);
   __syncthreads();
   VS_STOP(1, grad[0] + norm[5])
   vseg_mlp_rows_bf16<5>(wb, tl, grad, norm, VS_MAXROWS, part, wave, lane);
