@@ -351,8 +351,8 @@ def make_mixed_corpus(torch, frames, first_index, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="units (frames / crops) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
