@@ -202,7 +202,8 @@ constexpr int kDenseList = 96;
 // (the boxes of a 640 x 480 frame: the map offset of a step is then an immediate of the LDS store), else 0.
 template <bool VERT, int LC>
 __device__ __forceinline__ void nms_pixel(const DmzBoxParams &bp, const WalkCtx &c, int s, bool owner, int low,
-                                          int high, int dxc, int dyc, int mp, int mc, int mn, unsigned char *map, unsigned short *seg, int seg_cap, int &ncand, int *s_int) {
+                                          int high, int dxc, int dyc, int mp, int mc, int mn, unsigned char *map,
+                                          unsigned short *seg, int seg_cap, int &ncand, int *s_int) {
   const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097*(1<<15) + 0.5)
   const int m = mc;
   const bool above = owner && m > low;

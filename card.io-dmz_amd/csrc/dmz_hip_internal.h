@@ -91,6 +91,8 @@ struct DmzBoxHit {
 struct DmzWarpWin {
   int wx0, wy0, wdw, wrows;
   double mx, my, kx, ky, aqx, aqy;
+  double rx0, ry0, rw0s;  // the row terms M0 x + M1 y + M2, M3 x + M4 y + M5, (M6 x + M7 y + M8) / 32 at the strip's first row
+                          // (the filtered path's chains start from them; the exact sequence evaluates its own)
 };
 constexpr int DMZ_WARP_STRIPS = 21;
 struct DmzWarpMat {

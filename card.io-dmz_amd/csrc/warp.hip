@@ -11,8 +11,9 @@
 // CDNA4 mapping: one workgroup per 64 x 90 destination strip (x origin = OpenCV's 64-px block
 // origin, the only one that enters the fp64 association; 428 x 270 = 7 x 3 strips).  A lane owns
 // one destination column and walks down the strip's rows, so everything that depends on the
-// column only (M0*x1, M3*x1, M6*x1) is computed once per lane, and everything that depends on
-// the row only (M0*x + M1*y + M2, ...) is computed once per workgroup and broadcast from LDS.
+// column only (M0*x1, M3*x1, M6*x1) is computed once per lane; what depends on the row only
+// (M0*x + M1*y + M2, ...) the filtered path advances from the strip's first row (k_warp_windows)
+// and the exact sequence evaluates where it runs.
 // What is left per pixel is what exactness needs -- the kernel is VALU-issue bound (fp64 and most
 // integer instructions issue at about the same rate on gfx950).  These are the EXACT sequences; since round 2 nearly every
 // pixel takes the filtered-exact coordinates further down (cheap coordinates wherever they provably round like the exact
@@ -41,7 +42,7 @@
 namespace {
 
 // developer ablation (tools/ablate.sh): 1 = cheap coordinates, 3 = no blend, 6 = no stores,
-// 8 = one row record, 9 = with an LDS address clamp, 10 = one row pair per wave (block overhead)
+// 9 = with an LDS address clamp, 10 = one row pair per wave (block overhead)
 #ifndef DMZ_WARP_ABLATE
 #define DMZ_WARP_ABLATE 0
 #endif
@@ -55,8 +56,8 @@ constexpr int LWMAX = 120;  // widest staged window (px): 30 dword columns
 #ifndef DMZ_WARP_LH
 #define DMZ_WARP_LH 136
 #endif
-constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at up to 1.47 source px per card px; with the row
-                                 // records the workgroup uses 20,288 B of LDS: eight per CU
+constexpr int LH = DMZ_WARP_LH;  // rows: a 90-row strip at up to 1.47 source px per card px: 17,408 B of LDS, nine
+                                 // workgroups per CU (round 5: no table of row terms beside the window)
 // waves per strip: each walks TH / kWaves rows of the strip's 64 columns.  Per-wave set-up (column terms, the start
 // of the reciprocal chains) is ~13 % of a 23-row walk.  Three waves of 30 rows cover the 90 rows exactly (no row twice,
 // no odd-row tail): 7 % fewer instructions at 24 instead of 32 waves per CU, measured 1 - 5 % faster than four waves
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
   if (i >= n * kTiles) return;
   const int frame = i / kTiles, tile = i - frame * kTiles;
   const DmzWarpMat &wm = mats[frame];
-  DmzWarpWin w = {0, 0, 0, 0, 0., 0., 0., 0., 0., 0.};
+  DmzWarpWin w = {0, 0, 0, 0, 0., 0., 0., 0., 0., 0., 0., 0., 0.};
   if (wm.valid) {
     const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
     const int x = tx * TW, y0 = ty * TH;
@@ -213,6 +214,9 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
     w.ky = affine ? myf + ay : myf;
     w.aqx = w.kx - mxf;
     w.aqy = w.ky - myf;
+    w.rx0 = M0 * x + M1 * y0 + M2;
+    w.ry0 = M3 * x + M4 * y0 + M5;
+    w.rw0s = (M6 * x + M7 * y0 + M8) * 0.03125;
   }
   mats[frame].win[tile] = w;
 }
@@ -222,7 +226,6 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
                                                const DmzWarpMat *__restrict__ mats,
                                                uint8_t *__restrict__ cards, size_t card_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char win[LW * LH];
-  __shared__ __attribute__((aligned(16))) RowXYW s_row[TH];
 
   // XCD-aware renumbering: logical id = xcd * (blocks/8) + k
   const unsigned int nblk = (unsigned int)n_pad * kTiles;
@@ -250,16 +253,18 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   const int wx0 = ww.wx0, wy0 = ww.wy0, wrows = ww.wrows & (kFastFlag - 1);
   const uint8_t *src = planes + (size_t)frame * frame_stride;
 
-  // ---- per-row terms, one thread per row ----
-  if (tid < TH) {
-    const int y = y0 + tid;
+  // The row terms M0 x + M1 y + M2 (...) of strip row j, in the reference's association: the exact sequence evaluates them
+  // where it runs (the generic path, the strips without the fast flag, the filter's rare fallback).  Rounds 1 - 4 kept a
+  // table of them in LDS (2 880 B of the workgroup's 20 288: eight workgroups per CU; round 5: 17 408, nine).
+  auto row_terms = [&](int j) {
+    const int y = y0 + j;
     RowXYW r;
     r.X0 = M0 * x + M1 * y + M2;
     r.Y0 = M3 * x + M4 * y + M5;
     r.W0 = M6 * x + M7 * y + M8;
     r.W0s = r.W0 * 0.03125;  // exact: the fast path divides by W / 32
-    s_row[tid] = r;
-  }
+    return r;
+  };
 
   if (ww.wdw == 0) {
     // ---- generic path: range-checked coordinates, taps straight from global memory ----
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     for (int i = tid; i < TW * TH; i += kThreads) {
       const int x1 = i & (TW - 1), j = i >> 6;
       if (x + x1 >= DMZ_CARD_WIDTH) continue;
-      const RowXYW r = s_row[j];
+      const RowXYW r = row_terms(j);
       const SrcXY p = map_pixel(r.X0, r.Y0, r.W0, M0, M3, M6, x1);
       const int sx = sat16(p.X >> 5), sy = sat16(p.Y >> 5);
       const int ax = p.X & 31, ay = p.Y & 31;
@@ -436,8 +441,8 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     for (int m = 0; m < kRows / 2; m++) {
       const int j0 = a + 2 * m, j1 = j0 + 1;
       uint32_t Xa, Ya, Xb, Yb, va, vb;
-      exact_xy(s_row[j0], Xa, Ya);
-      exact_xy(s_row[j1], Xb, Yb);
+      exact_xy(row_terms(j0), Xa, Ya);
+      exact_xy(row_terms(j1), Xb, Yb);
       blend2(Xa, Ya, Xb, Yb, va, vb);
       store_row(j0, va);
       store_row(j1, vb);
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     if constexpr (kRows & 1) {
       const int j = a + kRows - 1;
       uint32_t Xa, Ya, va, vb;
-      exact_xy(s_row[j], Xa, Ya);
+      exact_xy(row_terms(j), Xa, Ya);
       blend2(Xa, Ya, Xa, Ya, va, vb);
       store_row(j, va);
     }
@@ -479,7 +484,9 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   // (k rho)^2); the first extrapolations then start with <= 15 rho^2 and the Newton step leaves <= 225 rho^4 <= 2^-36.
   // The one step from y1 against Wd(a-1) - k sW is y1 (2 - (Wd(a-1) - k sW) y1) = y1 + k (sW y1) y1 wherever y1 Wd(a-1) = 1
   // (it is, to 2^-52): ONE fma per row on q = (sW y1) y1 instead of the row's Wd and two (round 5; same (k rho)^2).
-  const double Wa = s_row[a].W0s + C;
+  // (the filtered path needs its operands to ~2^-40 only: the chains start from the strip's row terms of k_warp_windows)
+  const double aD = (double)a;
+  const double Wa = __builtin_fma(sW, aD, ww.rw0s) + C;
   auto start_chains = [&](double &yA1, double &yA2, double &yB1, double &yB2) {
     const double Wd = Wa - sW;
     double y1 = __builtin_amdgcn_rcp(Wd);
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     yB1 = y1, yB2 = __builtin_fma(2.0, q, y1);       // chain B: rows a+1, a+3, ... (previous: a-1, a-3)
   };
   // Wd of a chain advances by recurrence (two rows per step; in the round 2 - 4 form the numerators too): the cheap path needs
-  // its operands to ~2^-40 only, so the rounding of a dozen additions is irrelevant, and the per-row LDS records (three
-  // broadcast reads per pixel pair: the LDS pipe was the next limit) are left to the exact path
+  // its operands to ~2^-40 only, so the rounding of a dozen additions is irrelevant; the exact row terms are the exact
+  // path's business (row_terms)
   struct Chain {
     double Xn, Yn, Wd, y1, y2;
   };
@@ -520,9 +527,8 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
     double bx = 0., by = 0.;
     Chain cA, cB;
     {
-      const RowXYW ra = s_row[a], rb = s_row[a + 1];
-      cA.Xn = ra.X0 + A, cA.Yn = ra.Y0 + B, cA.Wd = Wa;
-      cB.Xn = rb.X0 + A, cB.Yn = rb.Y0 + B, cB.Wd = rb.W0s + C;
+      cA.Xn = __builtin_fma(M1, aD, ww.rx0) + A, cA.Yn = __builtin_fma(M4, aD, ww.ry0) + B, cA.Wd = Wa;
+      cB.Xn = cA.Xn + M1, cB.Yn = cA.Yn + M4, cB.Wd = Wa + sW;
     }
     if constexpr (!LIN) start_chains(cA.y1, cA.y2, cB.y1, cB.y2);
     if constexpr (AFF) {
@@ -582,14 +588,14 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
           : "=&v"(lo16), "=s"(amb)
           : "v"(Xa), "v"(Ya), "v"(Xb), "v"(Yb));
       if (__builtin_expect(amb != 0, 0)) {
-        exact_xy(s_row[j0], Xa, Ya);
-        exact_xy(s_row[j1], Xb, Yb);
+        exact_xy(row_terms(j0), Xa, Ya);
+        exact_xy(row_terms(j1), Xb, Yb);
       }
 #ifdef DMZ_WARP_VERIFY  // developer check (tools/dev/warp_verify.sh): every cheap coordinate against the exact sequence
       {
         uint32_t Xe, Ye, Xf, Yf;
-        exact_xy(s_row[j0], Xe, Ye);
-        exact_xy(s_row[j1], Xf, Yf);
+        exact_xy(row_terms(j0), Xe, Ye);
+        exact_xy(row_terms(j1), Xf, Yf);
         if ((Xe ^ Xa) >> 16 || (Ye ^ Ya) >> 16 || (Xf ^ Xb) >> 16 || (Yf ^ Yb) >> 16)
           printf("WARP MISMATCH frame %d tile %d lane %d rows %d: %08x %08x %08x %08x exact %08x %08x %08x %08x mode %d\n", frame,
                  tile, lane, j0, Xa, Ya, Xb, Yb, Xe, Ye, Xf, Yf, MODE);
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
       const int j = a + kRows - 1;
       uint32_t Xa, Ya, va, vb;
       fast_xy(cA, Xa, Ya);
-      if (__builtin_amdgcn_ballot_w64((Xa & 0xffffu) == 0u || (Ya & 0xffffu) == 0u)) exact_xy(s_row[j], Xa, Ya);
+      if (__builtin_amdgcn_ballot_w64((Xa & 0xffffu) == 0u || (Ya & 0xffffu) == 0u)) exact_xy(row_terms(j), Xa, Ya);
       blend2(Xa, Ya, Xa, Ya, va, vb);
       store_row(j, va);
     }
