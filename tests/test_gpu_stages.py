@@ -309,6 +309,48 @@ def test_detect_other_frame_geometries(ctx, pkg, oracle):
         assert res[0]["found_all"] == want["found_all"]
 
 
+def test_hough_lines_at_the_limits_of_every_box(ctx, pkg, oracle):
+    """detect.hip keeps vote counters only for the rho bins a pixel of the box can reach (its corners bound them) and adds two
+    copies of them in the arg-max.  Straight edges along the rims and through the middle of each detection box, tilted to both
+    ends of the +-5 degree fan and beyond it, at the standard geometry and at 1280x720 / 320x240: found flags, the winning
+    (rho, theta) and the corners equal the oracle's."""
+    rng = np.random.default_rng(2024)
+    for (h, w, orientation) in ((480, 640, 3), (720, 1280, 3), (240, 320, 3)):
+        boxes = oracle.detection_boxes(w, h, orientation)  # four (x, y, w, h): the wide ones look for horizontal lines
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        frames = []
+        for tilt in (-6.0, -5.0, -4.5, 0.0, 4.5, 5.0, 6.0):
+            t = np.tan(np.radians(tilt))
+            for frac in (0.0, 0.1, 0.5, 0.9, 1.0):
+                # one nearly horizontal edge through the top and the bottom box, one nearly vertical through the left and the right
+                # one: at the box's first / last rows (columns) and in between, pivoting on the box's centre
+                f = np.full((h, w), 40.0)
+                for (bx, by, bw, bh) in boxes:
+                    cx, cy = bx + bw / 2.0, by + bh / 2.0
+                    if bw > bh:
+                        side = (yy - (by + frac * (bh - 1)) - t * (xx - cx)) > 0
+                        band = np.abs(yy - cy) < 3 * bh
+                    else:
+                        side = (xx - (bx + frac * (bw - 1)) - t * (yy - cy)) > 0
+                        band = np.abs(xx - cx) < 3 * bw
+                    f = np.where(band & side, f + 60.0, f)
+                frames.append((f + rng.integers(0, 6, (h, w))).clip(0, 255).astype(np.uint8))
+        frames = np.stack(frames)
+        n = len(frames)
+        res = np.zeros(n, pkg.RESULT_DTYPE)
+        ctx.detect(frames, n, res, width=w, height=h, orientation=orientation)
+        nfound = 0
+        for i in range(n):
+            want = oracle.detect_edges(frames[i], orientation=orientation)
+            assert np.array_equal(res[i]["found"], want["found"]), (w, h, i)
+            m = want["found"] != 0
+            nfound += int(m.sum())
+            assert np.array_equal(res[i]["rho"][m].view(np.uint32), want["rho"][m].view(np.uint32)), (w, h, i)
+            assert np.array_equal(res[i]["theta"][m].view(np.uint32), want["theta"][m].view(np.uint32)), (w, h, i)
+            assert np.array_equal(res[i]["corners"].view(np.uint32), want["corners"].view(np.uint32)), (w, h, i)
+        assert nfound >= n, (w, h, nfound)  # (the frames do put lines into the boxes)
+
+
 def test_dense_candidate_boxes_in_every_kernel_form(ctx, pkg, oracle):
     """Card-less texture leaves hundreds of weak Canny candidates per wave: the hysteresis then floods on bitmaps instead of
     walking candidate lists (detect.hip).  Noise, a noisy ramp and a fine checker at the standard geometry (single-walk
