@@ -260,6 +260,7 @@ def _cpu_worker(job):
         items = [o.synth_frame(SEED, first + i)[0] for i in range(nframes)]
     _cpu_barrier.wait()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     done = 0
     while True:
         it = items[done % nframes]
@@ -273,21 +274,59 @@ def _cpu_worker(job):
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    return done, time.perf_counter() - t0
+    return done, time.perf_counter() - t0, time.process_time() - c0
+
+
+def cpu_quota():
+    """(cores the cgroup lets this process use at once or None, where that was read): cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`.  A container with 256 visible cores and a 32-core quota runs 256 busy workers at an
+    eighth of a core each -- the per-core figure of such a run says nothing about the CPU."""
+    try:
+        rel = "/"
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[1] in ("", "cpu,cpuacct", "cpu"):
+                rel = parts[2]
+        cands = []
+        for base in ("/sys/fs/cgroup" + rel, "/sys/fs/cgroup"):
+            cands.append((os.path.join(base, "cpu.max"), None))
+        for base in ("/sys/fs/cgroup/cpu,cpuacct" + rel, "/sys/fs/cgroup/cpu" + rel, "/sys/fs/cgroup/cpu,cpuacct", "/sys/fs/cgroup/cpu"):
+            cands.append((os.path.join(base, "cpu.cfs_quota_us"), os.path.join(base, "cpu.cfs_period_us")))
+        for q, per in cands:
+            if not os.path.exists(q):
+                continue
+            if per is None:
+                a, b = open(q).read().split()[:2]
+                if a == "max":
+                    continue  # (no limit at this level: look further up)
+                return float(a) / float(b), q
+            quota, period = int(open(q).read()), int(open(per).read())
+            if quota > 0 and period > 0:
+                return quota / period, q
+    except (OSError, ValueError):
+        pass
+    return None, None
 
 
 def cpu_baseline(config, budget_s=3.0, frames_per_worker=48):
-    """Runs BEFORE this process touches the GPU (the workers are forked)."""
+    """Runs BEFORE this process touches the GPU (the workers are forked).  One worker alone first (1 s: the unloaded
+    single-process figure), then min(affinity, cgroup quota) workers at once."""
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0))
+    affinity = len(os.sched_getaffinity(0))
+    quota, quota_src = cpu_quota()
+    cores = max(1, min(affinity, int(quota) if quota is not None and quota >= 1 else affinity))
     ctx = mp.get_context("fork")
+    with ctx.Pool(1, initializer=_cpu_init, initargs=(ctx.Barrier(1),)) as pool:
+        d1, t1, _ = pool.map(_cpu_worker, [(0, config, 0, min(16, frames_per_worker), 1.0)], chunksize=1)[0]
+    single = d1 / t1
     barrier = ctx.Barrier(cores)
     with ctx.Pool(cores, initializer=_cpu_init, initargs=(barrier,)) as pool:
         res = pool.map(_cpu_worker, [(w, config, w * frames_per_worker, frames_per_worker, budget_s)
                                      for w in range(cores)], chunksize=1)
-    total = sum(d for d, _ in res)
-    wall = max(t for _, t in res)
-    per_core = float(np.mean([d / t for d, t in res]))
+    total = sum(d for d, _, _ in res)
+    wall = max(t for _, t, _ in res)
+    per_core = float(np.mean([d / t for d, t, _ in res]))
+    cpu_s = sum(c for _, _, c in res)  # CPU time the workers were actually given (a throttled or shared host gives less than wall x cores)
     unit = CONFIGS[config]["unit"]
     model = ""
     try:
@@ -298,11 +337,17 @@ def cpu_baseline(config, budget_s=3.0, frames_per_worker=48):
     except OSError:
         pass
     return {"value": round(total / wall, 1), "unit": unit + "/s", "cores": cores, "kind": "port",
-            "per_core": round(per_core, 1), "cpu": model,
+            "per_core": round(per_core, 1), "single_process_%s_per_s" % unit: round(single, 1),
+            "cpu": model, "cpu_affinity": affinity,
+            "cpu_quota": ({"cores": round(quota, 2), "source": quota_src} if quota is not None else None),
+            "loaded_over_single": round(per_core / single, 3) if single > 0 else None,
+            "effective_cores": round(cpu_s / wall, 1), "per_effective_core": round(total / cpu_s, 1) if cpu_s > 0 else None,
             "sample": "%d %s of the benchmark corpus per process (indices [%d w, %d w + %d), cycled), "
-                      "%s, one process per host core (%d), %.1f s wall, %.0f s of CPU work"
+                      "%s, one process per usable host core (%d = min(affinity %d, cgroup quota %s)), %.1f s wall, %.0f s of CPU "
+                      "work; before it ONE process alone for 1 s (single_process_*: the unloaded per-core figure)"
                       % (frames_per_worker, unit, frames_per_worker, frames_per_worker, frames_per_worker,
-                         CONFIGS[config]["workload"], cores, wall, sum(t for _, t in res))}
+                         CONFIGS[config]["workload"], cores, affinity, "%.1f" % quota if quota is not None else "none",
+                         wall, cpu_s)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -361,11 +406,13 @@ def main():
     ap.add_argument("--corpus", choices=("cards", "mixed"), default="cards",
                     help="cards: every frame shows a card (the metric's corpus); mixed: 40 %% card-less, 10 %% upside-down, "
                          "50 %% cards (config 4 only; a second line for the gated throughput, not the headline metric)")
-    ap.add_argument("--gather", choices=("auto", "capi", "torch"), default="torch",
-                    help="N > 1: gather of the records on rank 0 through torch.distributed (default: the path that has run on "
-                         "hardware) or through the C-ABI (dmz_hip_gather_records over RCCL; auto = capi when librccl loads on "
-                         "every rank and the communicator comes up).  The C-ABI path is VERIFIED after the timed loop against a "
-                         "torch.distributed gather of the same records, and the run fails on a mismatch.")
+    ap.add_argument("--gather", choices=("auto", "capi", "torch"), default="auto",
+                    help="N > 1: gather of the records on rank 0.  auto (default): through the C-ABI (dmz_hip_gather_records: "
+                         "RCCL send / recv on the context's communication queue) when librccl loads on every rank and the "
+                         "communicator comes up, VERIFIED after the timed loop against a torch.distributed gather of the same "
+                         "records; if the communicator fails or a byte differs the timed loop is REPEATED over the "
+                         "torch.distributed gather and the JSON line says so (config.gather = \"torch (capi failed: ...)\").  "
+                         "capi: the same, but a failure ends the run.  torch: torch.distributed only.")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: the same per-GPU batch at every N (like-for-like curve); strong: the 1 048 576-frame corpus of "
                          "BASELINE configs[4] every step at every N (config 4 only)")
@@ -432,6 +479,7 @@ def main():
     # the context's communication queue) when librccl loads and the communicator comes up; the torch.distributed gather
     # (same ranges, same asynchrony) otherwise.  At N = 1 there is nothing to gather.
     use_capi = False
+    capi_failure = None  # why the C-ABI gather is not the one that was timed (auto mode), for the JSON line
     root_dst = None
     if world > 1 and ctx is not None and args.gather in ("auto", "capi"):
         # every rank first agrees that librccl loads everywhere: a rank that entered ncclCommInitRank alone would hang the others
@@ -452,10 +500,14 @@ def main():
             except pkg.DmzHipError as e:
                 print("bench.py: rank %d: C-ABI communicator failed (%s)" % (rank, e), file=sys.stderr)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not bool(ok.item()):
+                capi_failure = "ncclCommInitRank failed on a rank"
+        else:
+            capi_failure = "librccl did not load on every rank"
         use_capi = bool(ok.item())
         if not use_capi:
             if args.gather == "capi":
-                sys.exit("bench.py: --gather capi: no RCCL communicator")
+                sys.exit("bench.py: --gather capi: no RCCL communicator (%s)" % capi_failure)
             try:
                 ctx.comm_destroy()
             except pkg.DmzHipError:
@@ -502,7 +554,7 @@ def main():
     def step():
         k = step_no[0] % nbuf
         step_no[0] += 1
-        if world > 1 and use_capi:
+        if world > 1 and use_capi:  # (read at call time: the auto mode may turn it off after the verification)
             # only the gathers that still read this pair of buffers (slots 2k, 2k + 1): the other pair's stay in flight
             ctx.gather_wait(2 * k, host_sync=False)
             ctx.gather_wait(2 * k + 1, host_sync=False)
@@ -535,34 +587,39 @@ def main():
         for _ in range(passes):
             one_pass()
 
-    for _ in range(args.warmup):
-        step()
-    gather_drain()
-    sync()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    if ctx is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    gather_drain()  # the timed region includes the last exchange
-    if ctx is not None:
-        ev1.record(stream)
-    sync()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    dev_ms = ev0.elapsed_time(ev1) if ctx is not None else elapsed * 1e3
+    def timed_run():
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(args.warmup):
+            step()
+        gather_drain()
+        sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if ctx is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        gather_drain()  # the timed region includes the last exchange
+        if ctx is not None:
+            ev1.record(stream)
+        sync()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, (ev0.elapsed_time(ev1) if ctx is not None else el * 1e3)
+
+    elapsed, dev_ms = timed_run()
 
     # The C-ABI gather has no second implementation inside the timed loop to compare with: afterwards the LAST step's records
     # travel once more through torch.distributed and rank 0 compares the two destinations byte for byte.  A wrong offset or
-    # count, or a second RCCL beside torch's, fails the run instead of producing a plausible frames/s figure.
+    # count, or a second RCCL beside torch's, must not produce a plausible frames/s figure: with --gather capi the run fails;
+    # with auto the timed loop is repeated over the torch.distributed gather and the JSON line names the reason.
     if world > 1 and use_capi:
         last = (step_no[0] - 1) % nbuf
         ref = sharding.RootGatherer(world)
@@ -578,7 +635,15 @@ def main():
                 same.zero_()
         dist.broadcast(same, src=0)
         if not bool(same.item()):
-            sys.exit("bench.py: the C-ABI gather's records differ from the torch.distributed gather of the same step")
+            if args.gather == "capi":
+                sys.exit("bench.py: the C-ABI gather's records differ from the torch.distributed gather of the same step")
+            capi_failure = "its records differed from the torch.distributed gather of the same step"
+            use_capi = False
+            try:
+                ctx.comm_destroy()
+            except pkg.DmzHipError:
+                pass
+            elapsed, dev_ms = timed_run()
 
     if args.dry_run:
         ok = True
@@ -776,7 +841,8 @@ def main():
                 "baseline_config": cfg["name"],
                 **({"corpus": "mixed: 40 % card-less frames, 10 % upside-down cards, 50 % cards (not the metric's corpus: the gated "
                               "throughput line of SURVEY section 7)"} if args.corpus == "mixed" else {}),
-                **({"gather": "C-ABI dmz_hip_gather_records (RCCL send/recv)" if use_capi else "torch.distributed gather"} if world > 1 else {}),
+                **({"gather": "capi (dmz_hip_gather_records: RCCL send / recv; verified against torch.distributed after the timed loop)"
+                              if use_capi else ("torch (capi failed: %s)" % capi_failure if capi_failure else "torch")} if world > 1 else {}),
                 "units_per_gpu": B * passes,
                 "corpus_frames": world * B * passes,
                 **({"resident_batch": B, "passes_per_step": passes} if passes > 1 else {}),
