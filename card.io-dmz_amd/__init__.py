@@ -34,6 +34,8 @@ EXPIRY_CONV_F32, EXPIRY_CONV_BF16X3, EXPIRY_CONV_BF16, EXPIRY_CONV_F16X3 = 0, 1,
 OPT_TRUNCATE_CORNERS = 1
 OPT_UPSAMPLE = 2
 OPT_EIGEN_SSE2 = 4
+OPT_EIGEN_SCALAR = 8  # per-call override of set_reference_flavour(1)
+FLAG_FAULT = 16       # a device self-check did not settle (include/dmz_hip.h)
 STAGES = ("detect", "geometry", "warp", "vseg", "hseg", "digits", "expiry_seg", "expiry_cat")
 
 # mirror of struct dmz_hip_frame_result (include/dmz_hip.h), 1024 bytes
@@ -89,8 +91,10 @@ EXPORTS = (
     "dmz_hip_shard_range", "dmz_hip_comm_unique_id", "dmz_hip_comm_init", "dmz_hip_comm_destroy",
     "dmz_hip_gather_records", "dmz_hip_gather_wait", "dmz_hip_expiry_sort_positions",
     "dmz_hip_categorize_expiry_groups_batch", "dmz_hip_scharr3_dx_abs", "dmz_hip_best_n_hseg_batch",
-    "dmz_hip_debug_fill_lds", "dmz_hip_set_reference_flavour",
+    "dmz_hip_set_reference_flavour",
 )
+# test / developer entry points (include/dmz_hip_test.h): not part of the drop-in boundary
+TEST_EXPORTS = ("dmz_hip_debug_fill_lds",)
 
 
 class DmzHipError(RuntimeError):

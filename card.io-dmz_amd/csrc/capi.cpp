@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "dmz_hip_internal.h"
+#include "../../include/dmz_hip_test.h"
 
 extern "C" const unsigned char dmz_weights_blob[];
 extern "C" const unsigned char dmz_weights_blob_end[];
@@ -88,6 +89,12 @@ int fail(dmz_hip_context *ctx, int code, const char *what, hipError_t e = hipSuc
     }
   }
   return code;
+}
+
+// the homography's summation order of a call: its own option bit if it carries one (SCALAR wins), else the context default
+int effective_options(const dmz_hip_context *ctx, int options) {
+  if (options & DMZ_HIP_OPT_EIGEN_SCALAR) return options & ~(DMZ_HIP_OPT_EIGEN_SSE2 | DMZ_HIP_OPT_EIGEN_SCALAR);
+  return (options & DMZ_HIP_OPT_EIGEN_SSE2) ? options : options | ctx->default_options;
 }
 
 #define HIP_TRY(ctx, call)                                                 \
@@ -438,7 +445,7 @@ int run_transform(dmz_hip_context *ctx, const uint8_t *plane, size_t frame_strid
   if (rc) return rc;
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_GEOMETRY);
-    dmz_launch_homography(ctx->stream, n, orientation, options | ctx->default_options, results, (DmzWarpMat *)ctx->mats.p);
+    dmz_launch_homography(ctx->stream, n, orientation, effective_options(ctx, options), results, (DmzWarpMat *)ctx->mats.p);
   }
   {
     StageTimer t(ctx, DMZ_HIP_STAGE_WARP);
@@ -1771,7 +1778,7 @@ int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_inde
 int dmz_hip_debug_fill_lds(dmz_hip_context *ctx, uint32_t word) {
   if (!ctx) return DMZ_HIP_EINVAL;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dmz_launch_fill_lds(ctx->stream, word);
+  if (dmz_launch_fill_lds(ctx->stream, ctx->device, word)) return fail(ctx, DMZ_HIP_ERUNTIME, "dmz_launch_fill_lds", hipGetLastError());
   HIP_TRY(ctx, hipGetLastError());
   return DMZ_HIP_OK;
 }

@@ -220,7 +220,7 @@ size_t dmz_synth_params_bytes(int n);
 int dmz_synth_upload_params(hipStream_t s, uint64_t seed, uint64_t first, int n, void *scratch);
 void dmz_launch_synth_frames(hipStream_t s, const void *params, int n, uint8_t *y);
 void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *cards);
-void dmz_launch_fill_lds(hipStream_t s, uint32_t word);
+int dmz_launch_fill_lds(hipStream_t s, int device, uint32_t word);  // include/dmz_hip_test.h; nonzero: device attributes unavailable
 // Developer probe (tools/dev/marginal_cost.sh): -DDMZ_DUP=<kernel tag> launches that kernel TWICE (every kernel of the pipeline
 // is idempotent: same inputs, same outputs): the difference in the step time is what the kernel costs INSIDE the pipeline,
 // beside whatever runs on the other queues -- as opposed to its run time alone.

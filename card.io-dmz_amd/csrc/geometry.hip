@@ -236,6 +236,35 @@ __global__ __launch_bounds__(64) void k_geometry(int n, const DmzDetectParams *_
   res->flags = 0;
 }
 
+// calc_persp_transform, evaluated again until two consecutive results agree bit for bit (at most six times); false = they
+// never did.  Round 5 measured why: with another queue's kernels (the expiry CNN of a previous frame chunk) in flight beside
+// k_homography, about once per 65 536 frames one quarter-wave (always lanes 48..63) came out of this register-to-register
+// computation with a wrong matrix from the right corners; a repeated evaluation in the same wave gave the right one
+// (DESIGN_LOG.md "transient fault in k_homography", profiles/r5_homography_quarter_wave.log; cause not established).  The
+// library's own pipeline never runs these kernels beside another one of the same context, a second context on the same GPU
+// may: 40 us per 65 536 frames buy the check.
+template <bool SSE>
+__device__ __forceinline__ bool persp_checked(const float *sp, const float *dp, float *m) {
+  calc_persp_transform<SSE>(sp, dp, m);
+#ifdef DMZ_HOMOGRAPHY_NOCHECK  /* developer switch (tools/dev/two_context_stress.py): the single evaluation of rounds 1 - 4 */
+  return true;
+#else
+  for (int tries = 0; tries < 6; tries++) {
+    float m2[9], sp2[8];
+    for (int i = 0; i < 8; i++) {
+      sp2[i] = sp[i];
+      asm volatile("" : "+v"(sp2[i]));  // (not the same value to the compiler: the second evaluation is not folded into the first)
+    }
+    calc_persp_transform<SSE>(sp2, dp, m2);
+    bool same = true;
+    for (int i = 0; i < 9; i++) same = same && (__float_as_uint(m2[i]) == __float_as_uint(m[i]));
+    for (int i = 0; i < 9; i++) m[i] = m2[i];
+    if (same) return true;
+  }
+  return false;
+#endif
+}
+
 // dmz_transform_card's part before the warp: corners -> source points -> float
 // homography -> inverse double matrix (dmz.cpp:446-471, warp.cpp:153-165).
 template <bool SSE>
@@ -276,29 +305,15 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
     const float rw = (float)(DMZ_CARD_WIDTH - 1), rh = (float)(DMZ_CARD_HEIGHT - 1);
     dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f + rw; dp[3] = 0.0f;
     dp[4] = 0.0f; dp[5] = 0.0f + rh; dp[6] = 0.0f + rw; dp[7] = 0.0f + rh;
-    calc_persp_transform<SSE>(sp, dp, m);
-    // Evaluated again until two consecutive results agree bit for bit.  Round 5 measured why: with another queue's kernels
-    // (the expiry CNN of a previous frame chunk) in flight beside this kernel, about once per 65 536 frames one quarter-wave
-    // (always lanes 48..63) came out of this register-to-register computation with a wrong matrix from the right corners; a
-    // repeated evaluation in the same wave gave the right one (tools/dev/rejected/pipe_chunks_r5.patch.txt,
-    // profiles/r5_homography_quarter_wave.log; cause not established).  The library's own pipeline never runs this kernel
-    // beside another one of the same context, a second context on the same GPU may: 40 us per 65 536 frames buy the check.
-#ifndef DMZ_HOMOGRAPHY_NOCHECK  /* developer switch (tools/dev/two_context_stress.py): the single evaluation of rounds 1 - 4 */
-    for (int tries = 0; tries < 6; tries++) {
-      float m2[9], sp2[8];
-      for (int i = 0; i < 8; i++) {
-        sp2[i] = sp[i];
-        asm volatile("" : "+v"(sp2[i]));  // (not the same value to the compiler: the second evaluation is not folded into the first)
-      }
-      calc_persp_transform<SSE>(sp2, dp, m2);
-      bool same = true;
-      for (int i = 0; i < 9; i++) same = same && (__float_as_uint(m2[i]) == __float_as_uint(m[i]));
-      for (int i = 0; i < 9; i++) m[i] = m2[i];
-      if (same) break;
+    if (persp_checked<SSE>(sp, dp, m)) {
+      invert3x3(m, &wm);
+      res->flags = (res->flags & ~(DMZ_HIP_FLAG_WARPED | DMZ_HIP_FLAG_FAULT)) | DMZ_HIP_FLAG_WARPED;
+    } else {
+      // six evaluations, no two consecutive ones alike: not a result.  The frame is not rectified (its card stays zero, the
+      // scan stages skip it) and the record says why.
+      wm.valid = 0;
+      res->flags = (res->flags & ~DMZ_HIP_FLAG_WARPED) | DMZ_HIP_FLAG_FAULT;
     }
-#endif
-    invert3x3(m, &wm);
-    res->flags = (res->flags & ~DMZ_HIP_FLAG_WARPED) | DMZ_HIP_FLAG_WARPED;
   } else {
     res->flags = res->flags & ~DMZ_HIP_FLAG_WARPED;
   }
@@ -315,8 +330,9 @@ __global__ __launch_bounds__(64) void k_persp(int n, const float *__restrict__ s
     sp[i] = src_pts[f * 8 + i];
     dp[i] = dst_pts[f * 8 + i];
   }
-  calc_persp_transform<SSE>(sp, dp, m);
-  for (int i = 0; i < 9; i++) m9[f * 9 + i] = m[i];
+  // (no flag travels with a bare matrix: a self-check that never settles returns NaNs, not a plausible wrong homography)
+  const bool ok = persp_checked<SSE>(sp, dp, m);
+  for (int i = 0; i < 9; i++) m9[f * 9 + i] = ok ? m[i] : __uint_as_float(0x7FC00000u);
 }
 
 __global__ __launch_bounds__(64) void k_mats_from_float(int n, const float *__restrict__ m9, DmzWarpMat *__restrict__ mats) {

@@ -265,14 +265,16 @@ __global__ __launch_bounds__(256) void k_synth_cards(const SynthParams *__restri
   *(uint32_t *)(cards + (size_t)f * (428 * 270) + (size_t)v * 428 + u0) = packed;
 }
 
-// test utility: every CU's LDS is overwritten with `word` (a kernel that reads LDS it did not write sees it afterwards)
-__global__ __launch_bounds__(1024) void k_fill_lds(uint32_t word, uint32_t *__restrict__ sink) {
-  __shared__ uint32_t lds[16384];  // 64 KiB, the largest static allocation: two to three workgroups cover a CU's 160 KiB
-  for (int i = threadIdx.x; i < 16384; i += 1024) lds[i] = word;
+// test utility (include/dmz_hip_test.h): every CU's LDS is overwritten with `word` (a kernel that reads LDS it did not write
+// sees it afterwards).  Dynamic LDS: the launcher sizes a workgroup's share from the device attributes so that the workgroups
+// resident on a CU together own ALL of its LDS (gfx950: one workgroup with the whole 160 KiB).
+__global__ void k_fill_lds(uint32_t word, int words, uint32_t *__restrict__ sink) {
+  extern __shared__ uint32_t fill_lds[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) fill_lds[i] = word;
   __syncthreads();
-  // (the stores must not be eliminated; the spin keeps workgroups resident together so that all of a CU's LDS is claimed)
+  // (the stores must not be eliminated; with more than one workgroup per CU the spin keeps them resident together)
   uint32_t acc = 0;
-  for (int r = 0; r < 64; r++) acc += lds[(threadIdx.x * 17 + r * 1031) & 16383];
+  for (int r = 0; r < 64; r++) acc += fill_lds[(threadIdx.x * 17u + r * 1031u) % (unsigned)words];
   if (acc == 0x12345u && sink) sink[0] = acc;
 }
 
@@ -301,6 +303,17 @@ void dmz_launch_synth_cards(hipStream_t s, const void *params, int n, uint8_t *c
                      (const SynthParams *)params, n, cards);
 }
 
-void dmz_launch_fill_lds(hipStream_t s, uint32_t word) {
-  hipLaunchKernelGGL(k_fill_lds, dim3(256u * 16u), dim3(1024), 0, s, word, (uint32_t *)nullptr);
+int dmz_launch_fill_lds(hipStream_t s, int device, uint32_t word) {
+  int per_cu = 0, per_wg = 0, cus = 0;
+  if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess ||
+      hipDeviceGetAttribute(&per_wg, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu <= 0 || per_wg <= 0)
+    return 1;
+  const int nper = (per_cu + per_wg - 1) / per_wg;        // workgroups that share a CU's LDS (1 on gfx950)
+  const int bytes = (per_cu / nper) & ~3;
+  // (1024 threads = 16 waves: two such workgroups could meet on a CU by wave slots, never by LDS when nper == 1)
+  const int threads = nper == 1 ? 1024 : 256;
+  if (hipFuncSetAttribute((const void *)k_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_fill_lds, dim3((unsigned)(cus * nper * 8)), dim3(threads), bytes, s, word, bytes / 4, (uint32_t *)nullptr);
+  return 0;
 }

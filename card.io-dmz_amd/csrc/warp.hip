@@ -195,9 +195,17 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
         // perspective down a column (rho <= 2^-24; M7 == 0 included) the reciprocal itself is linear in the row to
         // (29 rho)^2 <= 2^-38 instead.  The two cover every fast strip: |alpha| = 32 |M / W| / rho with 32 |M / W| <= 64
         // (the window bounds the slope) is <= 2^30 wherever rho > 2^-24; a strip that fails both takes the exact loop.
-        if (fabs(M7) * 16777216.0 <= wmin)
+        // The budget is checked here, per strip, not assumed: an error eps of the reciprocal enters the cheap
+        // coordinate as (|fX| + |alpha|) eps with |fX| the ABSOLUTE source coordinate in 1/32 px (the window origin is folded
+        // into the rounding constant, not into the product) -- the strip's corners bound it -- and the filter needs the sum
+        // below 2^-17: eps = 225 r^4 for the extrapolated reciprocal, (29 r)^2 for the linear one, r = |M7| / min |W| >= rho.
+        // A wide plane (source x of 8 000 px and more) near rho = 2^-11 fails the affine test and takes the exact loop.
+        const double r = fabs(M7) / wmin, r2 = r * r;
+        const double fmaxabs = 32.0 * (double)(imax(imax(-bx0, bx1), imax(-by0, by1)) + 2);
+        const double amax = fmax(fabs(ax), fabs(ay));
+        if (fabs(M7) * 16777216.0 <= wmin && fmaxabs * 841.0 * r2 <= 0x1p-19)
           w.wrows |= kFastFlag | kLinFlag;
-        else if (fabs(ax) <= 1073741824.0 && fabs(ay) <= 1073741824.0)  // 2^30 (NaN fails)
+        else if (amax <= 1073741824.0 && (amax + fmaxabs) * 225.0 * r2 * r2 <= 0x1p-19)  // |alpha| <= 2^30 (NaN fails)
           w.wrows |= kFastFlag | kAffFlag, affine = true;
 #else
         w.wrows |= kFastFlag;

@@ -79,6 +79,10 @@ typedef struct dmz_hip_frame_result {
 #define DMZ_HIP_FLAG_UPSIDE_DOWN 2 /* FrameScanResult.upside_down */
 #define DMZ_HIP_FLAG_VSEG_OK 4     /* passed the vseg gates (frame.cpp:38-47) */
 #define DMZ_HIP_FLAG_WARPED 8      /* card image was rectified */
+#define DMZ_HIP_FLAG_FAULT 16      /* a device self-check did not settle for this frame (the homography evaluated six times without
+                                      two consecutive results alike, geometry.hip): the frame is NOT rectified (no
+                                      DMZ_HIP_FLAG_WARPED, zero card, scan stages skip it).  Never seen in a sweep; a caller
+                                      re-submits the frame */
 
 /* ---- expiry path: scan/expiry_seg.h best_expiry_seg + the per-frame half of
  * scan/expiry_categorize.cpp (categorize_expiry_digits, :138-160).  One record per frame; the
@@ -112,7 +116,11 @@ typedef struct dmz_hip_expiry_result {
                                           defines no EIGEN_DONT_VECTORIZE).  Default (bit clear): Eigen's scalar order, what the
                                           reference's non-NEON ARM builds and -DEIGEN_DONT_VECTORIZE compute.  The two differ in
                                           the last bits of the homography on three frames of four, hence in ~15 bytes of such a
-                                          card.  Also a context default: dmz_hip_set_reference_flavour. */
+                                          card.  HOMOGRAPHY ONLY: hseg_score's last bits and the bilateral
+                                          filter stay in the scalar order.  Also a context default:
+                                          dmz_hip_set_reference_flavour. */
+#define DMZ_HIP_OPT_EIGEN_SCALAR 8     /* this call in Eigen's scalar order even when the context's default flavour is SSE2
+                                          (the per-call override of dmz_hip_set_reference_flavour; wins over DMZ_HIP_OPT_EIGEN_SSE2) */
 
 typedef struct dmz_hip_context dmz_hip_context;
 
@@ -303,9 +311,10 @@ int dmz_hip_blur_cards_batch(dmz_hip_context *ctx, uint8_t *rgb, size_t card_str
  * src_pts/dst_pts: 4 (x,y) pairs; m: 9 floats row-major (host pointers). */
 int dmz_hip_calc_persp_transform(dmz_hip_context *ctx, const float *src_pts,
                                  const float *dst_pts, float *m);
-/* Which build of the reference the context reproduces bit for bit where the two differ (today: the homography, see
- * DMZ_HIP_OPT_EIGEN_SSE2): 0 = Eigen's scalar paths (default), 1 = a stock x86-64 build (SSE2 packets).  The choice is OR-ed
- * into the options of every later transform / pipeline call of the context and applies to dmz_hip_calc_persp_transform. */
+/* The summation order of the HOMOGRAPHY (llcv_calc_persp_transform, and only that: see DMZ_HIP_OPT_EIGEN_SSE2) for the calls
+ * of this context that do not say: 0 = Eigen's scalar paths (default), 1 = a stock x86-64 build (SSE2 packets).  It is the
+ * default of every later transform / pipeline call -- a call with DMZ_HIP_OPT_EIGEN_SCALAR or DMZ_HIP_OPT_EIGEN_SSE2 in its
+ * options chooses for itself -- and applies to dmz_hip_calc_persp_transform. */
 int dmz_hip_set_reference_flavour(dmz_hip_context *ctx, int flavour);
 /* Batched cvWarpPerspective as used by llcv_unwarp (warp.cpp:153-166) with
  * caller-supplied 3x3 float matrices (n x 9, row-major). */
@@ -352,10 +361,6 @@ int dmz_hip_synth_frames(dmz_hip_context *ctx, uint64_t seed, uint64_t first_ind
                          uint8_t *y);
 int dmz_hip_synth_cards(dmz_hip_context *ctx, uint64_t seed, uint64_t first_index, int n,
                         uint8_t *cards);
-
-/* Test utility: overwrite the LDS of every CU with `word` (asynchronous, on the context's stream).  A kernel that reads
- * LDS words it never wrote sees them afterwards -- tests/test_gpu_hseg.py runs the scan behind 0xFFFFFFFF (a NaN pattern). */
-int dmz_hip_debug_fill_lds(dmz_hip_context *ctx, uint32_t word);
 
 /* Per-stage device timing with hipEvents on the context's stream. */
 #define DMZ_HIP_STAGE_DETECT 0

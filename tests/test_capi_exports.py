@@ -14,6 +14,12 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), "libdmz_hip.so does not export %s" % name
     assert sorted(pkg.EXPORTS) == declared
+    # the test-only entry points live in their own header, outside the boundary
+    test_header = open(os.path.join(ROOT, "include", "dmz_hip_test.h")).read()
+    test_declared = sorted(set(re.findall(r"\b(dmz_hip_[a-z0-9_]+)\s*\(", test_header)))
+    assert test_declared == sorted(pkg.TEST_EXPORTS) and not set(test_declared) & set(declared)
+    for name in test_declared:
+        assert hasattr(lib, name), "libdmz_hip.so does not export %s" % name
 
 
 def test_result_record_layout(pkg, orc):

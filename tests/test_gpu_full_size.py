@@ -169,7 +169,10 @@ def test_mixed_corpus_of_the_bench_against_the_oracle(ctx, pkg, oracle):
     kind = bench.mixed_kind(np.arange(first, first + n, dtype=np.int64))
     assert (kind < 4).sum() > n // 4 and (kind == 4).sum() > n // 32 and (kind > 4).sum() > n // 3
     rng = np.random.default_rng(77)
-    host = np.stack([oracle.synth_frame(SEED, first + i)[0] for i in range(n)])
+    synth = [oracle.synth_frame(SEED, first + i) for i in range(n)]
+    host = np.stack([y for y, _ in synth])
+    # the generator's card kind (oracle/orc_synth.c:103-135): a 16-digit card's number starts with 4, a 15-digit one's with 3
+    fifteen = np.array([d[0] == 3 for _, d in synth])
     for i in range(n):
         if kind[i] < 4:
             host[i] = rng.integers(18, 58, (480, 640), dtype=np.uint8)
@@ -183,8 +186,12 @@ def test_mixed_corpus_of_the_bench_against_the_oracle(ctx, pkg, oracle):
     gexp = exp.download(pkg.EXPIRY_DTYPE, n)
     assert not got["found_all"][kind < 4].any()                                  # no card: detection stops the frame
     assert ((got["flags"][kind == 4] & pkg.FLAG_UPSIDE_DOWN) != 0).all()         # upside down: vseg stops it
-    # (every tenth card is a 15-digit one, and a third of those are not read as such: the per-frame comparison below decides)
-    assert ((got["flags"][kind > 4] & pkg.FLAG_VSEG_OK) != 0).mean() > 0.9
+    # by card kind: EVERY 16-digit card passes the vseg gates; of the 15-digit ones (every tenth card) a third
+    # are not read as such -- a rate bound there, and the per-frame comparison below decides each frame
+    vseg_ok = (got["flags"] & pkg.FLAG_VSEG_OK) != 0
+    assert vseg_ok[(kind > 4) & ~fifteen].all()
+    if ((kind > 4) & fifteen).any():
+        assert vseg_ok[(kind > 4) & fifteen].mean() >= 0.3
     for i in range(n):
         w, wcard = oracle.scan_frame(host[i])
         g = got[i]

@@ -170,6 +170,18 @@ def test_warp_perspective_strength_sweep_byte_exact(ctx, pkg, oracle):
     for i in range(n):
         want = oracle.warp_perspective(frames[i], mats[i])
         assert np.array_equal(cards[i], want), (i, float(insets[i]), int((cards[i] != want).sum()))
+    # The same sweep on a WIDE plane: source x of ~7 600 .. 8 100 px puts |fX| at 2^18 units of 1/32 px, where
+    # the affine form's error budget no longer holds near rho = 2^-11 -- k_warp_windows checks the budget per strip and such
+    # strips take the exact loop; the bytes must not care which form ran.
+    W, H = 8192, 400
+    shift = np.array([7600, -40] * 4, np.float32)
+    mats_w = np.stack([oracle.calc_persp_transform(q + shift, dst) for q in quads])
+    plane = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    cards_w = np.full((n, 270, 428), 0x5A, np.uint8)
+    ctx.warp_perspective(plane, n, mats_w, cards_w, width=W, height=H)
+    for i in range(n):
+        want = oracle.warp_perspective(plane[i], mats_w[i])
+        assert np.array_equal(cards_w[i], want), ("wide", i, float(insets[i]), int((cards_w[i] != want).sum()))
 
 
 def test_scan_prewarped_cards(ctx, pkg, oracle):
