@@ -65,11 +65,20 @@ def test_homography_in_the_sse2_order_of_a_stock_x86_build(ctx, pkg, oracle):
         ctx.synchronize()
         sse_cards = cards.download(np.uint8).reshape(n, 270, 428)
         got = res.download(pkg.RESULT_DTYPE, n)
+        # the per-call override (DMZ_HIP_OPT_EIGEN_SCALAR): one call in the scalar order while the context default is SSE2
+        ctx.pipeline(y.ptr, n, res.ptr, cards.ptr, options=pkg.OPT_EIGEN_SCALAR)
+        ctx.synchronize()
+        scalar_call_cards = cards.download(np.uint8).reshape(n, 270, 428)
     finally:
         ctx.set_reference_flavour(0)
     ctx.pipeline(y.ptr, n, res.ptr, cards.ptr)
     ctx.synchronize()
     default_cards = cards.download(np.uint8).reshape(n, 270, 428)
+    assert np.array_equal(scalar_call_cards, default_cards)
+    ctx.pipeline(y.ptr, n, res.ptr, cards.ptr, options=pkg.OPT_EIGEN_SSE2)  # and the other way round
+    ctx.synchronize()
+    assert np.array_equal(cards.download(np.uint8).reshape(n, 270, 428), sse_cards)
+    assert not (res.download(pkg.RESULT_DTYPE, n)["flags"] & pkg.FLAG_FAULT).any()
     frames = y.download(np.uint8).reshape(n, 480, 640)
     moved = 0
     for i in range(n):
