@@ -251,6 +251,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #ifndef DMZ_XSEG_TIES  /* developer ablation (timing only, wrong ties): 0 = column tie-break, no watch; 1 = watch, never re-order */
 #define DMZ_XSEG_TIES 2
 #endif
+#ifndef DMZ_XSEG_ROWS2  /* developer A/B: 0 = round 5's horizontal pass (a dword per lane and row, column sums from LDS) */
+#define DMZ_XSEG_ROWS2 1
+#endif
 #ifndef DMZ_XSEG_FOLD  /* developer switch: 0 = the slash MLP always on Scharr samples */
 #define DMZ_XSEG_FOLD 1
 #endif
@@ -411,6 +414,109 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     if (R >= y0 && R <= CH - 1) vmask |= 1u << k;
   }
 
+#if DMZ_XSEG_ROWS2
+  // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766) AND the column sums
+  // (456-486) in one go (round 6).  Lane l < 54 owns the dword PAIR (2 l, 2 l + 1) of every row: one 8-byte load per row, all
+  // 23 in flight together; of the four neighbour dwords a pair needs, two are its own and two come from the adjacent lanes
+  // (DPP wave shifts; the column clamp at 0 / 427, sobel.cpp:729-734, rides in the shifts' `old` operand and in one v_perm).
+  // |p[c+1] - p[c-1]| on 16-bit fields: the left / right neighbours of a dword's even and odd columns are each ONE v_perm_b32
+  // (or a mask) of (previous | this | next) dword, the absolute difference is two saturating v_pk_sub_u16 and an OR
+  // (12 VALU per dword where the alignbyte / mask / negate / max form took 26).  The even / odd fields are exactly what the
+  // column sums accumulate -- colA[c] = sum over window rows k = 3 .. 19 of the Scharr sample v_k (0 outside the ROI), colB
+  // the same over k = 2 .. 18; v_k = 3 inter[k] + 10 inter[k + 1] + 3 inter[k + 2], so both are WEIGHTED SUMS OF THE INTER
+  // ROWS with wave-uniform weights (<= 16) that fold the ROI mask in: one v_mad_u32_u24 per field pair, row and sum, ten rows
+  // per accumulator (10 x 16 x 255 < 2^16), no LDS round trip.  Integer arithmetic throughout: the sums are exact. ----
+  {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    auto absdiff = [](uint32_t r, uint32_t l) {
+      const u16x2 rv = __builtin_bit_cast(u16x2, r), lv = __builtin_bit_cast(u16x2, l);
+      return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(rv, lv)) |
+             __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(lv, rv));
+    };
+    unsigned ca[24], cb[24];  // uniform (scalar registers)
+#pragma unroll
+    for (int r = 0; r < IROWS; r++) {
+      unsigned wa = 0u, wb = 0u;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {  // inter row r is tap t of sample k = r - t (weights 3, 10, 3)
+        const int k = r - t;
+        const unsigned wt = t == 1 ? 10u : 3u, m = (vmask >> (k < 0 ? 0 : k)) & 1u;
+        if (k >= 3 && k <= 19) wa += wt * m;
+        if (k >= 2 && k <= 18) wb += wt * m;
+      }
+      ca[r] = wa, cb[r] = wb;
+    }
+    // (buffer loads: the dword past a card's last row -- lane 53's second one, never used -- reads as zero)
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void *)card, 0, CW * CH, 0x00020000);
+    const int pl = lane < 54 ? lane : 53;
+    u32x2 cc[IROWS];
+#pragma unroll
+    for (int t = 0; t < IROWS; t++) {
+      const int rowc = imin(imax(base - 4 + t, y0), CH - 1);
+      cc[t] = __builtin_amdgcn_raw_buffer_load_b64(crs, 8 * pl, rowc * CW, 0);
+    }
+    // lane 53's second dword does not exist: the column clamp wants its first dword's last byte there (byte 0)
+    const uint32_t ysel = lane == 53 ? 0x0c0c0c07u : 0x03020100u;
+    uint32_t ox[IROWS], oy[IROWS];
+    uint32_t aE[2][2] = {{0u, 0u}, {0u, 0u}}, aO[2][2] = {{0u, 0u}, {0u, 0u}}, bE[2][2] = {{0u, 0u}, {0u, 0u}}, bO[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int t = 0; t < IROWS; t++) {
+      const uint32_t x = cc[t].x, y = __builtin_amdgcn_perm(x, cc[t].y, ysel);
+      // dword 2 l - 1 (lane 0: the clamp, p[-1] = p[0], as byte 3) and dword 2 l + 2 (lanes past 52: unused)
+      const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp((int)(x << 24), (int)y, 0x138, 0xf, 0xf, false);
+      const uint32_t ny = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true);
+      // even columns (0, 2) / odd columns (1, 3) of a dword as two 16-bit fields: left = p[c - 1], right = p[c + 1]
+      const uint32_t xe = absdiff(__builtin_amdgcn_perm(x, x, 0x0c030c01u), __builtin_amdgcn_perm(x, px, 0x0c050c03u));
+      const uint32_t xo = absdiff(__builtin_amdgcn_perm(y, x, 0x0c040c02u), x & 0x00FF00FFu);
+      const uint32_t ye = absdiff(__builtin_amdgcn_perm(y, y, 0x0c030c01u), __builtin_amdgcn_perm(y, x, 0x0c050c03u));
+      const uint32_t yo = absdiff(__builtin_amdgcn_perm(ny, y, 0x0c040c02u), y & 0x00FF00FFu);
+      ox[t] = xe | (xo << 8);
+      oy[t] = ye | (yo << 8);
+      if (t >= 2 && t <= 21) {
+        const int g = t >= 12;
+        aE[0][g] = __umul24(xe, ca[t]) + aE[0][g], aO[0][g] = __umul24(xo, ca[t]) + aO[0][g];
+        bE[0][g] = __umul24(xe, cb[t]) + bE[0][g], bO[0][g] = __umul24(xo, cb[t]) + bO[0][g];
+        aE[1][g] = __umul24(ye, ca[t]) + aE[1][g], aO[1][g] = __umul24(yo, ca[t]) + aO[1][g];
+        bE[1][g] = __umul24(ye, cb[t]) + bE[1][g], bO[1][g] = __umul24(yo, cb[t]) + bO[1][g];
+      }
+    }
+    if (lane < 54) {
+#pragma unroll
+      for (int t = 0; t < IROWS; t++) *(uint32_t *)(L.inter + t * ISTRIDE + 8 * lane) = ox[t];
+#pragma unroll
+      for (int h = 0; h < 1; h++) {
+        const int c = 8 * lane;
+        L.u.colA[c + 0] = (int)((aE[0][0] & 0xffffu) + (aE[0][1] & 0xffffu));
+        L.u.colA[c + 1] = (int)((aO[0][0] & 0xffffu) + (aO[0][1] & 0xffffu));
+        L.u.colA[c + 2] = (int)((aE[0][0] >> 16) + (aE[0][1] >> 16));
+        L.u.colA[c + 3] = (int)((aO[0][0] >> 16) + (aO[0][1] >> 16));
+        L.colB[c + 0] = (int)((bE[0][0] & 0xffffu) + (bE[0][1] & 0xffffu));
+        L.colB[c + 1] = (int)((bO[0][0] & 0xffffu) + (bO[0][1] & 0xffffu));
+        L.colB[c + 2] = (int)((bE[0][0] >> 16) + (bE[0][1] >> 16));
+        L.colB[c + 3] = (int)((bO[0][0] >> 16) + (bO[0][1] >> 16));
+      }
+    }
+    if (lane < 53) {
+#pragma unroll
+      for (int t = 0; t < IROWS; t++) *(uint32_t *)(L.inter + t * ISTRIDE + 8 * lane + 4) = oy[t];
+      const int c = 8 * lane + 4;
+      L.u.colA[c + 0] = (int)((aE[1][0] & 0xffffu) + (aE[1][1] & 0xffffu));
+      L.u.colA[c + 1] = (int)((aO[1][0] & 0xffffu) + (aO[1][1] & 0xffffu));
+      L.u.colA[c + 2] = (int)((aE[1][0] >> 16) + (aE[1][1] >> 16));
+      L.u.colA[c + 3] = (int)((aO[1][0] >> 16) + (aO[1][1] >> 16));
+      L.colB[c + 0] = (int)((bE[1][0] & 0xffffu) + (bE[1][1] & 0xffffu));
+      L.colB[c + 1] = (int)((bO[1][0] & 0xffffu) + (bO[1][1] & 0xffffu));
+      L.colB[c + 2] = (int)((bE[1][0] >> 16) + (bE[1][1] >> 16));
+      L.colB[c + 3] = (int)((bO[1][0] >> 16) + (bO[1][1] >> 16));
+    }
+  }
+  __syncthreads();
+  XS_TL(0)
+  XSEG_STOP(1, L.inter[lane])
+  XS_TL(1)
+  XSEG_STOP(2, L.u.colA[lane])
+#else
   // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766).
   // Each dword of a row is loaded once (all 46 loads of a lane in flight together); the
   // neighbouring dwords come from the adjacent lanes. ----
@@ -489,6 +595,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
   __syncthreads();
   XS_TL(1)
   XSEG_STOP(2, L.u.colA[lane])
+#endif
   // thresholds (expiry_seg.cpp:447-449, 488-494).  While the running total stays below 2^24 every
   // float addition of these integers is exact, so the float total equals the integer total whenever
   // that is < 2^24 (the common case); only beyond that the additions round and the reference's

@@ -253,7 +253,10 @@ __device__ __forceinline__ void vseg_mlp_rows_bf16(const bf16x8 *__restrict__ wb
                                                   const float *__restrict__ norm, int nrows,
                                                   float *__restrict__ part /* [4][VS_PROWS][3] */, int wave,
                                                   int lane) {
-  const int ii = lane & 15, kk = lane >> 4;
+  int lane_here = lane;
+  asm volatile("" : "+v"(lane_here));  // (round 6: 8 kk is recomputed here from the lane -- kept alive across the feature
+                                       // phase it was the kernel's one spilled register)
+  const int ii = lane_here & 15, kk = lane_here >> 4;
   const unsigned char *ap[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
