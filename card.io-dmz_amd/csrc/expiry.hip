@@ -251,6 +251,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #ifndef DMZ_XSEG_TIES  /* developer ablation (timing only, wrong ties): 0 = column tie-break, no watch; 1 = watch, never re-order */
 #define DMZ_XSEG_TIES 2
 #endif
+#ifndef DMZ_XSEG_LAZY  /* developer A/B: 0 = every regridded rect is trimmed (round 5) */
+#define DMZ_XSEG_LAZY 1
+#endif
 #ifndef DMZ_XSEG_ROWS2  /* developer A/B: 0 = round 5's horizontal pass (a dword per lane and row, column sums from LDS) */
 #define DMZ_XSEG_ROWS2 1
 #endif
@@ -970,6 +973,130 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     XS_TL(5)
     if (DMZ_XSEG_STOP == 6) continue;
 
+#if DMZ_XSEG_LAZY
+    // ---- optimize_character_rects (231-339), round 6: LAZILY.  A rect is dropped for its position alone (:259-266) and
+    // every rect is trimmed on its own, so the group's rect COUNT is known here, and the trimmed positions are needed of the
+    // slash candidates only (the middle characters of the windows of five, :643) -- and, for a window whose middle character
+    // turns out to be a slash, of its other four.  Here the rects are listed untrimmed (cLeft = left of the expanded image,
+    // cTop = minus its width: pending); the trimming runs once over the stripe's candidates, and after the slash search over
+    // what the hits still need.  The synthetic corpus: 17.3 rects per stripe, 8 of them candidates. ----
+    const int ciw = cw + 4, cih = 17 + 4;
+    {
+      const int rect_left = (lane >= rs && lane < re) ? L.u.b.rL[lane] - 2 : 0;
+      const bool keep = lane >= rs && lane < re && !(rect_left < 0 || rect_left + ciw > CW || (g_top - 2) + cih > CH);
+      const unsigned long long kbal = __ballot(keep);
+      const int n2 = __popcll(kbal);
+      const int rank = __popcll(kbal & lanemask_lt(lane));
+      if (keep && rbase + rank < kMaxRects) {  // (always: see SegLds)
+        L.u.b.cLeft[rbase + rank] = (short)rect_left;
+        L.u.b.cTop[rbase + rank] = (short)-ciw;
+      }
+      // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623); the windows of five of this group: middle characters 2 .. n2 - 3
+      if (n2 >= 5 && DMZ_XSEG_STOP != 7 && rbase + n2 <= kMaxRects) {
+        if (lane >= 2 && lane < n2 - 2) L.u.b.cand[ncand + lane - 2] = (unsigned char)(rbase + lane);
+        ncand += n2 - 4;
+      }
+      rbase += n2;
+    }
+    __syncthreads();
+    XS_TL(6)
+  }
+  // three rects per pass, 21 lanes each.  Lane c of a slot owns column c of the 21-row window: one column of Scharr samples
+  // in registers serves the max, the normalise+threshold and the column sum; the row sums come from a transposed read of
+  // the thresholded tile (lane r = row r).  `idx` (per lane, uniform within a slot): the slot's rect in cLeft / cTop, < 0 none.
+  auto optimize_batch = [&](const int idx) {
+    const int sl = lane / 21, c = lane - sl * 21;
+    unsigned char *tile = L.u.b.tile;  // [3][21][19]
+    constexpr int cih = 17 + 4;
+    const bool have = sl < 3 && idx >= 0;
+    const int rect_left = have ? L.u.b.cLeft[idx] : 0;
+    const int ciw = have ? -L.u.b.cTop[idx] : 0;
+    const bool col = have && c < ciw;
+    int v[21];
+    int mx = 0;
+    {
+      // (idle lanes -- columns past the window, the slot-less lane 63 -- read column 0 and are zeroed once below: a
+      // predicated load per row was a v_mov, an exec save and an exec restore each)
+      int iv[IROWS];
+      const int rl = col ? rect_left + c : 0;
+#pragma unroll
+      for (int t = 0; t < IROWS; t++) iv[t] = (int)L.inter[t * ISTRIDE + rl];
+      if (vmask == 0x1FFFFFu) {  // (wave-uniform) the usual case: all 21 window rows inside the ROI, no per-row select
+#pragma unroll
+        for (int r = 0; r < 21; r++) {
+          v[r] = 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1];
+          mx = imax(mx, v[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 21; r++) {
+          v[r] = ((vmask >> r) & 1u) ? 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1] : 0;
+          mx = imax(mx, v[r]);
+        }
+      }
+    }
+    const int sidx = sl * 24 + c;  // this lane's entry of the per-slot arrays
+    if (!col) {
+      mx = 0;
+#pragma unroll
+      for (int r = 0; r < 21; r++) v[r] = 0;
+    }
+    L.u.b.cm[sidx] = mx;
+    __syncthreads();
+    if (sl < 3) {
+#pragma unroll
+      for (int j = 0; j < 18; j++) mx = imax(mx, L.u.b.cm[sl * 24 + j]);
+    }
+    // cvNormalize's scale is (float)(255.0 / (double)max); for every integer max in [1, 32767] that
+    // equals the correctly rounded float quotient (checked exhaustively, tests/test_oracle_units.py)
+    const float scale = mx > 0 ? 255.0f / (float)mx : 0.0f;
+    int cs = 0;
+    if (sl < 3) {
+#pragma unroll
+      for (int r = 0; r < 21; r++) {
+        const int t = norm_thresh(v[r], scale);
+        cs += t;
+        if (c < 19) tile[(sl * 21 + r) * XT_PITCH + c] = t;
+      }
+    }
+    L.u.b.cm[sidx] = cs;
+    __syncthreads();
+    // column trimming (every lane of the slot replays it: uniform within the slot)
+    int lc = 0, rc = ciw - 1;
+    if (sl < 3)
+      for (int wv = ciw; wv > TW; wv--) {
+        if (L.u.b.cm[sl * 24 + lc] <= L.u.b.cm[sl * 24 + rc]) lc++;
+        else rc--;
+      }
+    int rsm = 0;
+    if (sl < 3) {  // lane c is row c here: the eleven bytes lc .. lc + 10 (= rc) of its row, from four aligned dwords
+      typedef const volatile __attribute__((address_space(3))) uint32_t *lds_vu32;  // (volatile: no merging into b64 / b128)
+      const lds_vu32 rowp = (lds_vu32)(tile + (sl * 21 + c) * XT_PITCH + (lc & ~3));
+      const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2], w3 = rowp[3];
+      const uint32_t sh = (uint32_t)(lc & 3);
+      rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), 0u, 0u);
+      rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), 0u, (uint32_t)rsm);
+      rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w3, w2, sh) & 0x00FFFFFFu, 0u, (uint32_t)rsm);
+    }
+    __syncthreads();
+    L.u.b.cm[sidx] = rsm;  // row sums
+    __syncthreads();
+    if (have && c == 0) {  // the slot's first lane walks the rows and files the trimmed rect
+      int tr = 0, brw = cih - 1;
+      for (int hv = cih; hv > TH; hv--) {
+        if (L.u.b.cm[sl * 24 + tr] <= L.u.b.cm[sl * 24 + brw]) tr++;
+        else brw--;
+      }
+      L.u.b.cLeft[idx] = (short)(rect_left + lc);
+      L.u.b.cTop[idx] = (short)((g_top - 2) + tr);
+    }
+    __syncthreads();
+  };
+  for (int b0 = 0; b0 < ncand; b0 += 3) {
+    const int k = b0 + lane / 21;
+    optimize_batch(lane < 63 && k < ncand ? (int)L.u.b.cand[k] : -1);
+  }
+#else
     // ---- optimize_character_rects (231-339): three rects per pass, 21 lanes each.  Lane c of a
     // slot owns column c of the 21-row window: one column of Scharr samples in registers serves
     // the max, the normalise+threshold and the column sum; the row sums come from a transposed
@@ -1097,6 +1224,7 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     __syncthreads();
     XS_TL(6)
   }
+#endif
   XS_TL(7)
   {
     // ---- slash search (643-674): character first+2 of every window of five, sixteen candidates
@@ -1255,6 +1383,31 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
                                ((unsigned)__builtin_amdgcn_readlane((int)hits, 31) << 4) |
                                ((unsigned)__builtin_amdgcn_readlane((int)hits, 47) << 8) |
                                ((unsigned)__builtin_amdgcn_readlane((int)hits, 63) << 12);
+#if DMZ_XSEG_LAZY
+      if (hitmask) {
+        // the other four characters of the windows with a slash: whatever is still pending is trimmed now (rect indices are
+        // < 80: lane i looks at rects i and i + 64; the list goes where the regridded lefts were)
+        unsigned long long need0 = 0ull, need1 = 0ull;
+        for (int q = 0; q < nc; q++)
+          if ((hitmask >> q) & 1u) {
+            const int first = (int)L.u.b.cand[k0 + q] - 2;  // (uniform)
+            const unsigned long long five = 0x1Full;
+            need0 |= first < 64 ? five << first : 0ull;
+            need1 |= first >= 64 ? five << (first - 64) : (first > 59 ? five >> (64 - first) : 0ull);
+          }
+        const bool p0 = ((need0 >> lane) & 1ull) && L.u.b.cTop[lane] < 0;
+        const bool p1 = lane < kMaxRects - 64 && ((need1 >> lane) & 1ull) && L.u.b.cTop[64 + lane] < 0;
+        const unsigned long long bp0 = __ballot(p0), bp1 = __ballot(p1);
+        const int np0 = __popcll(bp0), npend = np0 + __popcll(bp1);
+        if (p0) L.u.b.rL[__popcll(bp0 & lanemask_lt(lane))] = (short)lane;
+        if (p1) L.u.b.rL[np0 + __popcll(bp1 & lanemask_lt(lane))] = (short)(64 + lane);
+        __syncthreads();
+        for (int b0 = 0; b0 < npend; b0 += 3) {
+          const int k = b0 + lane / 21;
+          optimize_batch(lane < 63 && k < npend ? (int)L.u.b.rL[k] : -1);
+        }
+      }
+#endif
       for (int q = 0; q < nc; q++) {
         if (!((hitmask >> q) & 1u)) continue;
         if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
