@@ -81,14 +81,23 @@ __device__ __forceinline__ int with_lane(int x, int v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict__ cards, size_t card_stride,
-                                                       int n, const dmz_hip_frame_result *__restrict__ results,
-                                                       dmz_hip_expiry_result *__restrict__ out,
-                                                       DmzExpiryStage *__restrict__ stage) {
-  const int f = blockIdx.x, lane = threadIdx.x;
-  if (f >= n) return;
-  __shared__ int I[128];
-  __shared__ int line[128 + 16];
+// LDS the stripe search needs (a kernel's own, or -- in the fused kernel -- the head of the segmentation's block)
+struct StripeLds {
+  int I[128];
+  int line[128 + 16];
+  unsigned sv[128];
+  unsigned sstack[20];
+  unsigned short sq[128];
+};
+// the body for frame f by one wave: clears the frame's expiry record and stage counters, finds the stripes, writes them to
+// out[f] and returns them (uniform) in base_row[] / sum[]; the return value is their number
+__device__ __forceinline__ int expiry_stripes_body(const int f, const int lane, const uint8_t *__restrict__ cards, size_t card_stride,
+                                                   const dmz_hip_frame_result *__restrict__ results,
+                                                   dmz_hip_expiry_result *__restrict__ out, DmzExpiryStage *__restrict__ stage,
+                                                   StripeLds &SL, int (&base_row)[3], long long (&sum_out)[3]) {
+  int *const I = SL.I, *const line = SL.line;
+  base_row[0] = base_row[1] = base_row[2] = 0;
+  sum_out[0] = sum_out[1] = sum_out[2] = 0;
   {
     uint32_t *o32 = (uint32_t *)(out + f);
     for (int i = lane; i < (int)(sizeof(dmz_hip_expiry_result) / 4); i += 64) o32[i] = 0u;
@@ -96,10 +105,10 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   }
   const int flags = results[f].flags, yoff = results[f].vseg_y_offset;
   // frame.cpp:72 -- and the vseg gates of frame.cpp:38-47 that precede it
-  if (!(flags & DMZ_HIP_FLAG_VSEG_OK) || !(yoff < CH - 2 * SCH) || yoff < 0) return;
+  if (!(flags & DMZ_HIP_FLAG_VSEG_OK) || !(yoff < CH - 2 * SCH) || yoff < 0) return 0;
   const int y0 = yoff + kNumberHeight;
   const int nrows = CH - y0;
-  if (nrows > 128 || nrows < 18) return;  // y_offset >= 121 for a card that is not upside down
+  if (nrows > 128 || nrows < 18) return 0;  // y_offset >= 121 for a card that is not upside down
   const uint8_t *card = cards + (size_t)f * card_stride;
 
   // 32 rows per trip, all of a trip's loads in flight together.  A lane loads dword 6 + lane of every row (p[24 + 4 lane ..]);
@@ -181,9 +190,8 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
   // the reference visits them in std::sort's order.  A round whose best sum is held by two live candidates is the only place
   // where that order can matter (0.3 % of the corpus' cards): then the good stripes are sorted as the library sorts them
   // (one lane; <= 111 elements) and the rounds repeat with the sorted position as tie-break.
-  __shared__ unsigned sv[128];
-  __shared__ unsigned sstack[20];
-  __shared__ unsigned short sq[128];
+  unsigned *const sv = SL.sv, *const sstack = SL.sstack;
+  unsigned short *const sq = SL.sq;
   const unsigned k0 = key[0], k1 = key[1];
   int np = 0;
   auto rounds = [&](bool watch) -> bool {
@@ -202,6 +210,8 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
         out[f].stripe_base_row[np] = y0 + 1 + idx;
         out[f].stripe_sum[np] = (int64_t)(m >> 7);
       }
+      base_row[np] = y0 + 1 + idx;
+      sum_out[np] = (long long)(m >> 7);
       np++;
 #pragma unroll
       for (int j = 0; j < 2; j++)
@@ -231,6 +241,19 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
       for (int i = np; i < 3; i++) out[f].stripe_base_row[i] = 0, out[f].stripe_sum[i] = 0;
   }
   if (lane == 0) out[f].n_stripes = np;
+  return np;
+}
+
+__global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict__ cards, size_t card_stride,
+                                                       int n, const dmz_hip_frame_result *__restrict__ results,
+                                                       dmz_hip_expiry_result *__restrict__ out,
+                                                       DmzExpiryStage *__restrict__ stage) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n) return;
+  __shared__ StripeLds SL;
+  int br[3];
+  long long su[3];
+  (void)expiry_stripes_body(f, lane, cards, card_stride, results, out, stage, SL, br, su);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -250,6 +273,10 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #endif
 #ifndef DMZ_XSEG_TIES  /* developer ablation (timing only, wrong ties): 0 = column tie-break, no watch; 1 = watch, never re-order */
 #define DMZ_XSEG_TIES 2
+#endif
+#ifndef DMZ_XSEG_FUSED  /* developer A/B: 1 = k_expiry_seg_fused, a wave per frame does the stripe search and then its stripes (round 6:
+                           stage -0.07 ms, timed step unchanged: not the default; profiles/r6_expiry_fused_stripes_ab.log) */
+#define DMZ_XSEG_FUSED 0
 #endif
 #ifndef DMZ_XSEG_LAZY  /* developer A/B: 0 = every regridded rect is trimmed (round 5) */
 #define DMZ_XSEG_LAZY 1
@@ -315,6 +342,7 @@ struct SegLds {
   } u;
   // surviving local groups (a group is at least four 9-px rects and groups are a rect apart: at most nine fit 428 columns)
   short gL[16], gW[16];
+  int stripe_row[4], stripe_sum[4];  // the fused kernel's stripes (k_expiry_seg_fused): kept here, not in registers, across a stripe's body
 };
 static_assert(sizeof(SegLds) <= 13648, "twelve stripes per CU");
 
@@ -388,20 +416,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-__global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
-                                                      const uint8_t *__restrict__ cards, size_t card_stride, int n,
-                                                      const dmz_hip_frame_result *__restrict__ results,
-                                                      const dmz_hip_expiry_result *__restrict__ er,
-                                                      DmzExpiryStage *__restrict__ stage) {
-  const int f = blockIdx.x / 3, st = blockIdx.x - f * 3, lane = threadIdx.x;
-  if (f >= n) return;
-  if (st >= er[f].n_stripes) return;
-  __shared__ SegLds L;
-  const int base = er[f].stripe_base_row[st];
-  const long long stripe_sum = er[f].stripe_sum[st];
-  const int y0 = results[f].vseg_y_offset + kNumberHeight;
-  const uint8_t *card = cards + (size_t)f * card_stride;
-  DmzExpiryStage *sg = stage + (size_t)f * 3 + st;
+// one (frame, stripe) by one wave
+__device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__restrict__ wts, const float *__restrict__ xw,
+                                                  const uint8_t *__restrict__ card, const int n, const int y0, const int base,
+                                                  const long long stripe_sum, DmzExpiryStage *__restrict__ sg, const int lane) {
   int n_emitted = 0;
 #ifdef DMZ_XSEG_DBG
   const long long dbg_start = __builtin_readcyclecounter();
@@ -461,21 +479,27 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
     }
     // lane 53's second dword does not exist: the column clamp wants its first dword's last byte there (byte 0)
     const uint32_t ysel = lane == 53 ? 0x0c0c0c07u : 0x03020100u;
-    uint32_t ox[IROWS], oy[IROWS];
+    // Lane 53's second dword does not exist: it is stored as a second copy of its first, at the first one's address (one
+    // predicate for both stores of a row; lanes past 53 store nothing).
+    const bool two = lane < 53, live = lane < 54;
+    unsigned char *const px = L.inter + 8 * pl, *const py = px + (two ? 4 : 0);
     uint32_t aE[2][2] = {{0u, 0u}, {0u, 0u}}, aO[2][2] = {{0u, 0u}, {0u, 0u}}, bE[2][2] = {{0u, 0u}, {0u, 0u}}, bO[2][2] = {{0u, 0u}, {0u, 0u}};
 #pragma unroll
     for (int t = 0; t < IROWS; t++) {
       const uint32_t x = cc[t].x, y = __builtin_amdgcn_perm(x, cc[t].y, ysel);
       // dword 2 l - 1 (lane 0: the clamp, p[-1] = p[0], as byte 3) and dword 2 l + 2 (lanes past 52: unused)
-      const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp((int)(x << 24), (int)y, 0x138, 0xf, 0xf, false);
+      const uint32_t px_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(x << 24), (int)y, 0x138, 0xf, 0xf, false);
       const uint32_t ny = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true);
       // even columns (0, 2) / odd columns (1, 3) of a dword as two 16-bit fields: left = p[c - 1], right = p[c + 1]
-      const uint32_t xe = absdiff(__builtin_amdgcn_perm(x, x, 0x0c030c01u), __builtin_amdgcn_perm(x, px, 0x0c050c03u));
+      const uint32_t xe = absdiff(__builtin_amdgcn_perm(x, x, 0x0c030c01u), __builtin_amdgcn_perm(x, px_, 0x0c050c03u));
       const uint32_t xo = absdiff(__builtin_amdgcn_perm(y, x, 0x0c040c02u), x & 0x00FF00FFu);
       const uint32_t ye = absdiff(__builtin_amdgcn_perm(y, y, 0x0c030c01u), __builtin_amdgcn_perm(y, x, 0x0c050c03u));
       const uint32_t yo = absdiff(__builtin_amdgcn_perm(ny, y, 0x0c040c02u), y & 0x00FF00FFu);
-      ox[t] = xe | (xo << 8);
-      oy[t] = ye | (yo << 8);
+      const uint32_t ox = xe | (xo << 8), oy = ye | (yo << 8);
+      if (live) {
+        *(uint32_t *)(px + t * ISTRIDE) = ox;
+        *(uint32_t *)(py + t * ISTRIDE) = two ? oy : ox;
+      }
       if (t >= 2 && t <= 21) {
         const int g = t >= 12;
         aE[0][g] = __umul24(xe, ca[t]) + aE[0][g], aO[0][g] = __umul24(xo, ca[t]) + aO[0][g];
@@ -484,34 +508,24 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
         bE[1][g] = __umul24(ye, cb[t]) + bE[1][g], bO[1][g] = __umul24(yo, cb[t]) + bO[1][g];
       }
     }
-    if (lane < 54) {
+    {
+      int *const qa = L.u.colA + 8 * pl, *const qb = L.colB + 8 * pl;
+      int sa[2][4], sb[2][4];
 #pragma unroll
-      for (int t = 0; t < IROWS; t++) *(uint32_t *)(L.inter + t * ISTRIDE + 8 * lane) = ox[t];
-#pragma unroll
-      for (int h = 0; h < 1; h++) {
-        const int c = 8 * lane;
-        L.u.colA[c + 0] = (int)((aE[0][0] & 0xffffu) + (aE[0][1] & 0xffffu));
-        L.u.colA[c + 1] = (int)((aO[0][0] & 0xffffu) + (aO[0][1] & 0xffffu));
-        L.u.colA[c + 2] = (int)((aE[0][0] >> 16) + (aE[0][1] >> 16));
-        L.u.colA[c + 3] = (int)((aO[0][0] >> 16) + (aO[0][1] >> 16));
-        L.colB[c + 0] = (int)((bE[0][0] & 0xffffu) + (bE[0][1] & 0xffffu));
-        L.colB[c + 1] = (int)((bO[0][0] & 0xffffu) + (bO[0][1] & 0xffffu));
-        L.colB[c + 2] = (int)((bE[0][0] >> 16) + (bE[0][1] >> 16));
-        L.colB[c + 3] = (int)((bO[0][0] >> 16) + (bO[0][1] >> 16));
+      for (int h = 0; h < 2; h++) {
+        sa[h][0] = (int)((aE[h][0] & 0xffffu) + (aE[h][1] & 0xffffu)), sa[h][1] = (int)((aO[h][0] & 0xffffu) + (aO[h][1] & 0xffffu));
+        sa[h][2] = (int)((aE[h][0] >> 16) + (aE[h][1] >> 16)), sa[h][3] = (int)((aO[h][0] >> 16) + (aO[h][1] >> 16));
+        sb[h][0] = (int)((bE[h][0] & 0xffffu) + (bE[h][1] & 0xffffu)), sb[h][1] = (int)((bO[h][0] & 0xffffu) + (bO[h][1] & 0xffffu));
+        sb[h][2] = (int)((bE[h][0] >> 16) + (bE[h][1] >> 16)), sb[h][3] = (int)((bO[h][0] >> 16) + (bO[h][1] >> 16));
       }
-    }
-    if (lane < 53) {
+      const int yo4 = two ? 4 : 0;
+      if (live) {
 #pragma unroll
-      for (int t = 0; t < IROWS; t++) *(uint32_t *)(L.inter + t * ISTRIDE + 8 * lane + 4) = oy[t];
-      const int c = 8 * lane + 4;
-      L.u.colA[c + 0] = (int)((aE[1][0] & 0xffffu) + (aE[1][1] & 0xffffu));
-      L.u.colA[c + 1] = (int)((aO[1][0] & 0xffffu) + (aO[1][1] & 0xffffu));
-      L.u.colA[c + 2] = (int)((aE[1][0] >> 16) + (aE[1][1] >> 16));
-      L.u.colA[c + 3] = (int)((aO[1][0] >> 16) + (aO[1][1] >> 16));
-      L.colB[c + 0] = (int)((bE[1][0] & 0xffffu) + (bE[1][1] & 0xffffu));
-      L.colB[c + 1] = (int)((bO[1][0] & 0xffffu) + (bO[1][1] & 0xffffu));
-      L.colB[c + 2] = (int)((bE[1][0] >> 16) + (bE[1][1] >> 16));
-      L.colB[c + 3] = (int)((bO[1][0] >> 16) + (bO[1][1] >> 16));
+        for (int k = 0; k < 4; k++) {
+          qa[k] = sa[0][k], qb[k] = sb[0][k];
+          qa[yo4 + k] = two ? sa[1][k] : sa[0][k], qb[yo4 + k] = two ? sb[1][k] : sb[0][k];
+        }
+      }
     }
   }
   __syncthreads();
@@ -1446,6 +1460,59 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 #endif
 }
 
+__global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                      const uint8_t *__restrict__ cards, size_t card_stride, int n,
+                                                      const dmz_hip_frame_result *__restrict__ results,
+                                                      const dmz_hip_expiry_result *__restrict__ er,
+                                                      DmzExpiryStage *__restrict__ stage) {
+  const int f = blockIdx.x / 3, st = blockIdx.x - f * 3, lane = threadIdx.x;
+  if (f >= n) return;
+  if (st >= er[f].n_stripes) return;
+  __shared__ SegLds L;
+  expiry_seg_stripe(L, wts, xw, cards + (size_t)f * card_stride, n, results[f].vseg_y_offset + kNumberHeight,
+                    er[f].stripe_base_row[st], er[f].stripe_sum[st], stage + (size_t)f * 3 + st, lane);
+}
+
+// Round 6, measured, not the default: stripes + segmentation in ONE kernel, a wave per frame -- the row sums
+// below the number, the stripe search, then the frame's (up to three) stripes one after the other.  The stripe search's loads
+// (~92 scattered 258-byte row pieces per card, a pass of its own over HBM) then wait beside eleven other waves' list logic, and
+// the 23 rows a stripe stages come back from the cache the search has just pulled them through.  expiry_seg stage 2.66 ->
+// 2.59 ms, the three-queue step 18.88 -> 18.91 ms (profiles/r6_expiry_fused_stripes_ab.log): the search's 13 k cycles of waiting
+// cost a 12-wave-per-CU kernel about what they cost a kernel of their own at 32 waves per CU.
+static_assert(sizeof(StripeLds) <= IROWS * ISTRIDE, "the stripe search's arrays lie over the horizontal-pass bytes");
+__global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg_fused(const float *__restrict__ wts, const float *__restrict__ xw,
+                                                            const uint8_t *__restrict__ cards, size_t card_stride, int n,
+                                                            const dmz_hip_frame_result *__restrict__ results,
+                                                            dmz_hip_expiry_result *__restrict__ out,
+                                                            DmzExpiryStage *__restrict__ stage) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n) return;
+  __shared__ SegLds L;
+  int ns;
+  {
+    int br[3];
+    long long su[3];
+    ns = expiry_stripes_body(f, lane, cards, card_stride, results, out, stage, *(StripeLds *)L.inter, br, su);
+    if (lane < 3) {
+      L.stripe_row[lane] = lane == 0 ? br[0] : (lane == 1 ? br[1] : br[2]);
+      L.stripe_sum[lane] = (int)(lane == 0 ? su[0] : (lane == 1 ? su[1] : su[2]));  // (a sum is the upper 25 bits of a 32-bit key)
+    }
+  }
+#pragma unroll 1
+  for (int st = 0; st < ns; st++) {
+    __syncthreads();  // (one wave: orders the LDS traffic of two stripes)
+    const int base = __builtin_amdgcn_readfirstlane(L.stripe_row[st]);
+    const long long sum = (long long)__builtin_amdgcn_readfirstlane(L.stripe_sum[st]);
+    // (the lane index is made opaque per stripe: with it loop-invariant the compiler hoists every lane-derived constant of the
+    // body -- column keys, lane masks, addresses -- out of the stripe loop and keeps them alive across it: 60 bytes of scratch)
+    int lane_st = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane_st));
+    expiry_seg_stripe(L, wts, xw, cards + (size_t)blockIdx.x * card_stride, n,
+                      __builtin_amdgcn_readfirstlane(results[blockIdx.x].vseg_y_offset) + kNumberHeight, base, sum,
+                      stage + (size_t)blockIdx.x * 3 + st, lane_st);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Expiry digit CNN (applyc_bf4dd6c8) for up to four 16x11 inputs resident in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -2244,11 +2311,17 @@ void dmz_launch_expiry(hipStream_t s, const float *weights, const float *xw, con
                        const uint8_t *cards, size_t card_stride, int n, const dmz_hip_frame_result *results,
                        DmzExpiryStage *stage, dmz_hip_expiry_result *out, hipEvent_t mid, int conv_mode, int phases) {
   if (phases & 1) {
+#if DMZ_XSEG_FUSED
+    DMZ_REPEAT(xseg)
+    hipLaunchKernelGGL(k_expiry_seg_fused, dim3((unsigned)n), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
+                       out, stage);
+#else
     DMZ_REPEAT(stripes)
     hipLaunchKernelGGL(k_expiry_stripes, dim3((unsigned)n), dim3(64), 0, s, cards, card_stride, n, results, out, stage);
     DMZ_REPEAT(xseg)
     hipLaunchKernelGGL(k_expiry_seg, dim3((unsigned)n * 3), dim3(64), DMZ_LDS_PAD, s, weights, xw, cards, card_stride, n, results,
                        out, stage);
+#endif
   }
   if (mid) (void)hipEventRecord(mid, s);
   if (!(phases & 2)) return;
