@@ -319,7 +319,7 @@ def test_eigen_flavour_gap_report(oracle, reference, orc):
     with its SSE2 packet paths: eigen.h defines no EIGEN_DONT_VECTORIZE) from the -DEIGEN_DONT_VECTORIZE flavour that the
     oracle restates and the device reproduces bit for bit?  Per corpus frame: the float[9] of llcv_calc_persp_transform
     (cv/warp.cpp:34-125, float Householder QR of an ill-conditioned 8 x 8) from both builds on the oracle's corners, each
-    pushed through the oracle's warp and scan.  DESIGN.md section 3 quotes the printed figures."""
+    pushed through the oracle's warp and scan.  DESIGN_LOG.md (parity section) quotes the printed figures."""
     import os
     if not orc.Reference.available("_vec"):
         pytest.skip("oracle/_ref/libdmzref_vec.so not built (make -C oracle ref, build container only)")

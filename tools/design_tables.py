@@ -40,6 +40,21 @@ META = {
 }
 
 
+# stage -> (floor of the formulation in VALU instructions per frame or None = "the measured count" for the data-dependent list /
+# MFMA-paced kernels, the exact-semantics requirement that sets it)
+CEILING = {
+    "detect": (36000, "int16-saturating Sobel-7 on `v_dot4_u32_u8` + binomial cascades (22 per wave-step), per-pixel NMS branches as the reference takes them, LDS-atomic Hough votes that serialise per shared counter"),
+    "geometry": (None, "-"),
+    "warp": (39500, "cvWarpPerspective's fp64 association per pixel (6 fp64 for a filtered-exact coordinate pair: reciprocal by extrapolation + Newton, two fma) + 12 integer for the 5-bit bilinear blend from four byte taps; 3.7 per pixel of per-wave set-up"),
+    "vseg": (13000, "408-column row features with two wave reductions per row (float min / max / sum in the reference's order), exact bf16 operand splits for the hidden layer"),
+    "hseg": (4400, "428-term sequential float sums per candidate (bit-exact `hseg_score`), the reference's four passes"),
+    "digits": (7100, "5-tap cross gradient + exact 256-bin equalisation per digit; nine-tile max-pool and 160 tanh per wave on the CNN side"),
+    "expiry_seg": (None, "data-dependent list logic in the reference's visiting order (incl. the `std::sort` tie order on 19 % of the stripes); round 6 removed the work that was not needed (lazy trimming)"),
+    "expiry_cat": (None, "MFMA-paced: operand builds (24 per conv1 tile) and epilogues (56 per tile) around f16 x 3 products that keep 1e-5"),
+}
+ISSUE_CEILING = 256 * 4 * 2.4e9 / 4 * 0.966  # wave64 VALU instructions / s at the half-rate class's measured saturation
+
+
 def kernel_stats(tag):
     out = {}
     path = os.path.join(ROOT, "profiles", "%s_kernel_stats_batch65536.csv" % tag)
@@ -102,15 +117,42 @@ def main():
         if floor != "-":
             L.append("* `%s`: %s" % (k, floor))
     text = "\n".join(L) + "\n"
-    if "--write" in sys.argv:
-        p = os.path.join(ROOT, "DESIGN.md")
-        s = open(p).read()
-        a, z = "<!-- GENERATED:kernel-tables (tools/design_tables.py) -->\n", "<!-- /GENERATED:kernel-tables -->"
+    # the ceiling table (DESIGN.md section 0 and README.md): measured instructions, floor of the formulation, what sets it
+    C = ["Generated by `tools/design_tables.py` from `profiles/%s_*`.\n" % tag,
+         "| stage | VALU instructions / frame (PMC) | floor of the formulation | ms at the issue ceiling (measured count; 65 536 frames) | measured ms | what exact semantics set the floor |",
+         "|---|---|---|---|---|---|"]
+    tm = tf = 0.0
+    for stage in bench.STAGE_KERNELS:
+        if stage not in b["stages"]:
+            continue
+        sv = bench.stage_valu(valu, stage) or 0.0
+        fl, why = CEILING[stage]
+        tm += sv
+        tf += fl if fl is not None else sv
+        C.append("| %s | %d | %s | %.2f | %.2f | %s |" % (stage, sv, ("%d" % fl) if fl is not None else "(= measured)",
+                                                        sv * 65536 / ISSUE_CEILING * 1e3, b["stages"][stage]["ms_per_step"], why))
+    C.append("| **pipeline** | **%d** | **%d** | **%.2f** | **%.2f** | at the ceiling of %.2e instructions/s: **%.2f M frames/s** with the measured counts, **%.2f M** "
+             "with every kernel at its floor = %.2f of the HBM roof (the contract's 0.50 = 9.4 M frames/s needs <= %d instructions per frame) |"
+             % (tm, tf, tm * 65536 / ISSUE_CEILING * 1e3, tot_ms, ISSUE_CEILING, ISSUE_CEILING / tm / 1e6, ISSUE_CEILING / tf / 1e6,
+                ISSUE_CEILING / tf * b["config"]["algorithmic_bytes_per_unit"] / 8e12, ISSUE_CEILING / 9.4e6))
+    ctext = "\n".join(C) + "\n"
+
+    def put(path, a, z, body):
+        s = open(path).read()
+        if a not in s:
+            return False
         i, j = s.index(a) + len(a), s.index(z)
-        open(p, "w").write(s[:i] + text + s[j:])
-        print("DESIGN.md updated from profiles/%s_*" % tag)
+        open(path, "w").write(s[:i] + body + s[j:])
+        return True
+
+    if "--write" in sys.argv:
+        put(os.path.join(ROOT, "DESIGN.md"), "<!-- GENERATED:kernel-tables (tools/design_tables.py) -->\n", "<!-- /GENERATED:kernel-tables -->", text)
+        for f in ("DESIGN.md", "README.md"):
+            put(os.path.join(ROOT, f), "<!-- GENERATED:ceiling-table (tools/design_tables.py) -->\n", "<!-- /GENERATED:ceiling-table -->", ctext)
+        print("DESIGN.md / README.md updated from profiles/%s_*" % tag)
     else:
         print(text)
+        print(ctext)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 """Developer stress test (GPU box): two contexts on ONE GPU, each driven by its own thread -- context A rectifies the same
 frames again and again (dmz_hip_transform_batch: k_homography + k_warp) while context B keeps the expiry CNN running
 (dmz_hip_scan_expiry_batch).  Every pass of A is compared with its first: the transient fault round 5 found in k_homography
-beside another queue's kernels would show as cards that move.  usage: two_context_stress.py [frames] [passes]
+beside another queue's kernels (DESIGN_LOG.md, round 5) would show as cards that move.  usage: two_context_stress.py [frames] [passes]
 (DMZ_HIP_LIB selects a library variant, e.g. one built with -DDMZ_HOMOGRAPHY_NOCHECK)"""
 import hashlib
 import os
