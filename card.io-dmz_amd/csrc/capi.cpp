@@ -1198,6 +1198,82 @@ int dmz_hip_best_n_hseg_batch(dmz_hip_context *ctx, const uint8_t *cards, size_t
   return DMZ_HIP_OK;
 }
 
+#ifdef DMZ_DEV_PIPE_CHUNKS
+// DEVELOPER SCHEDULE, compiled only with -DDMZ_DEV_PIPE_CHUNKS (tools/dev/homography_fault.sh): frame chunks of the WHOLE
+// pipeline in flight.  The main queue walks detect -> geometry -> warp -> vseg chunk by chunk; behind a chunk's vseg its scan
+// chains leave for three auxiliary queues (stripes + segmentation | hseg + digit models | the expiry CNN, which needs both)
+// and run beside the NEXT chunk's detect / homography / warp.  Round 5 measured it (-1 % at best: rejected as a schedule,
+// profiles/r5_pipe_chunks_ab.log) and found that it is the one queue pattern under which k_homography's transient fault shows
+// (profiles/r5_homography_quarter_wave.log) -- which is what it is kept for.  Chunks: DMZ_HIP_PIPE_CHUNKS (2 .. 8).
+static int pipeline_chunks_dev(dmz_hip_context *ctx, const uint8_t *dy, size_t frame_stride, int row_stride, int width, int height,
+                               int n, int orientation, int options, uint8_t *dcards, size_t card_stride,
+                               dmz_hip_frame_result *dres, dmz_hip_expiry_result *dexp, int pchunks) {
+  static hipStream_t aux3 = nullptr;
+  static hipEvent_t ev_vseg[kMaxChunks] = {};
+  if (!aux3) {
+    if (hipStreamCreateWithFlags(&aux3, hipStreamNonBlocking) != hipSuccess) return fail(ctx, DMZ_HIP_ERUNTIME, "dev: aux3");
+    for (int i = 0; i < kMaxChunks; i++)
+      if (hipEventCreateWithFlags(&ev_vseg[i], hipEventDisableTiming) != hipSuccess) return fail(ctx, DMZ_HIP_ERUNTIME, "dev: events");
+  }
+  int rc;
+  // everything is sized for the whole batch up front: `ensure` must not reallocate between chunks
+  if ((rc = ensure(ctx, ctx->hits, sizeof(DmzBoxHit) * 4 * (size_t)n * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->mats, sizeof(DmzWarpMat) * (size_t)n))) return rc;
+  if ((rc = ensure(ctx, ctx->xstage, sizeof(DmzExpiryStage) * 3 * (size_t)n))) return rc;
+  if ((rc = ensure_patches(ctx, n))) return rc;
+#define PIPE_TRY(expr)                                                            \
+  do {                                                                            \
+    const hipError_t fe__ = (expr);                                               \
+    if (fe__ != hipSuccess) {                                                     \
+      (void)hipStreamSynchronize(ctx->aux_stream);                                \
+      (void)hipStreamSynchronize(ctx->aux2_stream);                               \
+      (void)hipStreamSynchronize(aux3);                                           \
+      return fail(ctx, DMZ_HIP_ERUNTIME, #expr, fe__);                            \
+    }                                                                             \
+  } while (0)
+  const int skipmask = getenv("DMZ_HIP_PIPE_SKIP") ? atoi(getenv("DMZ_HIP_PIPE_SKIP")) : 0;  // 1 seg, 2 hseg, 4 digits, 8 expiry CNN
+  for (int ck = 0; ck < pchunks; ck++) {
+    const int first = (int)((long long)n * ck / pchunks), cn = (int)((long long)n * (ck + 1) / pchunks) - first;
+    dmz_hip_frame_result *cres = dres + first;
+    uint8_t *ccards = dcards + (size_t)first * card_stride;
+    const uint8_t *cy = dy + (size_t)first * frame_stride;
+    DmzExpiryStage *cstage = (DmzExpiryStage *)ctx->xstage.p + (size_t)3 * first;
+    DmzBoxHit *hits = (DmzBoxHit *)ctx->hits.p + 4 * 3 * (size_t)first;
+    DmzWarpMat *mats = (DmzWarpMat *)ctx->mats.p + first;
+    PIPE_TRY(hipMemsetAsync(cres, 0, sizeof(dmz_hip_frame_result) * (size_t)cn, ctx->stream));
+    if (dmz_launch_detect(ctx->stream, cy, frame_stride, row_stride, cn, ctx->h_params[0], hits, nullptr))
+      return fail(ctx, DMZ_HIP_ERUNTIME, "detect launch failed");
+    dmz_launch_geometry(ctx->stream, cn, ctx->d_params, hits, 1, cres);
+    dmz_launch_homography(ctx->stream, cn, orientation, effective_options(ctx, options), cres, mats);
+    dmz_launch_warp(ctx->stream, cy, frame_stride, row_stride, width, height, cn, mats, ccards, card_stride);
+    dmz_launch_vseg(ctx->stream, ctx->d_weights, ctx->d_hidwt + dmzv::WFRAG, ccards, card_stride, cn, 1, cres);
+    PIPE_TRY(hipEventRecord(ev_vseg[ck], ctx->stream));
+    PIPE_TRY(hipStreamWaitEvent(ctx->aux_stream, ev_vseg[ck], 0));
+    if (!(skipmask & 1))
+      dmz_launch_expiry(ctx->aux_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
+                        dexp + first, nullptr, ctx->expiry_conv, 1);
+    PIPE_TRY(hipEventRecord(ctx->ev_seg[ck], ctx->aux_stream));
+    PIPE_TRY(hipStreamWaitEvent(aux3, ev_vseg[ck], 0));
+    if (!(skipmask & 2)) dmz_launch_hseg(aux3, ccards, card_stride, cn, cres);
+    if (!(skipmask & 4))
+      dmz_launch_digits(aux3, ctx->d_weights, ctx->d_hidwt, ccards, card_stride, cn, cres,
+                        (unsigned char *)ctx->patches.p + (size_t)first * dmz_digit_patch_bytes());
+    PIPE_TRY(hipEventRecord(ctx->ev_dig[ck], aux3));
+    PIPE_TRY(hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_seg[ck], 0));
+    PIPE_TRY(hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_dig[ck], 0));
+    if (!(skipmask & 8))
+      dmz_launch_expiry(ctx->aux2_stream, ctx->d_weights, ctx->d_xw, ctx->d_xtab, ccards, card_stride, cn, cres, cstage,
+                        dexp + first, nullptr, ctx->expiry_conv, 2);
+    PIPE_TRY(hipGetLastError());
+  }
+  // the third queue's last kernel waited for the two others' last kernels: one join
+  PIPE_TRY(hipEventRecord(ctx->ev_join, ctx->aux2_stream));
+  PIPE_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+#undef PIPE_TRY
+  return DMZ_HIP_OK;
+}
+#endif
+
 static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_stride, int row_stride,
                          int width, int height, int n, int orientation, int options, uint8_t *cards,
                          size_t card_stride, dmz_hip_frame_result *results, dmz_hip_expiry_result *expiry,
@@ -1235,6 +1311,20 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
       dexp = (dmz_hip_expiry_result *)ctx->stage_exp.p;
     }
   }
+  bool chunks_done = false;  // (developer schedule, below)
+#ifdef DMZ_DEV_PIPE_CHUNKS
+  {
+    const char *e = getenv("DMZ_HIP_PIPE_CHUNKS");
+    const int pc = e ? atoi(e) : 1;
+    if (with_expiry && ctx->overlap && !ctx->profiling && pc > 1 && pc <= kMaxChunks && n >= 2048 * pc) {
+      if ((rc = pipeline_chunks_dev(ctx, (const uint8_t *)dy, frame_stride, row_stride, width, height, n, orientation, options,
+                                    dcards, card_stride, dres, dexp, pc)))
+        return rc;
+      chunks_done = true;
+    }
+  }
+#endif
+  if (!chunks_done) {
   if ((rc = run_detect(ctx, (const uint8_t *)dy, frame_stride, row_stride, nullptr, nullptr, 0, 0, n, dres)))
     return rc;
   if ((rc = run_transform(ctx, (const uint8_t *)dy, frame_stride, row_stride, width, height, n,
@@ -1296,6 +1386,7 @@ static int pipeline_impl(dmz_hip_context *ctx, const uint8_t *y, size_t frame_st
     FORK_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
 #undef FORK_TRY
   }
+  }  // !chunks_done
   if (with_expiry) {
     if (!exp_dev)
       HIP_TRY(ctx, hipMemcpyAsync(expiry, dexp, sizeof(dmz_hip_expiry_result) * (size_t)n, hipMemcpyDeviceToHost,

@@ -186,6 +186,9 @@ __device__ bool parametric_intersect(float rho1, float c1, float s1, float rho2,
   return true;
 }
 
+#ifdef DMZ_DEV_SELFCHECK
+__device__ unsigned long long g_dev_selfcheck_geom[2];  // frames with four edges evaluated twice, frames whose corners differed
+#endif
 __global__ __launch_bounds__(64) void k_geometry(int n, const DmzDetectParams *__restrict__ params,
                            const DmzBoxHit *__restrict__ hits, int nplanes,
                            dmz_hip_frame_result *__restrict__ results) {
@@ -228,6 +231,24 @@ __global__ __launch_bounds__(64) void k_geometry(int n, const DmzDetectParams *_
     const bool d = parametric_intersect(rho[2], ct[2], st[2], rho[3], ct[3], st[3], &cx[3], &cy[3]);
     all = a && b && c && d;
   }
+#ifdef DMZ_DEV_SELFCHECK  /* developer probe (tools/dev/homography_fault.sh selfcheck): the intersections computed twice and compared */
+  if (found[0] && found[1] && found[2] && found[3]) {
+    float r2[4], c2[4], s2[4], x2[4] = {0, 0, 0, 0}, y2[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 4; e++) {
+      r2[e] = rho[e], c2[e] = ct[e], s2[e] = st[e];
+      asm volatile("" : "+v"(r2[e]), "+v"(c2[e]), "+v"(s2[e]));
+    }
+    (void)parametric_intersect(r2[0], c2[0], s2[0], r2[1], c2[1], s2[1], &x2[0], &y2[0]);
+    (void)parametric_intersect(r2[2], c2[2], s2[2], r2[1], c2[1], s2[1], &x2[1], &y2[1]);
+    (void)parametric_intersect(r2[0], c2[0], s2[0], r2[3], c2[3], s2[3], &x2[2], &y2[2]);
+    (void)parametric_intersect(r2[2], c2[2], s2[2], r2[3], c2[3], s2[3], &x2[3], &y2[3]);
+    bool same = true;
+    for (int i = 0; i < 4; i++)
+      same = same && __float_as_uint(x2[i]) == __float_as_uint(cx[i]) && __float_as_uint(y2[i]) == __float_as_uint(cy[i]);
+    atomicAdd(&g_dev_selfcheck_geom[0], 1ull);
+    if (!same) atomicAdd(&g_dev_selfcheck_geom[1], 1ull);
+  }
+#endif
   for (int i = 0; i < 4; i++) {
     res->corners[2 * i] = cx[i];
     res->corners[2 * i + 1] = cy[i];
@@ -348,6 +369,13 @@ __global__ __launch_bounds__(64) void k_mats_from_float(int n, const float *__re
 }
 
 }  // namespace
+
+#ifdef DMZ_DEV_SELFCHECK
+extern "C" void dmz_dbg_selfcheck_geom(unsigned long long *out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dev_selfcheck_geom), sizeof(unsigned long long) * 2);
+}
+#endif
 
 void dmz_launch_geometry(hipStream_t s, int n, const DmzDetectParams *params, const DmzBoxHit *hits,
                          int nplanes, dmz_hip_frame_result *results) {

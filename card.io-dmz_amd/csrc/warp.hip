@@ -142,6 +142,9 @@ struct RowXYW {
 
 static_assert(kTiles == DMZ_WARP_STRIPS, "strip count");
 
+#ifdef DMZ_DEV_SELFCHECK
+__device__ unsigned long long g_dev_selfcheck_warp[2];  // windows evaluated twice, pairs that differed
+#endif
 // One thread per (frame, strip): the strip's source window from its four corner pixels.
 __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int aligned,
                                                        DmzWarpMat *__restrict__ mats) {
@@ -149,12 +152,19 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
   if (i >= n * kTiles) return;
   const int frame = i / kTiles, tile = i - frame * kTiles;
   const DmzWarpMat &wm = mats[frame];
+#ifdef DMZ_DEV_SELFCHECK  /* developer probe (tools/dev/homography_fault.sh selfcheck): the strip's window computed twice and compared */
+  DmzWarpWin w_first = {0, 0, 0, 0, 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+  for (int pass = 0; pass < 2; pass++) {
+#endif
   DmzWarpWin w = {0, 0, 0, 0, 0., 0., 0., 0., 0., 0., 0., 0., 0.};
   if (wm.valid) {
     const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
     const int x = tx * TW, y0 = ty * TH;
-    const double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
-                 M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
+    double M0 = wm.m[0], M1 = wm.m[1], M2 = wm.m[2], M3 = wm.m[3], M4 = wm.m[4], M5 = wm.m[5],
+           M6 = wm.m[6], M7 = wm.m[7], M8 = wm.m[8];
+#ifdef DMZ_DEV_SELFCHECK
+    asm volatile("" : "+v"(M0), "+v"(M1), "+v"(M2), "+v"(M3), "+v"(M4), "+v"(M5), "+v"(M6), "+v"(M7), "+v"(M8));
+#endif
     const double sW = M7 * 0.03125, ax = M1 / sW, ay = M4 / sW;
     if (tile == 0) {  // (frame-uniform)
       mats[frame].sw = sW;
@@ -226,7 +236,23 @@ __global__ __launch_bounds__(256) void k_warp_windows(int n, int sw, int sh, int
     w.ry0 = M3 * x + M4 * y0 + M5;
     w.rw0s = (M6 * x + M7 * y0 + M8) * 0.03125;
   }
+#ifdef DMZ_DEV_SELFCHECK
+  if (pass == 0) {
+    w_first = w;
+    continue;
+  }
+  {
+    const unsigned *a = (const unsigned *)&w, *b = (const unsigned *)&w_first;
+    bool same = true;
+    for (int i = 0; i < (int)(sizeof(DmzWarpWin) / 4); i++) same = same && a[i] == b[i];
+    atomicAdd(&g_dev_selfcheck_warp[0], 1ull);
+    if (!same) atomicAdd(&g_dev_selfcheck_warp[1], 1ull);
+  }
+#endif
   mats[frame].win[tile] = w;
+#ifdef DMZ_DEV_SELFCHECK
+  }
+#endif
 }
 
 __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ planes, size_t frame_stride,
@@ -634,6 +660,13 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
 }
 
 }  // namespace
+
+#ifdef DMZ_DEV_SELFCHECK
+extern "C" void dmz_dbg_selfcheck_warp(unsigned long long *out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dev_selfcheck_warp), sizeof(unsigned long long) * 2);
+}
+#endif
 
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,

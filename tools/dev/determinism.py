@@ -55,3 +55,10 @@ for r in range(reps):
                     d = c0 != c1
                     print("    frame %d: card bytes that differ from the first run's: %d (rows %s)" % (f, int(d.sum()), np.nonzero(d.any(1))[0][:6]))
 print("[%s] %d runs of %d frames compared, %d with differences" % (tag, reps, B, events))
+# a library built with -DDMZ_DEV_SELFCHECK (tools/dev/homography_fault.sh selfcheck) counts double evaluations that disagreed
+import ctypes
+for name, what in (("dmz_dbg_selfcheck_geom", "k_geometry corner sets"), ("dmz_dbg_selfcheck_warp", "k_warp_windows strip windows")):
+    if hasattr(ctx.lib, name):
+        out = (ctypes.c_ulonglong * 2)()
+        getattr(ctx.lib, name)(out)
+        print("[%s] %s evaluated twice: %d, differed: %d" % (tag, what, out[0], out[1]))
