@@ -60,8 +60,16 @@ __device__ __forceinline__ float eigen_redux_n(const float (&x)[7], int n) {
   }
 }
 
+// (developer probe, -DDMZ_DEV_HTRACE: `tr` receives a hash of the matrix state after each of the eight Householder steps, of
+// Q^T b and of the solution -- which step two evaluations first disagree at; nullptr in every product build)
+__device__ __forceinline__ unsigned htrace_hash(const float *v, int n) {
+  unsigned h = 0x9E3779B9u;
+#pragma unroll
+  for (int i = 0; i < n; i++) h = ((h << 5) | (h >> 27)) ^ __float_as_uint(v[i]);
+  return h;
+}
 template <bool SSE>
-__device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
+__device__ __forceinline__ void householder_qr_solve8(float *a, float *b, unsigned *tr = nullptr) {
   float hcoef[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -105,6 +113,7 @@ __device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
         for (int i = 1; i < rem; i++) QA(k + i, col) = QA(k + i, col) - (tau * QA(k + i, k)) * tmp;
       }
     }
+    if (tr) tr[k] = __float_as_uint(beta) ^ ((__float_as_uint(tau) << 13) | (__float_as_uint(tau) >> 19));  // (pivot and coefficient of the step)
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -123,16 +132,18 @@ __device__ __forceinline__ void householder_qr_solve8(float *a, float *b) {
       for (int i = 1; i < rem; i++) b[k + i] = b[k + i] - (tau * QA(k + i, k)) * tmp;
     }
   }
+  if (tr) tr[8] = htrace_hash(b, 8);
 #pragma unroll
   for (int i = 7; i >= 0; i--) {
     b[i] = b[i] / QA(i, i);
 #pragma unroll
     for (int r = 0; r < i; r++) b[r] = b[r] - b[i] * QA(r, i);
   }
+  if (tr) tr[9] = htrace_hash(b, 8);
 }
 
 template <bool SSE>
-__device__ __forceinline__ void calc_persp_transform(const float *sp, const float *dp, float *m) {
+__device__ __forceinline__ void calc_persp_transform(const float *sp, const float *dp, float *m, unsigned *tr = nullptr) {
   float a[64], b[8];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -145,7 +156,7 @@ __device__ __forceinline__ void calc_persp_transform(const float *sp, const floa
     b[i] = dx;
     b[i + 4] = dy;
   }
-  householder_qr_solve8<SSE>(a, b);
+  householder_qr_solve8<SSE>(a, b, tr);
   m[0] = b[0]; m[1] = b[1]; m[2] = b[2];
   m[3] = b[3]; m[4] = b[4]; m[5] = b[5];
   m[6] = b[6]; m[7] = b[7]; m[8] = 1.0f;
@@ -257,6 +268,9 @@ __global__ __launch_bounds__(64) void k_geometry(int n, const DmzDetectParams *_
   res->flags = 0;
 }
 
+#ifndef DMZ_HOMOGRAPHY_PAD256  /* developer switch (tools/dev/homography_fault.sh nocheck / wait run with 0: the 162-register kernel of round 5) */
+#define DMZ_HOMOGRAPHY_PAD256 1
+#endif
 // calc_persp_transform, evaluated again until two consecutive results agree bit for bit (at most six times); false = they
 // never did.  Round 5 measured why: with another queue's kernels (the expiry CNN of a previous frame chunk) in flight beside
 // k_homography, about once per 65 536 frames one quarter-wave (always lanes 48..63) came out of this register-to-register
@@ -264,8 +278,55 @@ __global__ __launch_bounds__(64) void k_geometry(int n, const DmzDetectParams *_
 // (DESIGN_LOG.md "transient fault in k_homography", profiles/r5_homography_quarter_wave.log; cause not established).  The
 // library's own pipeline never runs these kernels beside another one of the same context, a second context on the same GPU
 // may: 40 us per 65 536 frames buy the check.
+#ifdef DMZ_DEV_HCANARY  /* tools/dev/homography_fault.sh canary: registers the kernel never uses hold a pattern from its first to its last instruction */
+__device__ unsigned g_hcanary[256][4];  // [event][frame of lane 0, register, changed lanes lo, hi]
+__device__ unsigned g_hcanary_n;
+#define HCANARY_SET(R) asm volatile("v_mov_b32 v" #R ", %0" ::"v"(0x5A5A0000u + R) : "v" #R);
+#define HCANARY_CHK(R)                                                                                       \
+  {                                                                                                          \
+    unsigned long long cm_;                                                                                  \
+    asm volatile("v_cmp_ne_u32 %0, v" #R ", %1" : "=s"(cm_) : "v"(0x5A5A0000u + R) : "v" #R);                \
+    if (cm_ && threadIdx.x == 0) {                                                                           \
+      const unsigned e_ = atomicAdd(&g_hcanary_n, 1u);                                                       \
+      if (e_ < 256u) g_hcanary[e_][0] = blockIdx.x * 64u, g_hcanary[e_][1] = R, g_hcanary[e_][2] = (unsigned)cm_, g_hcanary[e_][3] = (unsigned)(cm_ >> 32); \
+    }                                                                                                        \
+  }
+#define HCANARY_ALL(F) F(164) F(165) F(166) F(167) F(168) F(169) F(170) F(171) F(172) F(173) F(174) F(175) F(176) F(177) F(178) F(179) \
+  F(180) F(181) F(182) F(183) F(184) F(185) F(186) F(187) F(188) F(189) F(190) F(191)
+#endif
+#ifdef DMZ_DEV_HTRACE  /* tools/dev/homography_fault.sh trace: two traced evaluations; a pair that disagrees is dumped */
+__device__ unsigned g_htrace[64][40];  // [event][frame, 10 + 10 step hashes, 9 + 9 matrix bits, lane]
+__device__ unsigned g_htrace_n;
+#endif
 template <bool SSE>
-__device__ __forceinline__ bool persp_checked(const float *sp, const float *dp, float *m) {
+__device__ __forceinline__ bool persp_checked(const float *sp, const float *dp, float *m, int frame = -1) {
+#ifdef DMZ_DEV_HTRACE
+  {
+    unsigned t1[10], t2[10];
+    float m1[9], sp2[8];
+    calc_persp_transform<SSE>(sp, dp, m1, t1);
+    // (the second evaluation starts when the first has finished: its inputs are tied to the first one's last hash -- interleaved,
+    // the two took 437 registers and the kernel no longer shared a SIMD with what makes it fault)
+    for (int i = 0; i < 8; i++) {
+      sp2[i] = sp[i];
+      asm volatile("" : "+v"(sp2[i]), "+v"(t1[9]), "+v"(m1[i]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    calc_persp_transform<SSE>(sp2, dp, m, t2);
+    bool same = true;
+    for (int i = 0; i < 9; i++) same = same && __float_as_uint(m1[i]) == __float_as_uint(m[i]);
+    if (!same) {
+      const unsigned e = atomicAdd(&g_htrace_n, 1u);
+      if (e < 64u) {
+        g_htrace[e][0] = (unsigned)frame;
+        for (int i = 0; i < 10; i++) g_htrace[e][1 + i] = t1[i], g_htrace[e][11 + i] = t2[i];
+        for (int i = 0; i < 9; i++) g_htrace[e][21 + i] = __float_as_uint(m1[i]), g_htrace[e][30 + i] = __float_as_uint(m[i]);
+        g_htrace[e][39] = threadIdx.x;
+      }
+    }
+    return true;  // (the second evaluation is used, as the shipped kernel's first repeat would)
+  }
+#endif
   calc_persp_transform<SSE>(sp, dp, m);
 #ifdef DMZ_HOMOGRAPHY_NOCHECK  /* developer switch (tools/dev/two_context_stress.py): the single evaluation of rounds 1 - 4 */
   return true;
@@ -293,6 +354,9 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
                              dmz_hip_frame_result *__restrict__ results,
                              DmzWarpMat *__restrict__ mats) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef DMZ_DEV_HCANARY
+  HCANARY_ALL(HCANARY_SET)
+#endif
   if (f >= n) return;
   dmz_hip_frame_result *res = results + f;
   const bool all = res->found_all != 0;
@@ -323,10 +387,30 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
       sp[2 * i] = px;
       sp[2 * i + 1] = py;
     }
+#ifdef DMZ_DEV_HWAIT  /* developer probe (tools/dev/homography_fault.sh): every load of the kernel has landed, and then some, before the computation starts */
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_sleep 16" ::: "memory");
+    for (int i = 0; i < 8; i++) asm volatile("" : "+v"(sp[i]));
+#endif
+#ifdef DMZ_DEV_HPADN  /* developer probe: claim registers up to v<DMZ_DEV_HPADN> (tools/dev/homography_fault.sh padn <N>) */
+#define DMZ_STR2(x) #x
+#define DMZ_STR(x) DMZ_STR2(x)
+    asm volatile("v_mov_b32 v" DMZ_STR(DMZ_DEV_HPADN) ", 0" ::: "v" DMZ_STR(DMZ_DEV_HPADN));
+#endif
+#if DMZ_HOMOGRAPHY_PAD256
+    // Round 6: the kernel claims a 256-register allocation.  The transient fault of round 5 does NOT depend on this kernel's
+    // instruction stream: the same stream with every load landed and slept on (-DDMZ_DEV_HWAIT) faults as before (8 events in
+    // 24 chunked passes of 65 536 frames, as the plain single evaluation), while the same stream with this one extra register
+    // write -- 162 -> 256 registers, so that at most one other large wave shares its SIMD's register file instead of two -- did
+    // not fault once in 24 passes; neither did the traced build (437 registers).  k_geometry and k_warp_windows (the same
+    // division sequences, 40 / 62 registers) evaluated twice under the same load: 0 of 23 million pairs differ.  What decides is
+    // what shares the register file, not what the wave executes (profiles/r6_homography_fault_probes.log).  The self-check
+    // below stays: it costs 40 us per 65 536 frames and is what makes a recurrence visible (DMZ_HIP_FLAG_FAULT).
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
     const float rw = (float)(DMZ_CARD_WIDTH - 1), rh = (float)(DMZ_CARD_HEIGHT - 1);
     dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f + rw; dp[3] = 0.0f;
     dp[4] = 0.0f; dp[5] = 0.0f + rh; dp[6] = 0.0f + rw; dp[7] = 0.0f + rh;
-    if (persp_checked<SSE>(sp, dp, m)) {
+    if (persp_checked<SSE>(sp, dp, m, f)) {
       invert3x3(m, &wm);
       res->flags = (res->flags & ~(DMZ_HIP_FLAG_WARPED | DMZ_HIP_FLAG_FAULT)) | DMZ_HIP_FLAG_WARPED;
     } else {
@@ -339,6 +423,9 @@ __global__ __launch_bounds__(64) void k_homography(int n, int orientation, int o
     res->flags = res->flags & ~DMZ_HIP_FLAG_WARPED;
   }
   dmz_store_mat_head(mats + f, wm);
+#ifdef DMZ_DEV_HCANARY
+  HCANARY_ALL(HCANARY_CHK)
+#endif
 }
 
 template <bool SSE>
@@ -351,6 +438,9 @@ __global__ __launch_bounds__(64) void k_persp(int n, const float *__restrict__ s
     sp[i] = src_pts[f * 8 + i];
     dp[i] = dst_pts[f * 8 + i];
   }
+#if DMZ_HOMOGRAPHY_PAD256
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");  // (as k_homography)
+#endif
   // (no flag travels with a bare matrix: a self-check that never settles returns NaNs, not a plausible wrong homography)
   const bool ok = persp_checked<SSE>(sp, dp, m);
   for (int i = 0; i < 9; i++) m9[f * 9 + i] = ok ? m[i] : __uint_as_float(0x7FC00000u);
@@ -370,6 +460,24 @@ __global__ __launch_bounds__(64) void k_mats_from_float(int n, const float *__re
 
 }  // namespace
 
+#ifdef DMZ_DEV_HCANARY
+extern "C" int dmz_dbg_hcanary(unsigned *out /* 256 x 4 */) {
+  unsigned n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_hcanary_n), sizeof(n));
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hcanary), sizeof(unsigned) * 256 * 4);
+  return (int)n;
+}
+#endif
+#ifdef DMZ_DEV_HTRACE
+extern "C" int dmz_dbg_htrace(unsigned *out /* 64 x 40 */) {
+  unsigned n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_htrace_n), sizeof(n));
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_htrace), sizeof(unsigned) * 64 * 40);
+  return (int)n;
+}
+#endif
 #ifdef DMZ_DEV_SELFCHECK
 extern "C" void dmz_dbg_selfcheck_geom(unsigned long long *out) {
   (void)hipDeviceSynchronize();

@@ -62,3 +62,30 @@ for name, what in (("dmz_dbg_selfcheck_geom", "k_geometry corner sets"), ("dmz_d
         out = (ctypes.c_ulonglong * 2)()
         getattr(ctx.lib, name)(out)
         print("[%s] %s evaluated twice: %d, differed: %d" % (tag, what, out[0], out[1]))
+
+# a library built with -DDMZ_DEV_HTRACE (tools/dev/homography_fault.sh trace): k_homography evaluated twice with a hash of its
+# state after every Householder step; for every pair that disagreed, the first step whose hashes differ
+if hasattr(ctx.lib, "dmz_dbg_htrace"):
+    buf = (ctypes.c_uint * (64 * 40))()
+    nev = ctx.lib.dmz_dbg_htrace(buf)
+    ev = np.frombuffer(buf, np.uint32).reshape(64, 40)
+    names = ["pivot / coefficient of Householder step %d" % k for k in range(8)] + ["Q^T b", "back substitution"]
+    print("[%s] k_homography pairs that disagreed: %d" % (tag, nev))
+    for e in ev[:min(nev, 64)]:
+        t1, t2 = e[1:11], e[11:21]
+        d = np.nonzero(t1 != t2)[0]
+        m1, m2 = e[21:30].view(np.float32), e[30:39].view(np.float32)
+        print("    frame %d lane %d: first difference at %s (steps that differ: %s); matrix elements that differ: %s"
+              % (e[0], e[39] & 63, names[d[0]] if len(d) else "none of the traced states (the result only)", d.tolist(),
+                 np.nonzero(m1.view(np.uint32) != m2.view(np.uint32))[0].tolist()))
+
+# -DDMZ_DEV_HCANARY (tools/dev/homography_fault.sh canary): registers k_homography never uses held a pattern from its first to its
+# last instruction; every register found changed at the end, with the lanes that changed
+if hasattr(ctx.lib, "dmz_dbg_hcanary"):
+    buf = (ctypes.c_uint * (256 * 4))()
+    nev = ctx.lib.dmz_dbg_hcanary(buf)
+    ev = np.frombuffer(buf, np.uint32).reshape(256, 4)
+    print("[%s] k_homography canary registers found changed: %d" % (tag, nev))
+    for e in ev[:min(nev, 256)]:
+        mask = int(e[2]) | (int(e[3]) << 32)
+        print("    wave of frames %d..: v%d changed in lanes %s" % (e[0], e[1], [l for l in range(64) if (mask >> l) & 1]))
