@@ -205,6 +205,9 @@ int fill_box_params(dmz_hip_context *ctx, DmzBoxParams &bp, const int box[4], in
   int x1 = box[0] + box[2] > plane_w ? plane_w : box[0] + box[2];
   int y1 = box[1] + box[3] > plane_h ? plane_h : box[1] + box[3];
   bp.x = x0; bp.y = y0; bp.w = x1 - x0; bp.h = y1 - y0;
+#ifdef DMZ_DEV_HZ_LANES  /* developer probe (timing only, wrong edges): the top / bottom boxes narrowed to a whole number of 62-column waves */
+  if (!vertical && bp.w > DMZ_DEV_HZ_LANES) bp.w = DMZ_DEV_HZ_LANES;
+#endif
   if (bp.w < 8 || bp.h < 8) return fail(ctx, DMZ_HIP_EUNSUPPORTED, "detection box smaller than 8 px");
   // LDS layout of k_detect_walk (detect.hip): source tile | edge map | accumulator
   // The tile and the edge map live in "walk space": row = step along the short axis,

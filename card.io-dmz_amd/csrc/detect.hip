@@ -905,7 +905,11 @@ int launch_pair_nt(hipStream_t s, const uint8_t *planes, size_t frame_stride, in
   const int nt = a.nthreads > b.nthreads ? a.nthreads : b.nthreads;
   const int lds = a.lds_total > b.lds_total ? a.lds_total : b.lds_total;
   // the boxes of a 640 x 480 frame (28 steps x 389 lanes, 38 steps x 241 lanes): single-walk kernels
+#ifdef DMZ_DEV_HZ_LANES  /* developer probe (with capi.cpp's): what a top / bottom box of fewer waves costs */
+  constexpr int kSteps = VERT ? 38 : 28, kLanes = VERT ? 241 : DMZ_DEV_HZ_LANES, kNt = VERT ? 256 : 64 * ((DMZ_DEV_HZ_LANES + 61) / 62);
+#else
   constexpr int kSteps = VERT ? 38 : 28, kLanes = VERT ? 241 : 389, kNt = VERT ? 256 : 448;
+#endif
   auto compact = [](const DmzBoxParams &q) {  // a list of >= 1024 entries fits behind the tile, the map fits the tile
     return q.lds_red - q.lds_map >= 2048 && q.lanes * q.steps <= q.lds_map;
   };
