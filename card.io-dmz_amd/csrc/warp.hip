@@ -269,6 +269,9 @@ __global__ __launch_bounds__(kThreads) void k_warp(const uint8_t *__restrict__ p
   const int tile = (int)(logical - (unsigned int)frame * kTiles);
   if (frame >= n) return;
   const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
+#ifdef DMZ_DEV_WARP_SKIP_LAST  /* developer probe (timing only): the seventh strip column (44 of 64 lanes) is not produced */
+  if (tx == kTilesX - 1) return;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int x = tx * TW;   // OpenCV block origin in x
