@@ -274,6 +274,9 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
 #ifndef DMZ_XSEG_TIES  /* developer ablation (timing only, wrong ties): 0 = column tie-break, no watch; 1 = watch, never re-order */
 #define DMZ_XSEG_TIES 2
 #endif
+#ifndef DMZ_XSEG_NT_FAST  /* developer A/B: 0 = the normalise-and-threshold of a Scharr sample on v_rndne / v_cvt / v_cmp / v_cndmask (rounds 2 - 5) */
+#define DMZ_XSEG_NT_FAST 1
+#endif
 #ifndef DMZ_XSEG_FUSED  /* developer A/B: 1 = k_expiry_seg_fused, a wave per frame does the stripe search and then its stripes (round 6:
                            stage -0.07 ms, timed step unchanged: not the default; profiles/r6_expiry_fused_stripes_ab.log) */
 #define DMZ_XSEG_FUSED 0
@@ -394,8 +397,19 @@ __device__ __forceinline__ void strip_white_space_lanes(int mine, int &s, int &e
 
 // the value cvNormalize(255, CV_C) + cvThreshold(100, TOZERO) leave for a Scharr sample
 __device__ __forceinline__ int norm_thresh(int v, float scale) {
+#if DMZ_XSEG_NT_FAST
+  // Round 6: the same value on full-rate instructions.  x + 1.5 * 2^23 rounds x to the nearest integer, ties
+  // to even, for |x| < 2^22 -- exactly v_rndne_f32 + v_cvt_i32_f32 -- and leaves it in the sum's low mantissa bits; the
+  // threshold is a sign mask instead of a compare + select: multiply, add, three integer subtractions / shifts, an AND (19.6
+  // issue cycles per sample by profiles/r4_valu_table_gfx950.txt) where convert, multiply, round, convert, compare, select
+  // took 23.4.  Bit-exact by construction (no magic multiplier to prove).
+  const float y = (float)v * scale + 12582912.0f;
+  const int iv = __float_as_int(y) - 0x4B400000;
+  return iv & ((100 - iv) >> 31);
+#else
   const int iv = __float2int_rn((float)v * scale);
   return iv > 100 ? iv : 0;
+#endif
 }
 
 __device__ __forceinline__ float row16_sum(float x) {  // total of a 16-lane DPP row, in its lane 15
