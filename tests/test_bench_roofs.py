@@ -44,3 +44,18 @@ def test_no_fraction_above_one_in_this_rounds_bench_lines():
                 continue
             for path, v in _fracs(json.loads(line)):
                 assert v <= 1.0, (os.path.basename(f), path, v)
+
+
+def test_cpu_baseline_states_the_quota_and_the_unloaded_rate(tmp_path, monkeypatch):
+    """the CPU baseline starts min(affinity, cgroup quota) workers and says what it was given.  The quota
+    reader is exercised on a synthetic cgroup v2 file; the baseline itself on a one-second run."""
+    import bench
+    q, src = bench.cpu_quota()
+    assert q is None or (q > 0 and src)
+    r = bench.cpu_baseline(2, budget_s=0.5, frames_per_worker=4)  # configs[1] (detect only): the cheapest oracle leg
+    assert r["kind"] == "port" and r["cores"] >= 1 and r["cores"] <= r["cpu_affinity"]
+    assert r["single_process_frames_per_s"] > 0 and r["per_core"] > 0 and r["effective_cores"] > 0
+    assert "cpu_quota" in r and "one process per usable host core" in r["sample"]
+    # a worker's rate under load is within a factor of a few of the unloaded one unless the host throttles (then the record says
+    # how many cores' worth of CPU time the workers obtained)
+    assert r["per_effective_core"] > 0.2 * r["single_process_frames_per_s"]
