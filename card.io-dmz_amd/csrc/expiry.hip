@@ -281,12 +281,6 @@ __global__ __launch_bounds__(64) void k_expiry_stripes(const uint8_t *__restrict
                            stage -0.07 ms, timed step unchanged: not the default; profiles/r6_expiry_fused_stripes_ab.log) */
 #define DMZ_XSEG_FUSED 0
 #endif
-#ifndef DMZ_XSEG_LAZY  /* developer A/B: 0 = every regridded rect is trimmed (round 5) */
-#define DMZ_XSEG_LAZY 1
-#endif
-#ifndef DMZ_XSEG_ROWS2  /* developer A/B: 0 = round 5's horizontal pass (a dword per lane and row, column sums from LDS) */
-#define DMZ_XSEG_ROWS2 1
-#endif
 #ifndef DMZ_XSEG_FOLD  /* developer switch: 0 = the slash MLP always on Scharr samples */
 #define DMZ_XSEG_FOLD 1
 #endif
@@ -348,27 +342,6 @@ struct SegLds {
   int stripe_row[4], stripe_sum[4];  // the fused kernel's stripes (k_expiry_seg_fused): kept here, not in registers, across a stripe's body
 };
 static_assert(sizeof(SegLds) <= 13648, "twelve stripes per CU");
-
-// four |p[c+1] - p[c-1]| of dword d of a row (prev / cur / next = dwords d-1, d, d+1), column index
-// clamped at 0 and 427 (sobel.cpp:729-734), as bytes
-__device__ __forceinline__ uint32_t scharr_inter4(uint32_t prev, uint32_t cur, uint32_t next, int d) {
-  const uint32_t left = d > 0 ? __builtin_amdgcn_alignbyte(cur, prev, 3) : ((cur << 8) | (cur & 0xFFu));
-  const uint32_t right = d < 106 ? __builtin_amdgcn_alignbyte(next, cur, 1) : ((cur >> 8) | (cur & 0xFF000000u));
-  // |right - left| per byte on packed 16-bit halves: even bytes and odd bytes separately (v_pk_sub_i16,
-  // v_pk_max_i16 of the difference and its negation), then re-interleaved
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const s16x2 re = __builtin_bit_cast(s16x2, right & 0x00FF00FFu), le = __builtin_bit_cast(s16x2, left & 0x00FF00FFu);
-  const s16x2 ro = __builtin_bit_cast(s16x2, (right >> 8) & 0x00FF00FFu), lo = __builtin_bit_cast(s16x2, (left >> 8) & 0x00FF00FFu);
-  const s16x2 de = re - le, dod = ro - lo;
-  const s16x2 ae = __builtin_elementwise_max(de, -de), ao = __builtin_elementwise_max(dod, -dod);
-  return __builtin_bit_cast(uint32_t, ae) | (__builtin_bit_cast(uint32_t, ao) << 8);
-}
-
-// |Scharr dx| at window row k (image row base-3+k, k = 0..20) and column c; vmask = rows inside the ROI
-__device__ __forceinline__ int sob_at(const unsigned char *__restrict__ inter, unsigned vmask, int k, int c) {
-  const int a = inter[k * ISTRIDE + c], b = inter[(k + 1) * ISTRIDE + c], d = inter[(k + 2) * ISTRIDE + c];
-  return ((vmask >> k) & 1u) ? 3 * (a + d) + 10 * b : 0;
-}
 
 // strip_group_white_space (expiry_seg.cpp:101-129) on the index range [s, e) of a sum array
 __device__ __forceinline__ void strip_white_space(const int *__restrict__ sums, int &s, int &e) {
@@ -449,7 +422,6 @@ __device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__rest
     if (R >= y0 && R <= CH - 1) vmask |= 1u << k;
   }
 
-#if DMZ_XSEG_ROWS2
   // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766) AND the column sums
   // (456-486) in one go (round 6).  Lane l < 54 owns the dword PAIR (2 l, 2 l + 1) of every row: one 8-byte load per row, all
   // 23 in flight together; of the four neighbour dwords a pair needs, two are its own and two come from the adjacent lanes
@@ -547,86 +519,6 @@ __device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__rest
   XSEG_STOP(1, L.inter[lane])
   XS_TL(1)
   XSEG_STOP(2, L.u.colA[lane])
-#else
-  // ---- horizontal pass of rows base-4 .. base+18 (row index clamped to the ROI, sobel.cpp:765-766).
-  // Each dword of a row is loaded once (all 46 loads of a lane in flight together); the
-  // neighbouring dwords come from the adjacent lanes. ----
-  {
-    const int d0 = lane, d1 = lane + 64;
-    const bool has1 = d1 < 107;
-    uint32_t c0[IROWS], c1[IROWS];
-#pragma unroll
-    for (int t = 0; t < IROWS; t++) {
-      const int rowc = imin(imax(base - 4 + t, y0), CH - 1);
-      const uint32_t *row = (const uint32_t *)(card + (size_t)rowc * CW);
-      c0[t] = row[d0];
-      c1[t] = has1 ? row[d1] : 0u;
-    }
-#pragma unroll
-    for (int t = 0; t < IROWS; t++) {
-      // neighbours by DPP wave shifts (wave_shr:1 = lane - 1, wave_shl:1 = lane + 1) and readlane
-      const int i0 = (int)c0[t], i1 = (int)c1[t];
-      const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(i0, i0, 0x138, 0xf, 0xf, false);   // dword d0 - 1 (lane 0: unused)
-      const uint32_t n0s = (uint32_t)__builtin_amdgcn_update_dpp(i0, i0, 0x130, 0xf, 0xf, false);  // dword d0 + 1 for lanes < 63
-      const uint32_t first1 = (uint32_t)__builtin_amdgcn_readlane(i1, 0);                          // dword 64
-      const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane(i0, 63);                          // dword 63
-      const uint32_t p1s = (uint32_t)__builtin_amdgcn_update_dpp(i1, i1, 0x138, 0xf, 0xf, false);
-      const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(i1, i1, 0x130, 0xf, 0xf, false);   // dword d1 + 1 (lane 42: unused)
-      const uint32_t n0 = lane == 63 ? first1 : n0s;
-      const uint32_t p1 = lane == 0 ? last0 : p1s;
-      *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d0) = scharr_inter4(p0, c0[t], n0, d0);
-      if (has1) *(uint32_t *)(L.inter + t * ISTRIDE + 4 * d1) = scharr_inter4(p1, c1[t], n1, d1);
-    }
-  }
-  __syncthreads();
-  XS_TL(0)
-  XSEG_STOP(1, L.inter[lane])
-
-  // ---- column sums (456-486).  colA[c] = sum over window rows k = 3 .. 19 of the Scharr sample v_k (0 outside the ROI),
-  // colB the same over k = 2 .. 18; v_k = 3 inter[k] + 10 inter[k + 1] + 3 inter[k + 2], so both are WEIGHTED SUMS OF THE
-  // INTER ROWS with wave-uniform weights (<= 16) that fold the ROI mask in.  A dword's four columns travel as two packed
-  // pairs of 16-bit fields (even / odd bytes), one v_mad_u32_u24 per pair, row and sum; ten rows per accumulator keep a
-  // field below 2^16 (10 x 16 x 255).  Integer arithmetic throughout: the sums are exact. ----
-  {
-    unsigned ca[24], cb[24];  // uniform (scalar registers)
-#pragma unroll
-    for (int r = 2; r <= 21; r++) {
-      unsigned wa = 0u, wb = 0u;
-#pragma unroll
-      for (int t = 0; t < 3; t++) {  // inter row r is tap t of sample k = r - t (weights 3, 10, 3)
-        const int k = r - t;
-        const unsigned wt = t == 1 ? 10u : 3u, m = (vmask >> (k < 0 ? 0 : k)) & 1u;
-        if (k >= 3 && k <= 19) wa += wt * m;
-        if (k >= 2 && k <= 18) wb += wt * m;
-      }
-      ca[r] = wa, cb[r] = wb;
-    }
-    for (int d = lane; d < 107; d += 64) {
-      uint32_t aE[2] = {0u, 0u}, aO[2] = {0u, 0u}, bE[2] = {0u, 0u}, bO[2] = {0u, 0u};
-#pragma unroll
-      for (int r = 2; r <= 21; r++) {
-        const uint32_t w = *(const uint32_t *)(L.inter + r * ISTRIDE + 4 * d);
-        const uint32_t ev = w & 0x00FF00FFu, od = (w >> 8) & 0x00FF00FFu;  // columns (0, 2) and (1, 3) of the dword
-        const int g = r >= 12;
-        aE[g] = __umul24(ev, ca[r]) + aE[g];
-        aO[g] = __umul24(od, ca[r]) + aO[g];
-        bE[g] = __umul24(ev, cb[r]) + bE[g];
-        bO[g] = __umul24(od, cb[r]) + bO[g];
-      }
-      L.u.colA[4 * d + 0] = (int)((aE[0] & 0xffffu) + (aE[1] & 0xffffu));
-      L.u.colA[4 * d + 1] = (int)((aO[0] & 0xffffu) + (aO[1] & 0xffffu));
-      L.u.colA[4 * d + 2] = (int)((aE[0] >> 16) + (aE[1] >> 16));
-      L.u.colA[4 * d + 3] = (int)((aO[0] >> 16) + (aO[1] >> 16));
-      L.colB[4 * d + 0] = (int)((bE[0] & 0xffffu) + (bE[1] & 0xffffu));
-      L.colB[4 * d + 1] = (int)((bO[0] & 0xffffu) + (bO[1] & 0xffffu));
-      L.colB[4 * d + 2] = (int)((bE[0] >> 16) + (bE[1] >> 16));
-      L.colB[4 * d + 3] = (int)((bO[0] >> 16) + (bO[1] >> 16));
-    }
-  }
-  __syncthreads();
-  XS_TL(1)
-  XSEG_STOP(2, L.u.colA[lane])
-#endif
   // thresholds (expiry_seg.cpp:447-449, 488-494).  While the running total stays below 2^24 every
   // float addition of these integers is exact, so the float total equals the integer total whenever
   // that is < 2^24 (the common case); only beyond that the additions round and the reference's
@@ -1001,7 +893,6 @@ __device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__rest
     XS_TL(5)
     if (DMZ_XSEG_STOP == 6) continue;
 
-#if DMZ_XSEG_LAZY
     // ---- optimize_character_rects (231-339), round 6: LAZILY.  A rect is dropped for its position alone (:259-266) and
     // every rect is trimmed on its own, so the group's rect COUNT is known here, and the trimmed positions are needed of the
     // slash candidates only (the middle characters of the windows of five, :643) -- and, for a window whose middle character
@@ -1124,135 +1015,6 @@ __device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__rest
     const int k = b0 + lane / 21;
     optimize_batch(lane < 63 && k < ncand ? (int)L.u.b.cand[k] : -1);
   }
-#else
-    // ---- optimize_character_rects (231-339): three rects per pass, 21 lanes each.  Lane c of a
-    // slot owns column c of the 21-row window: one column of Scharr samples in registers serves
-    // the max, the normalise+threshold and the column sum; the row sums come from a transposed
-    // read of the thresholded tile (lane r = row r). ----
-    const int ciw = cw + 4, cih = 17 + 4;
-    int my_left = -1, my_top = 0;  // optimised rect `lane` (my_left < 0: dropped)
-    {
-      const int sl = lane / 21, c = lane - sl * 21;
-      unsigned char *tile = L.u.b.tile;  // [3][21][19]
-#ifdef DMZ_XSEG_TL
-      if (lane == 0 && (blockIdx.x & 1023) == 7) {
-        atomicAdd(&g_xs_tl[9], (unsigned long long)((re - rs + 2) / 3)), atomicAdd(&g_xs_tl[10], (unsigned long long)((re - rs + 3) / 4));
-        atomicAdd(&g_xs_tl[11], 1ull), atomicAdd(&g_xs_tl[12], ciw <= 16 ? 1ull : 0ull), atomicAdd(&g_xs_tl[13], (unsigned long long)(re - rs));
-        atomicAdd(&g_xs_tl[14], ciw <= 16 ? (unsigned long long)((re - rs + 2) / 3 - (re - rs + 3) / 4) : 0ull);
-      }
-#endif
-      for (int b0 = rs; b0 < re; b0 += 3) {
-        const int k = b0 + sl;
-        const bool have = sl < 3 && k < re;
-        const int rect_left = have ? L.u.b.rL[k] - 2 : 0;
-        const bool valid = have && !(rect_left < 0 || rect_left + ciw > CW || (g_top - 2) + cih > CH);
-        const bool col = valid && c < ciw;
-        int v[21];
-        int mx = 0;
-        {
-          // (idle lanes -- columns past the window, the slot-less lane 63 -- read column 0 and are zeroed once below: a
-          // predicated load per row was a v_mov, an exec save and an exec restore each)
-          int iv[IROWS];
-          const int rl = col ? rect_left + c : 0;
-#pragma unroll
-          for (int t = 0; t < IROWS; t++) iv[t] = (int)L.inter[t * ISTRIDE + rl];
-          if (vmask == 0x1FFFFFu) {  // (wave-uniform) the usual case: all 21 window rows inside the ROI, no per-row select
-#pragma unroll
-            for (int r = 0; r < 21; r++) {
-              v[r] = 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1];
-              mx = imax(mx, v[r]);
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 21; r++) {
-              v[r] = ((vmask >> r) & 1u) ? 3 * (iv[r] + iv[r + 2]) + 10 * iv[r + 1] : 0;
-              mx = imax(mx, v[r]);
-            }
-          }
-        }
-        const int sidx = sl * 24 + c;  // this lane's entry of the per-slot arrays
-        if (!col) {
-          mx = 0;
-#pragma unroll
-          for (int r = 0; r < 21; r++) v[r] = 0;
-        }
-        L.u.b.cm[sidx] = mx;
-        __syncthreads();
-        if (sl < 3) {
-#pragma unroll
-          for (int j = 0; j < 18; j++) mx = imax(mx, L.u.b.cm[sl * 24 + j]);
-        }
-        // cvNormalize's scale is (float)(255.0 / (double)max); for every integer max in [1, 32767] that
-        // equals the correctly rounded float quotient (checked exhaustively, tests/test_oracle_units.py)
-        const float scale = mx > 0 ? 255.0f / (float)mx : 0.0f;
-        int cs = 0;
-        if (sl < 3) {
-#pragma unroll
-          for (int r = 0; r < 21; r++) {
-            const int t = norm_thresh(v[r], scale);
-            cs += t;
-            if (c < 19) tile[(sl * 21 + r) * XT_PITCH + c] = t;
-          }
-        }
-        L.u.b.cm[sidx] = cs;
-        __syncthreads();
-        // column trimming (every lane of the slot replays it: uniform within the slot)
-        int lc = 0, rc = ciw - 1;
-        if (sl < 3)
-          for (int wv = ciw; wv > TW; wv--) {
-            if (L.u.b.cm[sl * 24 + lc] <= L.u.b.cm[sl * 24 + rc]) lc++;
-            else rc--;
-          }
-        int rsm = 0;
-        if (sl < 3) {  // lane c is row c here: the eleven bytes lc .. lc + 10 (= rc) of its row, from four aligned dwords
-          typedef const volatile __attribute__((address_space(3))) uint32_t *lds_vu32;  // (volatile: no merging into b64 / b128)
-          const lds_vu32 rowp = (lds_vu32)(tile + (sl * 21 + c) * XT_PITCH + (lc & ~3));
-          const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2], w3 = rowp[3];
-          const uint32_t sh = (uint32_t)(lc & 3);
-          rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), 0u, 0u);
-          rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), 0u, (uint32_t)rsm);
-          rsm = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w3, w2, sh) & 0x00FFFFFFu, 0u, (uint32_t)rsm);
-        }
-        __syncthreads();
-        L.u.b.cm[sidx] = rsm;  // row sums
-        __syncthreads();
-        int tr = 0;
-        if (sl < 3 && c == 0 && have) {
-          int brw = cih - 1;
-          for (int hv = cih; hv > TH; hv--) {
-            if (L.u.b.cm[sl * 24 + tr] <= L.u.b.cm[sl * 24 + brw]) tr++;
-            else brw--;
-          }
-        }
-        // the slot's result (held by its lane 0) goes to the lane that owns rect b0 + slot
-        const int out_left = valid ? rect_left + lc : -1, out_top = (g_top - 2) + tr;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int vl = __builtin_amdgcn_readlane(out_left, 21 * q), vt = __builtin_amdgcn_readlane(out_top, 21 * q);
-          if (lane == b0 + q && b0 + q < re) my_left = vl, my_top = vt;
-        }
-      }
-    }
-    const bool keep = lane >= rs && lane < re && my_left >= 0;
-    const unsigned long long kbal = __ballot(keep);
-    const int n2 = __popcll(kbal);
-    if (keep) {
-      const int pos = rbase + __popcll(kbal & lanemask_lt(lane));
-      if (pos < kMaxRects) {  // (always: see SegLds)
-        L.u.b.cLeft[pos] = my_left;
-        L.u.b.cTop[pos] = my_top;
-      }
-    }
-    // kMinimumExpiryStripCharacters (expiry_seg.cpp:617-623); the windows of five of this group: middle characters 2 .. n2 - 3
-    if (n2 >= 5 && DMZ_XSEG_STOP != 7 && rbase + n2 <= kMaxRects) {
-      if (lane >= 2 && lane < n2 - 2) L.u.b.cand[ncand + lane - 2] = (unsigned char)(rbase + lane);
-      ncand += n2 - 4;
-    }
-    rbase += n2;
-    __syncthreads();
-    XS_TL(6)
-  }
-#endif
   XS_TL(7)
   {
     // ---- slash search (643-674): character first+2 of every window of five, sixteen candidates
@@ -1411,7 +1173,6 @@ __device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__rest
                                ((unsigned)__builtin_amdgcn_readlane((int)hits, 31) << 4) |
                                ((unsigned)__builtin_amdgcn_readlane((int)hits, 47) << 8) |
                                ((unsigned)__builtin_amdgcn_readlane((int)hits, 63) << 12);
-#if DMZ_XSEG_LAZY
       if (hitmask) {
         // the other four characters of the windows with a slash: whatever is still pending is trimmed now (rect indices are
         // < 80: lane i looks at rects i and i + 64; the list goes where the regridded lefts were)
@@ -1435,7 +1196,6 @@ __device__ __forceinline__ void expiry_seg_stripe(SegLds &L, const float *__rest
           optimize_batch(lane < 63 && k < npend ? (int)L.u.b.rL[k] : -1);
         }
       }
-#endif
       for (int q = 0; q < nc; q++) {
         if (!((hitmask >> q) & 1u)) continue;
         if (lane == 0 && n_emitted < DMZ_HIP_EXPIRY_MAX_GROUPS) {
@@ -1492,7 +1252,8 @@ __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg(const float *
 // (~92 scattered 258-byte row pieces per card, a pass of its own over HBM) then wait beside eleven other waves' list logic, and
 // the 23 rows a stripe stages come back from the cache the search has just pulled them through.  expiry_seg stage 2.66 ->
 // 2.59 ms, the three-queue step 18.88 -> 18.91 ms (profiles/r6_expiry_fused_stripes_ab.log): the search's 13 k cycles of waiting
-// cost a 12-wave-per-CU kernel about what they cost a kernel of their own at 32 waves per CU.
+// cost a 12-wave-per-CU kernel about what they cost a kernel of their own at 32 waves per CU.  (Its 168 registers also lie in
+// the 161 .. 199 band in which k_homography lost quarter-waves beside two 160-register waves -- geometry.hip, DESIGN_LOG.md round 6.)
 static_assert(sizeof(StripeLds) <= IROWS * ISTRIDE, "the stripe search's arrays lie over the horizontal-pass bytes");
 __global__ __launch_bounds__(64, DMZ_XSEG_WAVES) void k_expiry_seg_fused(const float *__restrict__ wts, const float *__restrict__ xw,
                                                             const uint8_t *__restrict__ cards, size_t card_stride, int n,
