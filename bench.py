@@ -479,6 +479,7 @@ def main():
     # the context's communication queue) when librccl loads and the communicator comes up; the torch.distributed gather
     # (same ranges, same asynchrony) otherwise.  At N = 1 there is nothing to gather.
     use_capi = False
+    comm_init_stuck = False  # a helper thread is still inside ncclCommInitRank: leave through os._exit at the end
     capi_failure = None  # why the C-ABI gather is not the one that was timed (auto mode), for the JSON line
     root_dst = None
     if world > 1 and ctx is not None and args.gather in ("auto", "capi"):
@@ -494,24 +495,42 @@ def main():
         ok = torch.zeros(1, dtype=torch.int32, device=dev)
         if bool(have.item()):
             dist.broadcast_object_list(uid, src=0)
-            try:
-                ctx.comm_init(world, rank, uid[0])
+            # ncclCommInitRank is collective: a rank that cannot reach its peers would wait in it for ever, and so would the
+            # whole run.  It runs on a helper thread with a deadline; the ranks then agree over torch.distributed whether every
+            # communicator came up in time (a thread still stuck in the call is abandoned: the process exits through os._exit).
+            import threading
+            init_err = []
+
+            def _init():
+                try:
+                    ctx.comm_init(world, rank, uid[0])
+                except pkg.DmzHipError as e:
+                    init_err.append(str(e))
+
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("DMZ_BENCH_COMM_TIMEOUT_S", "120")))
+            if th.is_alive():
+                comm_init_stuck = True
+                print("bench.py: rank %d: ncclCommInitRank did not return in time" % rank, file=sys.stderr)
+            elif init_err:
+                print("bench.py: rank %d: C-ABI communicator failed (%s)" % (rank, init_err[0]), file=sys.stderr)
+            else:
                 ok += 1
-            except pkg.DmzHipError as e:
-                print("bench.py: rank %d: C-ABI communicator failed (%s)" % (rank, e), file=sys.stderr)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if not bool(ok.item()):
-                capi_failure = "ncclCommInitRank failed on a rank"
+                capi_failure = "ncclCommInitRank failed or did not return within its deadline on a rank"
         else:
             capi_failure = "librccl did not load on every rank"
         use_capi = bool(ok.item())
         if not use_capi:
             if args.gather == "capi":
                 sys.exit("bench.py: --gather capi: no RCCL communicator (%s)" % capi_failure)
-            try:
-                ctx.comm_destroy()
-            except pkg.DmzHipError:
-                pass
+            if not comm_init_stuck:
+                try:
+                    ctx.comm_destroy()
+                except pkg.DmzHipError:
+                    pass
         elif rank == 0:
             root_dst = [(torch.empty((world * B, 1024), dtype=torch.uint8, device=dev),
                          torch.empty((world * B, XB), dtype=torch.uint8, device=dev) if with_expiry else None)
@@ -874,6 +893,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if comm_init_stuck:
+        sys.stdout.flush()
+        os._exit(0)  # (a helper thread is parked inside librccl: no orderly teardown of this context)
     ctx.close()
 
 
