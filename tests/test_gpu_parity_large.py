@@ -234,7 +234,9 @@ def assert_parity(stats, n, min_expiry_frames=0, max_ties=2):
     assert stats["label_diff"] <= max(2, n // 2048) and stats["flag_diff"] <= max(2, n // 2048), stats
     # ... and so are proven near-ties of two segmentations: none in 3 x 131 072 corpus frames, one per ~450 fuzz frames
     # (garbage cards have flat vseg scores; the fuzz test passes its own bound)
-    assert stats["ties"] <= max_ties, stats
+    # (round 6: the proven near-ties of the vseg GATE count here too -- measured 1 - 2 per 524 288 corpus frames together -- so
+    # the bound grows with the sweep: 2 up to 262 144 frames, n / 131 072 beyond)
+    assert stats["ties"] <= max(max_ties, n // 131072), stats
     assert stats["expiry_seg_diff"] == 0 and stats["expiry_slash_flips"] == 0 and stats["max_expiry_err"] <= 1e-4, stats
     assert stats["expiry_frames"] >= min_expiry_frames, stats
 
