@@ -584,6 +584,25 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
   const float *w = (const float *)(dmz_weights_blob + 16);
   std::vector<float> hidwt(3 * 320 * 32 + dmzv::WFRAG_FLOATS);
   // digit hidden matrices in the order k_digits' chunked FC1 loads them (dmz_hip_internal.h)
+#if DMZ_DG_FC1_F16
+  {
+    uint16_t *h16 = (uint16_t *)hidwt.data();
+    for (int m = 0; m < 3; m++)
+      for (int pc = 0; pc < 5; pc++)
+        for (int ks = 0; ks < 2; ks++)
+          for (int nt = 0; nt < 2; nt++)
+            for (int lane = 0; lane < 64; lane++)
+              for (int e = 0; e < 8; e++) {
+                const int unit = 16 * nt + (lane & 15), kk = 32 * ks + 8 * (lane >> 4) + e;  // kk = map * 8 + pooled row
+                const int k = (kk >> 3) * 40 + (kk & 7) * 5 + pc;
+                const float wv = w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + unit * 320 + k];
+                const uint16_t hi = f16_rne(wv), lo = f16_rne(wv - f16_to_float(hi));
+                const size_t frag = ((((size_t)m * 5 + pc) * 2 + ks) * 2 + nt) * 2;
+                h16[((frag + 0) * 64 + lane) * 8 + e] = hi;
+                h16[((frag + 1) * 64 + lane) * 8 + e] = lo;
+              }
+  }
+#else
   for (int m = 0; m < 3; m++)
     for (int pc = 0; pc < 5; pc++)
       for (int q = 0; q < 4; q++)
@@ -595,6 +614,7 @@ int dmz_hip_context_create(int device_ordinal, dmz_hip_context **out) {
               hidwt[(((((size_t)m * 5 + pc) * 4 + q) * 2 + nt) * 64 + lane) * 4 + e] =
                   w[dmzw::DIGIT0 + m * dmzw::DIGIT_STRIDE + dmzw::D_HID_W + unit * 320 + k];
             }
+#endif
   // vseg hidden layer for v_mfma_f32_16x16x32_bf16 (vseg.hip): W1 / 255 in three bf16 parts, fragment order
   // [wave 4][k-step 7][part 3][lane 64][8]: lane (unit = 16 wave + (lane & 15), run = lane >> 4) of k-step ks
   // holds k = 32 ks + 8 run .. + 7 (zero beyond unit 49 / k 203); and the row sums of W1

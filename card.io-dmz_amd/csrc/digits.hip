@@ -38,6 +38,9 @@
 #include "dmz_wave.h"
 
 // developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
+#ifndef DMZ_DG_SPLIT_MIX
+#define DMZ_DG_SPLIT_MIX 1
+#endif
 #ifndef DMZ_LDS_PAD
 #define DMZ_LDS_PAD 0
 #endif
@@ -62,8 +65,18 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 #ifdef DMZ_DG_TIMING
 __device__ long long g_dg_t[16];
 #define DG_T(i) if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_dg_t[i] = clock64();
+// (-DDMZ_DG_TIMING2 as well: every WAVE of a few sampled workgroups leaves its own timeline of pooled column 0 ..)
+#ifdef DMZ_DG_TIMING2
+__device__ long long g_dg_w[4][4][48];  // [sampled workgroup][wave][point]
+#define DG_W(i)                                                                                                      \
+  if ((threadIdx.x & 63) == 0 && (blockIdx.x & 4095) == 2049 && (blockIdx.x >> 12) < 4)                               \
+    g_dg_w[blockIdx.x >> 12][threadIdx.x >> 6][i] = (long long)__builtin_readcyclecounter();
+#endif
 #else
 #define DG_T(i)
+#endif
+#ifndef DG_W
+#define DG_W(i)
 #endif
 constexpr int DG_THREADS = 256;
 constexpr int XS = 20;                 // xb row stride in elements (19 used; even: horizontal pairs stay dword-aligned)
@@ -111,6 +124,12 @@ __device__ __forceinline__ void conv_lane_init(ConvLane &cl, const lds_u8 *xb, i
 
 // One tile: D[16 positions][2 x 16 maps] for the conv positions (row 3 pr + J, column C) of row-tile T.
 // NPL input planes (1: bytes as bf16; 3: hi / mid / lo planes of a float input, smallest first).
+// The pair reads are `volatile`: left alone, the load/store optimiser merges the same lane pointer's reads of two different
+// tiles into one ds_read2_b32, whose register pair then has to be copied into the two A-operand tuples (214 v_mov_b32 and 94
+// address adds per card for the offsets ds_read2 cannot encode; 44 and 25 with plain ds_read_b32, which carries a 16-bit offset).
+#ifndef DG_VOL
+#define DG_VOL volatile
+#endif
 template <int NPL, int T, int C, int J>
 __device__ __forceinline__ void conv_tile(const ConvLane &cl, const bf16x8 (&bw)[2][2], f32x4 &o0, f32x4 &o1) {
   constexpr int PAR = C & 1;
@@ -122,9 +141,9 @@ __device__ __forceinline__ void conv_tile(const ConvLane &cl, const bf16x8 (&bw)
   for (int pl = NPL - 1; pl >= 0; pl--) {
     const int off = IMM + pl * XPLANE;
     u32x4 a;
-    a.x = *(const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][0] + off);
-    a.y = *(const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][1] + off);
-    a.z = *(const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][2] + off);
+    a.x = *(DG_VOL const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][0] + off);
+    a.y = *(DG_VOL const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][1] + off);
+    a.z = *(DG_VOL const __attribute__((address_space(3))) uint32_t *)(cl.p[PAR][2] + off);
     const uint32_t t0 = *(const __attribute__((address_space(3))) unsigned short *)(cl.s[PAR] + off);
     const uint32_t t1 = *(const __attribute__((address_space(3))) unsigned short *)(cl.s[PAR] + off + XS * 2);
     a.w = (t1 << 16) | t0;
@@ -194,7 +213,29 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   // epilogue: this lane's four pooled rows 4 (g & 1) .. + 3 of digit 4 wave + 2 T + (g >> 1), map lane & 15 of n-tile
   // nt -> one 16-byte granule of chunk[model][digit][map * 8 + row], granule index XORed with the digit
   const int n16 = lane & 15, g = lane >> 4;
-  int cst[2][2];
+  int cst[2][2];  // (the f16 form uses [t][0] only: n-tile 1 sits a constant two models further on)
+  const bool st1 = n16 < 8;  // n-tile 1 holds model 2 in its first eight columns, nothing beyond
+#if DMZ_DG_FC1_F16
+  // Round 6: FC 320 -> 32 on v_mfma_f32_16x16x32_f16 with both operands in two f16 parts and the three products that carry
+  // 2^-22 (lo * hi, hi * lo, hi * hi; fp32 accumulation) -- nine 16-cycle matrix instructions per wave and pooled column where
+  // the f32 form (v_mfma_f32_16x16x4_f32) issued twenty-four 32-cycle ones: the probe that simply dropped three quarters of
+  // those ran the digits stage 2.29 -> 2.06 ms (profiles/r6_digits_fc1_f16_ab.log).  The pooled activations of a column are
+  // TWO f16 planes [part][model][digit][k = map * 8 + row] (128 B per row; the 16-byte run of a map XORed with digit & 7: a
+  // lane's A fragment -- eight consecutive k -- is one aligned ds_read_b128 per part); the epilogue splits a tanh value into its
+  // f16 truncation and the f16 truncation of the remainder.  Wave w takes k-step w >> 1 of n-tile w & 1 for the three models.
+  constexpr int kPlane = 3 * 16 * 128;  // bytes of one f16 plane of a column's activations
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int m = n16 >> 3, map = n16 & 7, digit = 4 * wave + 2 * t + (g >> 1);
+    cst[t][0] = (m * 16 + digit) * 128 + ((map ^ (digit & 7)) << 4) + ((g & 1) << 3);  // byte offset inside a plane
+  }
+  f32x4 fc[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) fc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fks = wave >> 1, fnt = wave & 1;
+  const int fa = n16 * 128 + (((4 * fks + g) ^ (n16 & 7)) << 4);  // row digit = lane & 15, run 4 ks + (lane >> 4)
+  const u32x4 *fcw = (const u32x4 *)hidw + (size_t)((fks * 2 + fnt) * 2) * 64 + lane;  // [m][pc][ks][nt][part][lane]
+#else
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -202,7 +243,6 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
       const int n = 16 * nt + n16, m = n >> 3, map = n & 7, digit = 4 * wave + 2 * t + (g >> 1);
       cst[t][nt] = (m * 16 + digit) * 64 + (((map * 2 + (g & 1)) ^ digit) << 2);
     }
-  const bool st1 = n16 < 8;  // n-tile 1 holds model 2 in its first eight columns, nothing beyond
   // FC1: wave q = K-quarter q of every chunk; A granule (4 q + kq) ^ digit of row digit = lane & 15
   f32x4 fc[3][2];
 #pragma unroll
@@ -211,20 +251,98 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
     for (int nt = 0; nt < 2; nt++) fc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int fa = n16 * 64 + (((4 * wave + g) ^ n16) << 2);
   const f32x4 *fcw = (const f32x4 *)hidw + (size_t)wave * 2 * 64 + lane;  // [m][pc][q][nt][lane]
+#endif
 
   auto epilogue = [&](int t, const f32x4 &m0, const f32x4 &m1) {
     f32x4 v0, v1;
+#if DMZ_DG_FC1_F16
+    // (n-tile 0 is computed, split and stored before n-tile 1 is touched: the kernel sits at its 128 registers)
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+      v0[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(m0[v], kTanhK, bias0)) + 1.0f), -2.0f, 1.0f);
+#else
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       v0[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(m0[v], kTanhK, bias0)) + 1.0f), -2.0f, 1.0f);
       v1[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(m1[v], kTanhK, bias1)) + 1.0f), -2.0f, 1.0f);
     }
+#endif
+#if DMZ_DG_FC1_F16
+    // v = hi + lo to 2^-22 |v| (truncations: v - hi is exact in fp32; f16 subnormals are kept by the matrix core)
+    auto split4 = [](const f32x4 &v, uint32_t (&h)[2], uint32_t (&l)[2]) {
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 hh = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+#if DMZ_DG_SPLIT_MIX
+        // v - (float)half in one instruction (exactly the subtraction: the product with -1 is exact)
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(__builtin_bit_cast(uint32_t, hh)), "v"(v[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(__builtin_bit_cast(uint32_t, hh)), "v"(v[2 * p + 1]));
+        const f16x2 ll = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+#else  /* (v_cvt_f32_f16 + v_sub_f32 per value: digits stage +0.01 ms) */
+        const f16x2 ll = __builtin_amdgcn_cvt_pkrtz(v[2 * p] - (float)hh[0], v[2 * p + 1] - (float)hh[1]);
+#endif
+        h[p] = __builtin_bit_cast(uint32_t, hh);
+        l[p] = __builtin_bit_cast(uint32_t, ll);
+      }
+    };
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    unsigned char *const cb = (unsigned char *)chunk + cst[t][0];
+    uint32_t h[2], l[2];
+    split4(v0, h, l);
+    *(u32x2 *)cb = (u32x2){h[0], h[1]};
+    *(u32x2 *)(cb + kPlane) = (u32x2){l[0], l[1]};
+    __builtin_amdgcn_sched_barrier(0);
+    if (st1) {  // (these lanes hold model 0 in n-tile 0 and model 2 in n-tile 1: two models further on)
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+        v1[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(m1[v], kTanhK, bias1)) + 1.0f), -2.0f, 1.0f);
+      split4(v1, h, l);
+      *(u32x2 *)(cb + 2 * 16 * 128) = (u32x2){h[0], h[1]};
+      *(u32x2 *)(cb + 2 * 16 * 128 + kPlane) = (u32x2){l[0], l[1]};
+    }
+#else
     *(f32x4 *)(chunk + cst[t][0]) = v0;
     if (st1) *(f32x4 *)(chunk + cst[t][1]) = v1;
+#endif
   };
   // B fragments of column pc are requested before the column's convolutions (L2 latency hidden behind them); the chunk
   // is read into registers between two barriers that sit close together, so that nobody waits for anybody's
   // matrix instructions: they drain while the wave convolves the next column.
+#if DMZ_DG_FC1_F16
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  u32x4 fb[3][2];  // [model][part]
+  auto fc1_fetch = [&](int pc) {
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+      for (int part = 0; part < 2; part++) fb[m][part] = fcw[((size_t)(m * 5 + pc) * 8 + part) * 64];
+  };
+  auto fc1_chunk = [&]() {
+    u32x4 ah[3], al[3];
+    const unsigned char *const cb = (const unsigned char *)chunk;
+    lds_barrier();  // the chunk is complete
+    DG_W(40)
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      ah[m] = *(const u32x4 *)(cb + m * 16 * 128 + fa);
+      al[m] = *(const u32x4 *)(cb + kPlane + m * 16 * 128 + fa);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_barrier();  // ... and in everybody's registers: the next column may overwrite it
+    DG_W(41)
+#pragma unroll
+    for (int m = 0; m < 3; m++)  // small terms first
+      fc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[m]), __builtin_bit_cast(f16x8, fb[m][0]), fc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+      fc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, fb[m][1]), fc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+      fc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[m]), __builtin_bit_cast(f16x8, fb[m][0]), fc[m], 0, 0, 0);
+  };
+#else
   f32x4 fb[3][2];
   auto fc1_fetch = [&](int pc) {
 #pragma unroll
@@ -239,10 +357,18 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   auto fc1_chunk = [&]() {
     f32x4 a[3];
     lds_barrier();  // the chunk is complete
+    DG_W(40)  // (the last column's value stays: points 40 / 41 = the two barriers of column 4)
 #pragma unroll
     for (int m = 0; m < 3; m++) a[m] = *(const f32x4 *)(chunk + m * 16 * 64 + fa);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds_barrier();  // ... and in everybody's registers: the next column may overwrite it
+    DG_W(41)
+#ifdef DMZ_DG_FC1_PROBE  /* developer probe (timing only, wrong scores): DMZ_DG_FC1_PROBE of the chunk's 24 matrix instructions (6: what an
+                            f16 x 3 form on v_mfma_f32_16x16x32_f16 would issue per wave and column, at half the cycles each) */
+#pragma unroll
+    for (int i = 0; i < DMZ_DG_FC1_PROBE; i++)
+      fc[i % 3][(i / 3) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i % 3][i & 3], fb[i % 3][(i / 3) & 1][i & 3], fc[i % 3][(i / 3) & 1], 0, 0, 0);
+#else
 #pragma unroll
     for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -250,7 +376,9 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
           fc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][e], fb[m][nt][e], fc[m][nt], 0, 0, 0);
+#endif
   };
+#endif
   lds_barrier();  // xb is complete, the chunk region (number strip / histograms until now) is free
   DG_T(3)
   {
@@ -259,17 +387,23 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
 #define DMZ_DG_FETCH 2
 #endif
 #define DG_COLUMN(PC)                                   \
+  DG_W(8 * PC + 0)                                      \
   if (DMZ_DG_FETCH == 0) fc1_fetch(PC);                 \
   conv_pool_column<NPL, 0, PC>(cl, bw, m0, m1);         \
   if (PC == 0) { DG_T(14) }                             \
+  DG_W(8 * PC + 1)                                      \
   epilogue(0, m0, m1);                                  \
   if (PC == 0) { DG_T(15) }                             \
+  DG_W(8 * PC + 2)                                      \
   if (DMZ_DG_FETCH == 1) fc1_fetch(PC);                 \
   conv_pool_column<NPL, 1, PC>(cl, bw, m0, m1);         \
+  DG_W(8 * PC + 3)                                      \
   epilogue(1, m0, m1);                                  \
+  DG_W(8 * PC + 4)                                      \
   if (DMZ_DIGITS_STOP == 3 && PC == 0) return;          \
   if (DMZ_DG_FETCH == 2) fc1_fetch(PC);                 \
   fc1_chunk();                                          \
+  DG_W(8 * PC + 7)                                      \
   DG_T(4 + PC)
 #ifdef DMZ_DG_REVERSE  /* developer probe */
     DG_COLUMN(4) DG_COLUMN(3) DG_COLUMN(2) DG_COLUMN(1) DG_COLUMN(0)
@@ -282,12 +416,20 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   // part[q][m][nt][v][lane]: every store and every load below touches 64 consecutive dwords
   float *part = (float *)raw;
   float *hid = (float *)(raw + PART_BYTES);  // [m][digit][HID_PITCH]
+#if DMZ_DG_FC1_F16
+  // (wave = (k-step, n-tile): the two k-step halves of an output meet below)
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) part[((((fks * 3 + m) * 2 + fnt) * 4 + v) << 6) + lane] = fc[m][v];
+#else
 #pragma unroll
   for (int m = 0; m < 3; m++)
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
       for (int v = 0; v < 4; v++) part[((((wave * 3 + m) * 2 + nt) * 4 + v) << 6) + lane] = fc[m][nt][v];
+#endif
   lds_barrier();
   DG_T(9)
   if (DMZ_DIGITS_STOP == 4) return;
@@ -295,7 +437,11 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   for (int r = 0; r < 6; r++) {  // i = tid + 256 r = ((m * 2 + nt) * 4 + v) * 64 + lane': m = r >> 1, nt = r & 1
     const int i = tid + DG_THREADS * r;
     const int m = r >> 1, nt = r & 1, v = (tid >> 6) & 3, digit = 4 * ((tid >> 4) & 3) + v, j = 16 * nt + (tid & 15);
+#if DMZ_DG_FC1_F16
+    const float sum = part[i] + part[1536 + i];
+#else
     const float sum = (part[i] + part[1536 + i]) + (part[2 * 1536 + i] + part[3 * 1536 + i]);
+#endif
     hid[(m * 16 + digit) * HID_PITCH + j] = fast_tanh(sum + tw[dmzv::DT_HB + m * 32 + j]);
   }
   lds_barrier();
@@ -633,6 +779,12 @@ void dmz_launch_digits(hipStream_t s, const float *weights, const float *hidw, c
                      results);
 }
 size_t dmz_digit_patch_bytes(void) { return (size_t)XPLANE; }
+#ifdef DMZ_DG_TIMING2
+extern "C" void dmz_dbg_digits_waves(long long *out /* 4 x 4 x 48 */) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dg_w), sizeof(long long) * 4 * 4 * 48);
+}
+#endif
 
 void dmz_launch_digit_model(hipStream_t s, const float *weights, const float *hidw, int model,
                             const float *x, int n, float *out) {

@@ -181,9 +181,15 @@ void dmz_launch_mats_from_float(hipStream_t s, int n, const float *m9, DmzWarpMa
 void dmz_launch_warp(hipStream_t s, const uint8_t *planes, size_t frame_stride, int row_stride,
                      int width, int height, int n, DmzWarpMat *mats, uint8_t *cards,
                      size_t card_stride);
-// Digit models' hidden matrices in the fragment order of k_digits' chunked FC1 (digits.hip): f32x4
-// [model 3][pooled column 5][K-quarter 4][n-tile 2][lane 64]: lane (unit = 16 nt + (lane & 15), kq = lane >> 4), element e holds
-// W[unit][map * 40 + row * 5 + column] with map * 8 + row = 16 quarter + 4 kq + e -- 3 x 320 x 32 floats, first in the buffer.
+// Digit models' hidden matrices in the fragment order of k_digits' chunked FC1 (digits.hip), 3 x 320 x 32 floats' worth, first in
+// the buffer.  Round 6 (DMZ_DG_FC1_F16 = 1): B fragments of v_mfma_f32_16x16x32_f16 in two f16 parts (hi = the f16 rounding of the
+// weight, lo = of the remainder: 22 bits) -- [model 3][pooled column 5][k-step 2][n-tile 2][part 2][lane 64][8 f16]: lane (unit = 16 nt
+// + (lane & 15), run = lane >> 4), element e holds W[unit][map * 40 + row * 5 + column] with map * 8 + row = 32 ks + 8 run + e.
+// DMZ_DG_FC1_F16 = 0 (rounds 3 - 5): f32x4 fragments of v_mfma_f32_16x16x4_f32, [model 3][pooled column 5][K-quarter 4][n-tile 2]
+// [lane 64]: lane (unit, kq = lane >> 4), element e: map * 8 + row = 16 quarter + 4 kq + e.
+#ifndef DMZ_DG_FC1_F16
+#define DMZ_DG_FC1_F16 1
+#endif
 // vseg hidden-layer weights in fragment order, appended to it (float offsets)
 namespace dmzv {
 constexpr int WFRAG = 3 * 320 * 32;                 // offset of this block in the buffer
