@@ -80,12 +80,21 @@ __device__ long long g_dg_w[4][4][48];  // [sampled workgroup][wave][point]
 #endif
 constexpr int DG_THREADS = 256;
 constexpr int XS = 20;                 // xb row stride in elements (19 used; even: horizontal pairs stay dword-aligned)
-constexpr int XD = 27 * XS;            // elements per digit
-constexpr int XPLANE = 16 * XD * 2;    // bytes of one bf16 plane of the 16 digits: 17,280
+// Elements per digit: 27 rows + 4 elements of padding = 272 dwords.  The LDS serves a half-wave (32 lanes) per cycle over 32 banks.
+// The sixteen (digit, pooled row) addresses of a conv read lie 30 dwords (three rows) apart over the eight pooled rows -- the
+// even banks 0, 30, .., 18 -- and one digit = D dwords apart: at D = 270 (= 14 mod 32) the second digit's rows sit on 14, 12,
+// .., 0 and bank 0 is hit twice: EVERY conv read took two passes (SQ_LDS_BANK_CONFLICT 41 % of SQ_LDS_IDX_ACTIVE, the LDS 78 %
+// busy: it, not the VALU, paced the kernel).  D = 16 mod 32 puts the second digit on the other eight even banks; lane group 3's
+// reads (21 / 19 / 9 / -1 dwords beside the others') and the 16-bit singles (one dword beside) fall on the odd banks.
+#ifndef DMZ_DG_XPAD
+#define DMZ_DG_XPAD 4
+#endif
+constexpr int XD = 27 * XS + DMZ_DG_XPAD;  // elements per digit
+constexpr int XPLANE = 16 * XD * 2;    // bytes of one bf16 plane of the 16 digits: 17,408
 constexpr int CHUNK_BYTES = 3 * 16 * 64 * 4;  // pooled activations of one pooled column: [model][digit][map 8 x row 8]
 constexpr int PART_BYTES = 4 * 3 * 16 * 32 * 4;  // FC1 partial sums of the four waves
 constexpr int HID_PITCH = dmzv::DT_PITCH;     // floats per row of the hidden activations / of the logistic weights
-constexpr int DG_RAW = 31616;                 // xb + chunk (29,568 B), partial sums + hidden activations (31,488 B)
+constexpr int DG_RAW = 31616;                 // xb + chunk (29,696 B), partial sums + hidden activations (31,488 B)
 constexpr int DG_TAILW = dmzv::DT_FLOATS * 4; // 7,488 B
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. every
@@ -477,10 +486,10 @@ __device__ __forceinline__ float digit_softmax(const float *__restrict__ prob, i
   return pp[c] / sum;
 }
 
-constexpr int DG_LDS = XPLANE + CHUNK_BYTES;  // 29,568 B
+constexpr int DG_LDS = XPLANE + CHUNK_BYTES;  // 29,696 B
 static_assert(PART_BYTES + 3 * 16 * HID_PITCH * 4 <= DG_RAW && DG_LDS <= DG_RAW, "partial sums + hidden activations overlay xb and the chunk");
 
-// k_digit_patches: the equalised digit patches of a card, as bf16 numbers, [16 digits][27][20] (17,280 B per card in a
+// k_digit_patches: the equalised digit patches of a card, as bf16 numbers, [16 digits][27][20] + 4 (17,408 B per card in a
 // scratch buffer; column 19 and the sixteenth digit of a 15-digit number are never written: whatever finite values they
 // hold meet zero weights / are never read back).  Its own kernel because this phase is short chains of LDS round trips
 // that need nothing but occupancy (64 registers, 19 KB: 32 waves per CU), which the CNN kernel (128 registers) cannot give.
