@@ -502,6 +502,9 @@ constexpr int DP_LDS = STRIP_BYTES + HIST_BYTES;  // 19,760 B: eight workgroups 
 #ifndef DMZ_DP_WGS
 #define DMZ_DP_WGS 8
 #endif
+#ifndef DMZ_DP_HROT  /* rotation of histogram copy q, in dwords per q (0: the round 3 - 5 layout) */
+#define DMZ_DP_HROT 8
+#endif
 #ifndef DMZ_DP_STOP  /* developer ablation: k_digit_patches returns after phase k */
 #define DMZ_DP_STOP 99
 #endif
@@ -587,7 +590,9 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
 #pragma unroll
         // value v -> byte v >> 6 of dword v & 63: neighbouring VALUES (neighbouring lanes see similar gradients) fall into
         // different dwords / banks; only equal values, or values 64 apart, still meet in one counter word
-        for (int k = 0; k < 9; k++) atomicAdd(&hc[gv[dj][k] & 63], 1u << ((gv[dj][k] >> 6) * 8));
+        // (the four copies are 64 dwords = two trips round the 32 banks apart, so copy q keeps its counters rotated by 8 q dwords:
+        // the lanes of a half-wave that see similar values then spread over four bank octets instead of queueing on one)
+        for (int k = 0; k < 9; k++) atomicAdd(&hc[(gv[dj][k] + DMZ_DP_HROT * (lane & 3)) & 63], 1u << ((gv[dj][k] >> 6) * 8));
       }
     __builtin_amdgcn_wave_barrier();
     if (DMZ_DP_STOP == 3) return;
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(DG_THREADS, DMZ_DP_WGS) void k_digit_patches(const 
       unsigned int ev = 0u, od = 0u;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const unsigned int cq = hq[(dj * 4 + q) * 64 + lane];
+        const unsigned int cq = hq[(dj * 4 + q) * 64 + ((lane + DMZ_DP_HROT * q) & 63)];
         ev += cq & 0x00FF00FFu;         // {count(l), count(l + 128)}
         od += (cq >> 8) & 0x00FF00FFu;  // {count(l + 64), count(l + 192)}
       }
