@@ -38,6 +38,9 @@
 #include "dmz_wave.h"
 
 // developer ablation (tools/ablate.sh): extra dynamic LDS per workgroup = fewer workgroups per CU
+#ifndef DMZ_DG_NT1_MERGE
+#define DMZ_DG_NT1_MERGE 1
+#endif
 #ifndef DMZ_DG_SPLIT_MIX
 #define DMZ_DG_SPLIT_MIX 1
 #endif
@@ -206,7 +209,9 @@ __device__ __forceinline__ void conv_weights_load(ConvWeights &cw, const float *
     for (int nt = 0; nt < 2; nt++) cw.bw[par][nt] = __builtin_bit_cast(bf16x8, bf[(par * 2 + nt) * 64 + lane]);
   // tanh(m + b) = 1 - 2 / (exp2(k m + k b) + 1), k = 2 log2(e): the bias enters the exponent's fma
   cw.bias0 = kTanhK * hidw[dmzv::WFRAG + dmzv::DCONV_BIAS + (lane & 15)];
-  cw.bias1 = kTanhK * hidw[dmzv::WFRAG + dmzv::DCONV_BIAS + 16 + (lane & 15)];
+  // (n-tile 1 has eight maps: lanes 8 - 15 of a row hold the bias of map lane & 7 as well -- they receive the other row-tile's
+  // values of that map when the two tiles' halves are merged, digits_cnn)
+  cw.bias1 = kTanhK * hidw[dmzv::WFRAG + dmzv::DCONV_BIAS + 16 + (lane & 7)];
 }
 
 template <int NPL>
@@ -223,7 +228,7 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   // nt -> one 16-byte granule of chunk[model][digit][map * 8 + row], granule index XORed with the digit
   const int n16 = lane & 15, g = lane >> 4;
   int cst[2][2];  // (the f16 form uses [t][0] only: n-tile 1 sits a constant two models further on)
-  const bool st1 = n16 < 8;  // n-tile 1 holds model 2 in its first eight columns, nothing beyond
+  [[maybe_unused]] const bool st1 = n16 < 8;  // n-tile 1 holds model 2 in its first eight columns, nothing beyond
 #if DMZ_DG_FC1_F16
   // Round 6: FC 320 -> 32 on v_mfma_f32_16x16x32_f16 with both operands in two f16 parts and the three products that carry
   // 2^-22 (lo * hi, hi * lo, hi * hi; fp32 accumulation) -- nine 16-cycle matrix instructions per wave and pooled column where
@@ -262,6 +267,15 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
   const f32x4 *fcw = (const f32x4 *)hidw + (size_t)wave * 2 * 64 + lane;  // [m][pc][q][nt][lane]
 #endif
 
+#if DMZ_DG_FC1_F16 && DMZ_DG_NT1_MERGE
+  // n-tile 1 carries eight maps in sixteen columns: the upper half of every row of lanes would run its tanh, split and stores on
+  // nothing.  Row-tile 0's n-tile-1 maxima wait for row-tile 1's, which move eight lanes up (one DPP move per register) into
+  // the idle half; one tanh / split / store pass then serves both.  cstm: where a lane's merged values go.
+  f32x4 m1keep = {0.f, 0.f, 0.f, 0.f};
+  // (one DPP move with every lane active, lanes 0 - 7 of a row keeping their own: a DPP read of a lane that EXEC has switched off
+  // returns nothing)
+  const int cstm = __builtin_amdgcn_update_dpp(cst[0][0], cst[1][0], 0x118 /* row_shr:8 */, 0xf, 0xc /* lanes 8 - 15 */, false) + 2 * 16 * 128;
+#endif
   auto epilogue = [&](int t, const f32x4 &m0, const f32x4 &m1) {
     f32x4 v0, v1;
 #if DMZ_DG_FC1_F16
@@ -303,6 +317,27 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
     *(u32x2 *)cb = (u32x2){h[0], h[1]};
     *(u32x2 *)(cb + kPlane) = (u32x2){l[0], l[1]};
     __builtin_amdgcn_sched_barrier(0);
+#if DMZ_DG_NT1_MERGE
+    if (t == 0) {
+      m1keep = m1;
+    } else {
+      f32x4 mm;
+#pragma unroll
+      for (int v = 0; v < 4; v++)  // lanes 8 - 15 of a row: row-tile 1's value of lane - 8; lanes 0 - 7 keep row-tile 0's
+      {
+        const float keep = m1keep[v], come = m1[v];
+        mm[v] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(come), 0x118 /* row_shr:8 */, 0xf,
+                                                           0xc /* banks 2, 3 */, false));
+      }
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+        v1[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(mm[v], kTanhK, bias1)) + 1.0f), -2.0f, 1.0f);
+      split4(v1, h, l);
+      unsigned char *const cm = (unsigned char *)chunk + cstm;
+      *(u32x2 *)cm = (u32x2){h[0], h[1]};
+      *(u32x2 *)(cm + kPlane) = (u32x2){l[0], l[1]};
+    }
+#else
     if (st1) {  // (these lanes hold model 0 in n-tile 0 and model 2 in n-tile 1: two models further on)
 #pragma unroll
       for (int v = 0; v < 4; v++)
@@ -311,6 +346,7 @@ __device__ __forceinline__ void digits_cnn(const float *__restrict__ wts, const 
       *(u32x2 *)(cb + 2 * 16 * 128) = (u32x2){h[0], h[1]};
       *(u32x2 *)(cb + 2 * 16 * 128 + kPlane) = (u32x2){l[0], l[1]};
     }
+#endif
 #else
     *(f32x4 *)(chunk + cst[t][0]) = v0;
     if (st1) *(f32x4 *)(chunk + cst[t][1]) = v1;
