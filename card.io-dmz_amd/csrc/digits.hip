@@ -27,11 +27,16 @@
 //     tile and selects one of two K layouts) and two 16-bit reads -- no conversion, one v_lshl_or to pack.
 //     The max-pool is an elementwise max over the nine tiles of a pool window (v_max3_f32), bias and
 //     tanh run on the accumulators: 8 instead of ~400 VALU instructions per 16 positions x 24 maps.
-//   * FC 320->32 on v_mfma_f32_16x16x4_f32, accumulated per pooled column: the pooled activations of one
-//     column (16 digits x 3 models x 8 maps x 8 rows = 12 KB, XOR-swizzled 16-byte granules) are all
-//     that ever exists in LDS; wave q multiplies K-quarter q of the chunk into its six accumulators
-//     (3 models x 2 tiles of 16 hidden units), the four partial sums meet in LDS at the end.
+//   * FC 320->32 accumulated per pooled column: the pooled activations of one column (16 digits x 3 models x 8 maps x 8 rows
+//     = 12 KB, XOR-swizzled 16-byte runs) are all that ever exists in LDS.  Rounds 3 - 5: v_mfma_f32_16x16x4_f32, wave q
+//     multiplying K-quarter q into six accumulators.  Round 6: v_mfma_f32_16x16x32_f16 with both operands in two f16 parts
+//     (three products, 2^-22; the epilogue writes the tanh values as hi / lo f16 planes), wave w = k-step w >> 1 of n-tile
+//     w & 1 -- nine 16-cycle matrix instructions per wave and column instead of twenty-four 32-cycle ones that, being fp32,
+//     share the VALU's multipliers and overlap with nothing (profiles/r6_mfma_valu_overlap_probe.log).
 //   * hidden tanh, FC 32->10, softmax, vote, arg-max and the usable gate as before.
+//   * Round 6, LDS banks (32 banks, a half-wave per cycle): the digit stride is 272 dwords, not 270 -- at 270 the sixteen
+//     (digit, pooled row) addresses of EVERY conv read met two-way on one bank (XD below); n-tile 1's two half-empty row-tiles
+//     share one tanh / split / store pass.
 #include <float.h>
 
 #include "dmz_hip_internal.h"
