@@ -33,7 +33,8 @@ META = {
     "k_vseg": ("vseg.hip", "a13-a18", "28", "~13 000: row features ~60 per row-wave (38 packed-u16 gradient + 18 for the two wave reductions), A operands 0.5 per feature, tanh + 50->3 layer 2 500, scans + norms + softmax 3 000"),
     "k_hseg": ("hseg.hip", "a19-a20", "16", "~4 400: cross gradient 1 900, score table 560, five table-score batches 1 300, the winner's ordered sum 600"),
     "k_digit_patches": ("digits.hip", "a21-a22", "32", "~2 200: 5 per pixel gradient x 36 px per lane + LUT scan"),
-    "k_digits": ("digits.hip", "a23", "16", "~4 900 (1 210 per wave): 90 tile packs, 320 v_max3 for the nine-tile max-pool, 160 tanh x 5; FC1 / tail 250"),
+    "k_digits": ("digits.hip", "a23", "16", "~4 600 (1 150 per wave; round 6): 90 tile packs, 320 v_max3 for the nine-tile max-pool, 140 tanh x 5 "
+                 "(n-tile 1's row-tiles merged), 70 f16 splits x 3, 20 DPP moves; tail 250"),
     "k_expiry_stripes": ("expiry.hip", "a25", "32", "- (HBM: 92 scattered 428-byte rows per card)"),
     "k_expiry_seg": ("expiry.hip", "a25", "12", "- (data-dependent list logic; + the library-order emulation on 19 % of the stripes)"),
     "k_expiry_cat": ("expiry.hip", "a26", "12", "- (MFMA-paced: conv1 A operands 24 per tile, epilogues 56 per tile)"),
@@ -48,7 +49,7 @@ CEILING = {
     "warp": (39500, "cvWarpPerspective's fp64 association per pixel (6 fp64 for a filtered-exact coordinate pair: reciprocal by extrapolation + Newton, two fma) + 12 integer for the 5-bit bilinear blend from four byte taps; 3.7 per pixel of per-wave set-up"),
     "vseg": (13000, "408-column row features with two wave reductions per row (float min / max / sum in the reference's order), exact bf16 operand splits for the hidden layer"),
     "hseg": (4400, "428-term sequential float sums per candidate (bit-exact `hseg_score`), the reference's four passes"),
-    "digits": (7100, "5-tap cross gradient + exact 256-bin equalisation per digit; nine-tile max-pool and 160 tanh per wave on the CNN side"),
+    "digits": (6800, "5-tap cross gradient + exact 256-bin equalisation per digit; nine-tile max-pool, 140 tanh and the f16 split of their values per wave on the CNN side"),
     "expiry_seg": (None, "data-dependent list logic in the reference's visiting order (incl. the `std::sort` tie order on 19 % of the stripes); round 6 removed the work that was not needed (lazy trimming)"),
     "expiry_cat": (None, "MFMA-paced: operand builds (24 per conv1 tile) and epilogues (56 per tile) around f16 x 3 products that keep 1e-5"),
 }
