@@ -12,6 +12,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int SHAPE>
 __device__ __forceinline__ void mm(f32x4 &acc, f16x8 a, f16x8 b) {
@@ -58,6 +59,63 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float *out) {
   if (s == 123.456f) out[0] = s;
 }
 
+// the same for v_mfma_f32_32x32x16_f16 (8 passes; two independent 16-register accumulators)
+template <int VOP, int NM, int NV>
+__device__ __forceinline__ void body32(f32x16 (&acc)[2], float (&x)[8], f16x8 a, f16x8 b, float c) {
+  constexpr int N = NM > 0 ? NM : 1, PER = NM > 0 ? NV / NM : NV;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    if (NM > 0) acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j & 1], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PER; q++) vv<VOP>(x[(j * PER + q) & 7], c);
+  }
+}
+template <int VOP, int NM, int NV>
+__global__ __launch_bounds__(512) void k32(int mode, int iters, float *out) {
+  f32x16 acc[2];
+  float x[8];
+  for (int i = 0; i < 2; i++)
+    for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+  for (int i = 0; i < 8; i++) x[i] = threadIdx.x * 1e-3f + i;
+  f16x8 a, b;
+  for (int i = 0; i < 8; i++) a[i] = (_Float16)(threadIdx.x & 3), b[i] = (_Float16)1;
+  const float c = 0.999f;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  if (mode == 0) for (int it = 0; it < iters; it++) body32<VOP, NM, 0>(acc, x, a, b, c);
+  else if (mode == 1) for (int it = 0; it < iters; it++) body32<VOP, 0, NV>(acc, x, a, b, c);
+  else if (mode == 2) for (int it = 0; it < iters; it++) body32<VOP, NM, NV>(acc, x, a, b, c);
+  else if (role == 0) for (int it = 0; it < iters; it++) body32<VOP, 2 * NM, 0>(acc, x, a, b, c);
+  else for (int it = 0; it < iters; it++) body32<VOP, 0, 2 * NV>(acc, x, a, b, c);
+  float s = 0;
+  for (int i = 0; i < 2; i++)
+    for (int e = 0; e < 16; e++) s += acc[i][e];
+  for (int i = 0; i < 8; i++) s += x[i];
+  if (s == 123.456f) out[0] = s;
+}
+template <int VOP, int NM, int NV>
+static float run32(int mode, int waves_per_simd, float *out) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+  const int grid = 256 * waves_per_simd / 2, iters = 20000;
+  k32<VOP, NM, NV><<<grid, 512>>>(mode, iters, out);
+  (void)hipEventRecord(e0);
+  k32<VOP, NM, NV><<<grid, 512>>>(mode, iters, out);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e6f / iters;
+}
+template <int VOP, int NM, int NV>
+static void line32(const char *name, float *out) {
+  for (int w = 2; w <= 4; w *= 2) {
+    const float m = run32<VOP, NM, NV>(0, w, out), v = run32<VOP, NM, NV>(1, w, out);
+    const float i = run32<VOP, NM, NV>(2, w, out), s = run32<VOP, NM, NV>(3, w, out);
+    printf("%s  %d waves/SIMD, per wave and iteration %2d matrix + %3d VALU:  M %6.0f ns (%.1f ns per instruction and SIMD)  V %6.0f ns (%.2f)  "
+           "I %6.0f  S %6.0f   [max %6.0f, sum %6.0f]\n", name, w, NM, NV, m, m / (w * NM), v, v / (w * NV), i, s, m > v ? m : v, m + v);
+  }
+}
+
 template <int SHAPE, int VOP, int NM, int NV>
 static float run(int mode, int waves_per_simd, float *out) {
   hipEvent_t e0, e1;
@@ -96,5 +154,10 @@ int main() {
   line<1, 0, 8, 64>("16x16x4 f32  + v_fma_f32 ", out);
   line<1, 0, 8, 128>("16x16x4 f32  + v_fma_f32 ", out);
   line<1, 1, 8, 64>("16x16x4 f32  + v_max3_f32", out);
+  // the same matrix work in half as many instructions of twice the size
+  line32<0, 4, 32>("32x32x16 f16 + v_fma_f32 ", out);
+  line32<0, 4, 64>("32x32x16 f16 + v_fma_f32 ", out);
+  line32<0, 4, 128>("32x32x16 f16 + v_fma_f32 ", out);
+  line32<1, 4, 64>("32x32x16 f16 + v_max3_f32", out);
   return 0;
 }
